@@ -1,0 +1,505 @@
+"""TEST INFRASTRUCTURE ONLY — the parity oracle.  Nothing under die_amd/ may import this.
+
+A float64 numpy/scipy CPU restatement of the reference's grid-update hot path
+(gkirgizov/die): `Env.step` field dynamics, `PhysarumAgent` / `GradientAgent` /
+`BrownianAgent` / `ConstAgent` `.forward`, and the `DataInitializer` allocation.
+Each function cites the reference lines it follows (paths relative to the
+reference checkout).  xarray label lookups are replaced by the index arithmetic
+they resolve to; every random draw is an explicit argument (see oracle/rng.py).
+
+PARITY STATUS: *partially pinned*.  The reference has no test, golden vector or
+fixture on this path (test/unit/agent.py covers core/agent/evo.py only) and cannot be
+imported here (xarray / skimage / gymnasium / perlin_noise / evotorch are absent —
+ordinary ModuleNotFoundError).  What pins this file:
+  * `cell()`                 == pandas `Index.get_indexer(method='nearest')`, the call
+                                xarray's `.sel(method='nearest')` resolves to (tests/test_oracle_pins.py)
+  * `diffuse_decay()`        calls scipy.ndimage.gaussian_filter — the function
+                                skimage.filters.gaussian wraps — and is cross-checked with explicit weights
+  * pure-numpy helper bodies (`renormalize_radians`, `discretize`, `polar2xy`, `xy2polar`,
+    `PhysarumAgent._choose_turn/_discrete_turn`, `GradientAgent._process_momentum`,
+    `DataInitializer._mask/get_random`, `Env._agent_move_handle_boundary`,
+    `WaveSequence.__getitem__`) were executed from the reference's own files in the build
+    container and their outputs committed as tests/golden/ref_helpers.npz
+    (script: tests/golden/make_ref_helper_vectors.py); the oracle is checked against them.
+The xarray-dependent glue of `Env.step` / `forward` itself stays unpinned by reference
+output; it is pinned by analytic known-answer tests only (tests/test_oracle_kat.py).
+"""
+from dataclasses import dataclass, field as dc_field
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+import scipy.ndimage
+
+from . import rng as orng
+
+# core/base_types.py:31-36
+MEDIUM_CHANNELS = ('agents', 'env_food', 'chem1')
+AGENT_CHANNELS = ('x', 'y', 'alive', 'agent_food')
+ACTION_CHANNELS = ('dx', 'dy', 'deposit1')
+M_AGENTS, M_FOOD, M_CHEM = 0, 1, 2
+A_X, A_Y, A_ALIVE, A_FOOD = 0, 1, 2, 3
+U_DX, U_DY, U_DEP = 0, 1, 2
+
+
+# --------------------------------------------------------------------------------------
+# helpers: core/utils.py:154-183
+# --------------------------------------------------------------------------------------
+def polar2xy(r, theta):
+    """core/utils.py:154-165 (r·e^{iθ} → real, imag)."""
+    z = r * np.exp(1j * np.asarray(theta))
+    return np.real(z), np.imag(z)
+
+
+def xy2polar(x, y):
+    """core/utils.py:158-169."""
+    z = np.asarray(x) + 1j * np.asarray(y)
+    return np.abs(z), np.angle(z)
+
+
+def get_radians(coords):
+    """core/utils.py:172-175."""
+    return xy2polar(coords[0], coords[1])[1]
+
+
+def renormalize_radians(rads):
+    """core/utils.py:178-180: into (-pi, pi]."""
+    return (rads - np.pi) % (-2 * np.pi) + np.pi
+
+
+def discretize(value, step):
+    """core/utils.py:183-184."""
+    return (value // step) * step
+
+
+def cell(v, n: int) -> np.ndarray:
+    """Nearest grid index of coordinate v on labels linspace(0, 1, n): what
+    `field.sel(x=v, method='nearest')` resolves to (core/utils.py:39-54 → pandas
+    `get_indexer(method='nearest')`): ties go to the larger index, out-of-range clamps."""
+    return np.clip(np.floor(np.asarray(v, dtype=np.float64) * (n - 1) + 0.5), 0, n - 1).astype(np.int64)
+
+
+def gaussian_weights(sigma: float, truncate: float = 4.0) -> np.ndarray:
+    """scipy.ndimage._gaussian_kernel1d (order 0): radius int(truncate*sigma + .5)."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    w = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return w / w.sum()
+
+
+# --------------------------------------------------------------------------------------
+# Env: core/env.py
+# --------------------------------------------------------------------------------------
+def linear_action_cost(action: np.ndarray, weights=(0.02, 0.01)) -> np.ndarray:
+    """core/env.py:29-35."""
+    dist = np.linalg.norm(action[[U_DX, U_DY]], axis=0)
+    return weights[0] * np.abs(action[U_DEP]) + weights[1] * dist
+
+
+def zero_cost(action: np.ndarray) -> np.ndarray:
+    """core/env.py:38-39."""
+    return np.zeros(action.shape[1:])
+
+
+@dataclass
+class RefDynamics:
+    """core/env.py:42-61."""
+    op_action_cost: Callable = linear_action_cost
+    op_food_flow: Callable = dc_field(default=lambda x: x)
+    rate_feed: float = 0.1
+    rate_decay_chem: float = 0.1
+    boundary: str = 'wrap'           # BoundaryCondition value: 'wrap' | 'limit' | anything else = pass-through
+    diffuse_mode: str = 'wrap'
+    diffuse_sigma: float = .5
+    apply_sense_mask: bool = False
+    strict_cost: bool = True
+    food_infinite: bool = False
+    agents_die: bool = False
+    agents_born: bool = False
+    init_agent_ratio: float = 0.1
+
+
+def move_handle_boundary(coords: np.ndarray, boundary: str) -> np.ndarray:
+    """core/env.py:152-161."""
+    if boundary == 'wrap':
+        return coords % 1.
+    if boundary == 'limit':
+        return coords.clip(0., 1.)
+    return coords
+
+
+def diffuse_decay(chem: np.ndarray, sigma: float, decay: float, mode: str = 'wrap') -> np.ndarray:
+    """core/env.py:136-145: skimage.filters.gaussian(preserve_range=True) is
+    scipy.ndimage.gaussian_filter(truncate=4.0) on a float image; then ×(1−decay)."""
+    out = scipy.ndimage.gaussian_filter(np.asarray(chem, dtype=np.float64), sigma=sigma, mode=mode, truncate=4.0)
+    out *= (1. - decay)
+    return out
+
+
+def diffuse_decay_explicit(chem: np.ndarray, sigma: float, decay: float) -> np.ndarray:
+    """Same as diffuse_decay(mode='wrap') with the separable weights written out:
+    axis 0 then axis 1, periodic with period W / H."""
+    w = gaussian_weights(sigma)
+    r = len(w) // 2
+    out = np.asarray(chem, dtype=np.float64)
+    for axis in (0, 1):
+        acc = np.zeros_like(out)
+        for k in range(-r, r + 1):
+            acc += w[k + r] * np.roll(out, -k, axis=axis)
+        out = acc
+    return out * (1. - decay)
+
+
+class RefEnv:
+    """core/env.py:64-311 on plain arrays: medium (3, W, H) f64, agents (4, N) f64."""
+
+    def __init__(self, medium: np.ndarray, agents: np.ndarray, dynamics: Optional[RefDynamics] = None):
+        self.medium = np.array(medium, dtype=np.float64)
+        self.agents = np.array(agents, dtype=np.float64)
+        self.dynamics = dynamics or RefDynamics()
+        assert self.medium.ndim == 3 and self.medium.shape[0] == 3
+        assert self.agents.ndim == 2 and self.agents.shape[0] == 4
+        self.last_gained = None
+
+    @property
+    def field_size(self) -> Tuple[int, int]:
+        return self.medium.shape[1], self.medium.shape[2]
+
+    # core/utils.py:26-54
+    def cells_of(self, xy: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+        W, H = self.field_size
+        return cell(xy[0], W), cell(xy[1], H)
+
+    def alive_index(self) -> np.ndarray:
+        """core/utils.py:67-75."""
+        return (self.agents[A_ALIVE] > 0).nonzero()[0]
+
+    @property
+    def num_alive(self) -> int:
+        return int(self.alive_index().shape[0])
+
+    def agent_move(self, action: np.ndarray):
+        """core/env.py:163-172 — every slot, dead ones too."""
+        self.agents[[A_X, A_Y]] = move_handle_boundary(self.agents[[A_X, A_Y]] + action[[U_DX, U_DY]],
+                                                       self.dynamics.boundary)
+
+    def agent_deposit_and_layout(self, action: np.ndarray):
+        """core/env.py:204-215.  `.loc[cells] += deposit` is get–add–set with fancy
+        indices: on a shared cell the LAST alive slot in index order wins."""
+        idx = self.alive_index()
+        ix, iy = self.cells_of(self.agents[[A_X, A_Y]][:, idx])
+        deposit = action[U_DEP, idx]
+        chem = self.medium[M_CHEM]
+        chem[ix, iy] = chem[ix, iy] + deposit
+        self.medium[M_AGENTS] = 0
+        self.medium[M_AGENTS][ix, iy] = 1.
+
+    def agent_feed(self, action: np.ndarray) -> np.ndarray:
+        """core/env.py:220-243."""
+        d = self.dynamics
+        food = self.medium[M_FOOD]
+        consumed_field = d.rate_feed * food * (self.medium[M_AGENTS] > 0)
+        ix, iy = self.cells_of(self.agents[[A_X, A_Y]])          # all N slots (only_alive=False)
+        consumed = consumed_field[ix, iy]
+        if not d.food_infinite:
+            self.medium[M_FOOD] = food - consumed_field
+        burned = d.op_action_cost(action)
+        gained = consumed - burned
+        self.agents[A_FOOD] += gained
+        return gained
+
+    def agent_lifecycle(self):
+        """core/env.py:245-261.  Intended semantics (zero the slots without food).  The
+        reference rebinds self.agents here while AgentIndexer keeps the old array
+        (core/utils.py:22) — that stale-indexer bug is deliberately not reproduced."""
+        if self.dynamics.agents_die:
+            have_food = self.agents[A_FOOD] > 1e-4
+            self.agents = np.where(have_food, self.agents, 0.)
+
+    def medium_resource_dynamics(self):
+        """core/env.py:147-150."""
+        self.medium[M_FOOD] = self.dynamics.op_food_flow(self.medium[M_FOOD])
+
+    def medium_diffuse_decay(self):
+        d = self.dynamics
+        self.medium[M_CHEM] = diffuse_decay(self.medium[M_CHEM], d.diffuse_sigma, d.rate_decay_chem, d.diffuse_mode)
+
+    def sense_mask(self) -> np.ndarray:
+        """core/env.py:276-290 (skimage default mode for gaussian is 'nearest')."""
+        a = self.medium[M_AGENTS]
+        if self.dynamics.apply_sense_mask:
+            return np.ceil(scipy.ndimage.gaussian_filter(a, sigma=2.0, mode='nearest', truncate=4.0).round(3))
+        return np.ones_like(a)
+
+    @property
+    def obs(self):
+        """core/env.py:292-298."""
+        return self.agents, np.where(self.sense_mask().astype(bool), self.medium, 0.)
+
+    def step(self, action: np.ndarray):
+        """core/env.py:101-131."""
+        action = np.asarray(action, dtype=np.float64)
+        self.agent_move(action)
+        self.agent_deposit_and_layout(action)
+        gained = self.agent_feed(action)
+        self.agent_lifecycle()
+        self.medium_resource_dynamics()
+        self.medium_diffuse_decay()
+        self.last_gained = gained
+        num_agents = self.num_alive
+        reward = float(gained.sum())
+        mean_gain = reward / num_agents if num_agents > 0 else 0.
+        info = {'num_agents': num_agents, 'reward': np.round(reward, 3), 'mean_reward': np.round(mean_gain, 5)}
+        return self.obs, reward, num_agents == 0, False, info
+
+
+# --------------------------------------------------------------------------------------
+# Agents: core/agent/gradient.py, core/agent/static.py
+# --------------------------------------------------------------------------------------
+def gradient_field(chem: np.ndarray, normalized: bool = True, grad_clip: Optional[float] = 1e-5) -> np.ndarray:
+    """core/agent/gradient.py:55-71: np.gradient (central, one-sided at the edges, NOT
+    periodic), optional normalisation with 0/0 → 0, mask of norms below grad_clip."""
+    grad = np.stack(np.gradient(np.asarray(chem, dtype=np.float64)))
+    norm = np.sqrt(grad[0] ** 2 + grad[1] ** 2)
+    if normalized:
+        with np.errstate(divide='ignore', invalid='ignore'):
+            grad = np.nan_to_num(np.true_divide(grad, norm))
+    if grad_clip is not None:
+        grad = grad * (norm >= grad_clip)
+    return grad
+
+
+class RefGradientAgent:
+    """core/agent/gradient.py:13-135.  `init_noise` (2, N) replaces the unseeded
+    `default_rng().normal(0, .4)` of :50-53; `noise` per forward likewise."""
+
+    def __init__(self, max_agents: int, scale=0.01, deposit=4.0, inertia=0.9, sense_offset=0.,
+                 noise_scale=0.025, normalized_grad=True, grad_clip=1e-5, init_noise: Optional[np.ndarray] = None,
+                 seed: int = 0):
+        self._size = max_agents
+        self._seed = seed
+        self._calls = 0
+        self._noise_scale = noise_scale
+        self._scale = scale
+        self._deposit = deposit
+        self._inertia = inertia
+        self._sense_offset_scale = sense_offset
+        self._normalized = normalized_grad
+        self._grad_clip = grad_clip
+        if init_noise is None:
+            init_noise = orng.normals2(seed, 0, max_agents, orng.STREAM_INIT_HEADING)
+        self._prev_grad = np.array(init_noise, dtype=np.float64)
+        self._direction_rads = get_radians(self._prev_grad)
+        self._render_grad = None
+
+    def _process_gradient(self, grad, turn_sign):
+        return grad
+
+    def _process_momentum(self, grad, noise):
+        """:82-91."""
+        grad = (1 - self._inertia) * grad + self._inertia * self._prev_grad
+        grad = grad + self._noise_scale * noise
+        self._prev_grad = grad
+        return grad
+
+    def _process_deposit(self, sensed_food):
+        return self._deposit * sensed_food
+
+    def forward(self, obs, turn_sign: Optional[np.ndarray] = None, noise: Optional[np.ndarray] = None) -> np.ndarray:
+        """:96-124.  No alive masking: every slot senses and acts."""
+        agents, medium = obs
+        N = agents.shape[1]
+        W, H = medium.shape[1:]
+        step = self._calls
+        self._calls += 1
+        if turn_sign is None:
+            turn_sign = orng.turn_signs(self._seed, step, N)
+        if noise is None:
+            noise = orng.normals2(self._seed, step + 1, N, orng.STREAM_NOISE) if self._noise_scale != 0 \
+                else np.zeros((2, N))
+        action = np.zeros((3, N))
+        grad_field = gradient_field(medium[M_CHEM], self._normalized, self._grad_clip)
+        off = np.stack(polar2xy(self._sense_offset_scale, self._direction_rads))          # :73-76
+        px, py = cell(agents[A_X] + off[0], W), cell(agents[A_Y] + off[1], H)             # clamped, not wrapped
+        g = grad_field[:, px, py]
+        g = self._process_gradient(g, turn_sign)
+        g = self._process_momentum(g, noise)
+        self._direction_rads = get_radians(g)
+        self._render_grad = grad_field
+        sensed_food = medium[M_FOOD][cell(agents[A_X], W), cell(agents[A_Y], H)]
+        action[[U_DX, U_DY]] = g * self._scale
+        action[U_DEP] = self._process_deposit(sensed_food)
+        return action
+
+
+class RefPhysarumAgent(RefGradientAgent):
+    """core/agent/gradient.py:138-219."""
+
+    def __init__(self, max_agents: int, scale=0.005, deposit=4.0, inertia=0.0, sense_offset=0.03,
+                 noise_scale=0.0, normalized_grad=True, grad_clip=1e-5, turn_angle=30, sense_angle=90,
+                 turn_tolerance=0.1, init_noise=None, seed: int = 0):
+        super().__init__(max_agents, scale, deposit, inertia, sense_offset, noise_scale, normalized_grad,
+                         grad_clip, init_noise, seed)
+        self._turn_radians = np.radians(turn_angle)
+        self._sense_radians = np.radians(sense_angle)
+        self._rtol = turn_tolerance
+        self._direction_rads = discretize(get_radians(self._prev_grad), self._turn_radians)
+        self._deposit_mask = 1.
+        self.last_undetermined = None
+
+    def _choose_turn(self, drads, turn_sign):
+        """:168-193."""
+        dir_delta = renormalize_radians(self._direction_rads - drads)
+        atol = self._turn_radians * self._rtol
+        undetermined_grad = np.isclose(0, drads, rtol=1e-5)
+        undetermined_turn = np.isclose(0, dir_delta, rtol=1e-2, atol=atol)
+        unseen_grad = np.abs(dir_delta) > self._sense_radians
+        undetermined = undetermined_grad | undetermined_turn | unseen_grad
+        dir_delta = dir_delta * np.logical_not(undetermined)
+        turn = np.array(turn_sign, dtype=np.float64)
+        turn[dir_delta > atol] = -1
+        turn[dir_delta < -atol] = 1
+        turn *= self._turn_radians
+        self._deposit_mask = np.logical_not(undetermined_grad | undetermined_turn)
+        self.last_undetermined = undetermined
+        return turn
+
+    def _process_gradient(self, grad, turn_sign):
+        """:195-208,216-219."""
+        dr, drads = xy2polar(grad[0], grad[1])
+        turn = self._choose_turn(drads, turn_sign)
+        directions = renormalize_radians(self._direction_rads + turn)
+        dr = 1. if self._normalized else dr
+        return np.stack(polar2xy(dr, directions))
+
+    def _process_deposit(self, sensed_food):
+        """:210-214."""
+        mask = np.clip(self._deposit_mask, 0.1, 1.0)
+        return self._deposit * sensed_food * mask
+
+
+class RefBrownianAgent:
+    """core/agent/static.py:31-50 with DataInitializer.action_for/with_noise/build_agents
+    (core/data_init.py:159-169,218-220,248-253): `(b-a)*u.round(3)+a`, times alive."""
+
+    def __init__(self, move_scale=0.01, deposit_scale=0.5, seed: int = 0):
+        self._scale = move_scale
+        self._dep_scale = deposit_scale
+        self._seed = seed
+        self._calls = 0
+
+    def forward(self, obs, units=None) -> np.ndarray:
+        agents, _ = obs
+        N = agents.shape[1]
+        if units is None:
+            units = orng.brownian_units(self._seed, self._calls, N)
+        self._calls += 1
+        s = self._scale
+        u = [np.asarray(q) / 1000.0 for q in units]
+        data = np.stack([(s - -s) * u[0] + -s, (s - -s) * u[1] + -s, (self._dep_scale - 0.) * u[2] + 0.])
+        return data * agents[A_ALIVE]
+
+
+class RefConstAgent:
+    """core/agent/static.py:9-28."""
+
+    def __init__(self, delta_xy, deposit=0.):
+        self._data = (delta_xy[0], delta_xy[1], deposit)
+
+    def forward(self, obs) -> np.ndarray:
+        agents, _ = obs
+        action = np.zeros((3, agents.shape[1]))
+        for c in range(3):
+            action[c] = self._data[c]
+        return action
+
+
+# --------------------------------------------------------------------------------------
+# Allocation: core/data_init.py
+# --------------------------------------------------------------------------------------
+def mask_range(sampled: np.ndarray, mask_below=0.0, mask_above=1.0) -> np.ndarray:
+    """core/data_init.py:181-185."""
+    return sampled * ((mask_below <= sampled) & (sampled <= mask_above))
+
+
+def agents_channel_from_uniform(u_round3: np.ndarray, ratio: float) -> np.ndarray:
+    """core/data_init.py:222-226: ceil(u·[0 ≤ u ≤ ratio])."""
+    return np.ceil(mask_range(u_round3, mask_above=ratio))
+
+
+def agents_from_medium(medium: np.ndarray, food_u_round3: np.ndarray, max_agents: Optional[int] = None,
+                       food_ratio: float = 1.0) -> np.ndarray:
+    """core/data_init.py:133-150 + core/utils.py:140-151: occupied cells in row-major
+    order fill slots [0, K): x = linspace(0,1,W)[ix], y likewise, alive = 1,
+    agent_food = (food_ratio − 0.1)·u.round(3) + 0.1; the rest is zero."""
+    W, H = medium.shape[1:]
+    ix, iy = (medium[M_AGENTS] > 0).nonzero()
+    K = ix.shape[0]
+    xs, ys = np.linspace(0, 1, W), np.linspace(0, 1, H)
+    if not max_agents:
+        max_agents = W * H
+    agents = np.zeros((4, max_agents))
+    agents[A_X, :K] = xs[ix]
+    agents[A_Y, :K] = ys[iy]
+    agents[A_ALIVE, :K] = 1.
+    agents[A_FOOD, :K] = (food_ratio - 0.1) * np.asarray(food_u_round3)[:K] + 0.1
+    return agents
+
+
+@dataclass
+class FoodSpec:
+    """Synthetic stand-in for the un-vendored `perlin_noise` food field
+    (core/data_init.py:190-196,228-231): a sum of torus-periodic sinusoids with the
+    positive half kept (≈50 % zeros, max ≈ amp), rounded to 3 decimals like the reference."""
+    fx: np.ndarray
+    fy: np.ndarray
+    phase: np.ndarray
+    amp: np.ndarray
+    scale: float = 0.5
+
+    @staticmethod
+    def from_seed(seed: int, n_waves: int = 6, max_freq: int = 5, scale: float = 0.5) -> 'FoodSpec':
+        r = orng._draw(seed, 0, np.arange(n_waves, dtype=np.uint64), orng.STREAM_INIT_FOOD)
+        fx = (r[0] % np.uint32(2 * max_freq + 1)).astype(np.int64) - max_freq
+        fy = (r[1] % np.uint32(max_freq)).astype(np.int64) + 1
+        phase = r[2].astype(np.float64) * (2 * np.pi / 4294967296.0)
+        amp = 0.5 + r[3].astype(np.float64) / 4294967296.0
+        amp = amp / amp.sum()
+        return FoodSpec(fx.astype(np.float64), fy.astype(np.float64), phase, amp, scale)
+
+    def field(self, W: int, H: int) -> np.ndarray:
+        x = (np.arange(W, dtype=np.float64) / W)[:, None]
+        y = (np.arange(H, dtype=np.float64) / H)[None, :]
+        s = np.zeros((W, H))
+        for fx, fy, ph, a in zip(self.fx, self.fy, self.phase, self.amp):
+            s += a * np.sin(2 * np.pi * (fx * x + fy * y) + ph)
+        # the waves sum to at most 1 in magnitude; stretch so typical peaks reach `scale`
+        s = np.clip(2.0 * self.scale * s, 0., self.scale)
+        return np.round(s, 3)
+
+
+def synthetic_init(W: int, H: int, ratio: float, seed: int, max_agents: Optional[int] = None):
+    """Env._init_data (core/env.py:74-86) with synthetic food; returns (medium, agents)."""
+    C = W * H
+    u = orng.uniform_round3(seed, 0, C, orng.STREAM_INIT_AGENTS).reshape(W, H)
+    medium = np.zeros((3, W, H))
+    medium[M_AGENTS] = agents_channel_from_uniform(u, ratio)
+    medium[M_FOOD] = FoodSpec.from_seed(seed).field(W, H)
+    K = int((medium[M_AGENTS] > 0).sum())
+    fu = orng.uniform_round3(seed, 0, K, orng.STREAM_INIT_AGENT_FOOD)
+    agents = agents_from_medium(medium, fu, max_agents)
+    return medium, agents
+
+
+def wave_field(W: int, H: int, t: float) -> np.ndarray:
+    """core/data_init.py:71-89 WaveSequence.__getitem__ (grid from core/utils.py:113-118:
+    meshgrid of the reversed sizes, so grid[0] varies along the last axis)."""
+    xcs = [np.linspace(0., 1., num=size) for size in reversed((W, H))]
+    grid = np.stack(np.meshgrid(*xcs))
+    pi = np.pi
+    x, y = (grid - 0.5) * 2
+    r = np.linalg.norm((x, y), axis=0)
+    rwave = r + np.cos(pi * x) + np.sin(0.4 * pi * y)
+    z_waves = np.cos(1 * pi * (rwave + t))
+    z_islands = (np.sin(pi * x * 3 + t) + np.cos(pi * y * 3 + t))
+    mix = 0.25
+    return (1 - mix) * z_waves + mix * z_islands

@@ -1,0 +1,155 @@
+"""Analytic known-answer tests of the oracle's Env.step / forward glue (SURVEY §8c list):
+the part of the path no reference-made vector pins."""
+import numpy as np
+
+from oracle import cpu_ref as R
+
+
+def _env(W=6, H=6, agents_xy=(), alive=None, food=0.0, chem=0.0, N=None, **dyn):
+    medium = np.zeros((3, W, H))
+    medium[R.M_FOOD] = food
+    medium[R.M_CHEM] = chem
+    K = len(agents_xy)
+    N = N or max(K, 1)
+    agents = np.zeros((4, N))
+    for k, (x, y) in enumerate(agents_xy):
+        agents[:, k] = [x, y, 1. if alive is None else alive[k], 0.5]
+    return R.RefEnv(medium, agents, R.RefDynamics(**dyn))
+
+
+def test_cell_table():
+    assert list(R.cell([0., 0.1, 0.1 + 1e-12, 0.5, 1., -3., 9.], 6)) == [0, 1, 1, 3, 5, 0, 5]
+    assert list(R.cell([0.0999], 6)) == [0]          # 0.0999*5+.5 = .9995
+    assert list(R.cell([0.3], 6)) == [2]             # tie 0.3*5 = 1.5 → larger index
+
+
+def test_move_wraps_all_slots_including_dead():
+    e = _env(agents_xy=[(0.9, 0.1), (0.2, 0.95)], alive=[1, 0])
+    act = np.array([[0.2, -0.3], [-0.2, 0.1], [0., 0.]])
+    e.agent_move(act)
+    assert np.allclose(e.agents[:2], [[0.1, 0.9], [0.9, 0.05]])
+    e2 = _env(agents_xy=[(0.9, 0.1)], boundary='limit')
+    e2.agent_move(np.array([[0.2], [-0.2], [0.]]))
+    assert np.allclose(e2.agents[:2, 0], [1.0, 0.0])
+
+
+def test_last_writer_wins_on_collision_and_layout():
+    # slots 0,1,3 share cell (1,1); slot 2 is elsewhere; slot 4 is dead on the shared cell
+    xy = [(0.2, 0.2), (0.21, 0.19), (0.8, 0.6), (0.2, 0.21), (0.2, 0.2)]
+    e = _env(agents_xy=xy, alive=[1, 1, 1, 1, 0], chem=1.0)
+    act = np.zeros((3, 5))
+    act[R.U_DEP] = [10., 20., 30., 40., 50.]
+    e.agent_deposit_and_layout(act)
+    chem = e.medium[R.M_CHEM]
+    assert chem[1, 1] == 1.0 + 40.          # highest ALIVE slot wins, no accumulation, dead ignored
+    assert chem[4, 3] == 1.0 + 30.
+    assert chem.sum() == 36 + 70.
+    a = e.medium[R.M_AGENTS]
+    assert a.sum() == 2 and a[1, 1] == 1 and a[4, 3] == 1
+
+
+def test_feed_duplicates_on_shared_cells_and_dead_slots_consume():
+    xy = [(0.2, 0.2), (0.2, 0.2), (0.8, 0.6), (0.2, 0.2), (0.6, 0.0)]
+    e = _env(agents_xy=xy, alive=[1, 1, 1, 0, 0], food=0.5)
+    act = np.zeros((3, 5))
+    act[:, 0] = [0.003, 0.004, 2.0]
+    e.agent_deposit_and_layout(act)
+    gained = e.agent_feed(act)
+    burned0 = 0.02 * 2.0 + 0.01 * 0.005
+    # both co-located alive agents AND the dead slot on the occupied cell get the full .05
+    assert np.allclose(gained, [0.05 - burned0, 0.05, 0.05, 0.05, 0.0])
+    food = e.medium[R.M_FOOD]
+    assert np.isclose(food[1, 1], 0.45) and np.isclose(food[4, 3], 0.45) and np.isclose(food[3, 0], 0.5)
+    assert np.isclose(food.sum(), 36 * 0.5 - 2 * 0.05)     # the field loses it once per cell
+    e2 = _env(agents_xy=xy[:1], food=0.5, food_infinite=True)
+    e2.agent_deposit_and_layout(act[:, :1])
+    e2.agent_feed(act[:, :1])
+    assert (e2.medium[R.M_FOOD] == 0.5).all()
+
+
+def test_gaussian_impulse_on_torus_corner():
+    chem = np.zeros((6, 6))
+    chem[0, 0] = 1.0
+    out = R.diffuse_decay(chem, 0.5, 0.1)
+    w = R.gaussian_weights(0.5)
+    k = np.zeros(6)
+    for i, o in enumerate(range(-2, 3)):
+        k[o % 6] += w[i]
+    assert np.allclose(out, 0.9 * np.outer(k, k), rtol=1e-13)
+    assert np.isclose(out.sum(), 0.9)                        # mass × (1 − decay)
+
+
+def test_step_reward_counts_every_slot_and_info():
+    xy = [(0.2, 0.2), (0.8, 0.6)]
+    e = _env(agents_xy=xy, food=0.5, N=5)                    # 3 dead slots at (0,0), unoccupied cell
+    act = np.zeros((3, 5))
+    act[R.U_DX] = 0.02                                       # dead slots move and burn too
+    obs, reward, term, trunc, info = e.step(act)
+    want = 2 * 0.05 - 5 * 0.01 * 0.02
+    assert np.isclose(reward, want)
+    assert info == {'num_agents': 2, 'reward': np.round(want, 3), 'mean_reward': np.round(want / 2, 5)}
+    assert term is False and trunc is False
+    assert np.allclose(e.agents[R.A_X], [0.22, 0.82, 0.02, 0.02, 0.02])
+    assert obs[1].shape == (3, 6, 6) and obs[1] is not e.medium
+
+
+def test_physarum_forward_probe_clamps_and_deposit_mask():
+    W = H = 8
+    N = 3
+    medium = np.zeros((3, W, H))
+    medium[R.M_CHEM] = np.add.outer(np.arange(W) ** 2, np.zeros(H)) * 0.1     # gradient along +x
+    medium[R.M_FOOD] = 0.25
+    agents = np.zeros((4, N))
+    agents[:, 0] = [0.5, 0.5, 1, 1]
+    agents[:, 1] = [0.98, 0.5, 1, 1]      # probe beyond the edge → clamped to the last row (one-sided grad)
+    agents[:, 2] = [0.5, 0.5, 0, 0]       # dead slot still acts
+    a = R.RefPhysarumAgent(N, scale=0.01, sense_offset=0.2, init_noise=np.array([[1., 1., 1.], [1e-3, 1e-3, -1.]]))
+    assert np.allclose(a._direction_rads, [0., 0., -np.pi / 6 * 2])           # floor(angle/30°)·30°
+    act = a.forward((agents, medium), turn_sign=np.array([1., -1., 1.]))
+    # gradient direction is exactly +x → drads == 0 → "undetermined gradient": random turn, mask .1
+    assert np.allclose(a._direction_rads, [np.pi / 6, -np.pi / 6, -np.pi / 6], atol=1e-12)
+    assert np.allclose(act[R.U_DEP], 4.0 * 0.25 * 0.1)
+    assert np.allclose(np.hypot(act[0], act[1]), 0.01)
+
+
+def test_physarum_turn_truth_table():
+    N = 6
+    a = R.RefPhysarumAgent(N, init_noise=np.ones((2, N)))
+    a._direction_rads = np.zeros(N)
+    atol = np.radians(30) * 0.1
+    # gradient angle = -delta (delta = dir - drads); cases: inside tol, just outside, left, right, unseen, zero grad
+    drads = np.array([-0.5 * atol, -(atol / 0.99 + 1e-6), -0.5, 0.5, 2.0, 0.0])
+    g = np.stack([np.cos(drads), np.sin(drads)])
+    g[:, 5] = 0
+    sign = np.array([1., 1., 1., 1., -1., -1.])
+    out = a._process_gradient(g, sign)
+    new_dir = np.arctan2(out[1], out[0])
+    t = np.pi / 6
+    assert np.allclose(new_dir, [t, -t, -t, t, -t, -t])
+    assert list(a._deposit_mask) == [False, True, True, True, True, False]
+    assert list(a.last_undetermined) == [True, False, False, False, True, True]
+
+
+def test_brownian_formula_and_alive_mask():
+    agents = np.zeros((4, 4))
+    agents[R.A_ALIVE] = [1, 1, 0, 1]
+    b = R.RefBrownianAgent(move_scale=0.01, deposit_scale=0.5)
+    units = (np.array([0, 1000, 500, 250]), np.array([500, 500, 500, 500]), np.array([0, 1000, 1, 2]))
+    act = b.forward((agents, None), units=units)
+    assert np.allclose(act[0], [-0.01, 0.01, 0, -0.005])
+    assert np.allclose(act[1], 0) and np.allclose(act[2], [0, 0.5, 0, 0.001])
+
+
+def test_agents_from_medium_row_major_and_synthetic_init():
+    medium, agents = R.synthetic_init(16, 12, 0.15, seed=1234)
+    ix, iy = medium[R.M_AGENTS].nonzero()
+    K = len(ix)
+    assert 10 < K < 60 and agents.shape == (4, 16 * 12)
+    assert np.allclose(agents[R.A_X, :K], ix / 15.) and np.allclose(agents[R.A_Y, :K], iy / 11.)
+    assert (agents[R.A_ALIVE, :K] == 1).all() and (agents[:, K:] == 0).all()
+    assert (agents[R.A_FOOD, :K] >= 0.1).all() and (agents[R.A_FOOD, :K] <= 1.0).all()
+    f = medium[R.M_FOOD]
+    assert f.min() == 0 and 0.3 < f.max() <= 0.5 and 0.3 < (f == 0).mean() < 0.7
+    assert np.array_equal(f, np.round(f, 3))
+    _, a2 = R.synthetic_init(16, 12, 0.15, seed=1234, max_agents=K)
+    assert a2.shape == (4, K)
