@@ -1,0 +1,104 @@
+"""ctypes binding of libdie_hip.so (include/die_hip.h).  There is no CPU fallback: if the
+library is missing or does not load, importing this module raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdie_hip.so')
+
+DIE_OK = 0
+DIE_F32, DIE_F16 = 0, 1
+DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
+DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
+DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
+OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
+ABI_VERSION = 1
+
+
+class Medium(C.Structure):
+    _fields_ = [('W', C.c_int32), ('H', C.c_int32), ('dtype', C.c_int32), ('epoch', C.c_int32),
+                ('owner', C.c_void_p), ('food', C.c_void_p), ('chem', C.c_void_p), ('chem_next', C.c_void_p)]
+
+
+class Agents(C.Structure):
+    _fields_ = [('N', C.c_int64), ('x', C.c_void_p), ('y', C.c_void_p), ('alive', C.c_void_p),
+                ('agent_food', C.c_void_p)]
+
+
+class Action(C.Structure):
+    _fields_ = [('N', C.c_int64), ('dx', C.c_void_p), ('dy', C.c_void_p), ('deposit', C.c_void_p)]
+
+
+class Dynamics(C.Structure):
+    _fields_ = [('rate_feed', C.c_float), ('rate_decay_chem', C.c_float), ('diffuse_sigma', C.c_float),
+                ('boundary', C.c_int32), ('cost', C.c_int32), ('cost_w_deposit', C.c_float),
+                ('cost_w_dist', C.c_float), ('food_infinite', C.c_int32), ('agents_die', C.c_int32),
+                ('has_dead_slots', C.c_int32)]
+
+
+class GradientAgent(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('normalized_grad', C.c_int32), ('scale', C.c_float), ('deposit', C.c_float),
+                ('inertia', C.c_float), ('sense_offset', C.c_float), ('noise_scale', C.c_float),
+                ('grad_clip', C.c_float), ('turn_radians', C.c_float), ('sense_radians', C.c_float),
+                ('turn_tolerance', C.c_float), ('reserved', C.c_int32), ('heading', C.c_void_p),
+                ('prev_gx', C.c_void_p), ('prev_gy', C.c_void_p), ('turn_sign', C.c_void_p),
+                ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32)]
+
+
+class FoodSpec(C.Structure):
+    _fields_ = [('n_waves', C.c_int32), ('scale', C.c_float), ('fx', C.c_double * 8), ('fy', C.c_double * 8),
+                ('phase', C.c_double * 8), ('amp', C.c_double * 8)]
+
+
+_P = C.POINTER
+_SIGNATURES = {
+    'die_abi_version': (C.c_int, []),
+    'die_last_error': (C.c_char_p, []),
+    'die_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
+    'die_gradient_forward': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), C.c_void_p]),
+    'die_brownian_forward': (C.c_int, [_P(Agents), C.c_float, C.c_float, C.c_uint64, C.c_uint32, _P(Action),
+                                       C.c_void_p]),
+    'die_const_forward': (C.c_int, [C.c_int64, C.c_float, C.c_float, C.c_float, _P(Action), C.c_void_p]),
+    'die_env_step': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64,
+                               C.c_void_p]),
+    'die_agent_move_claim': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
+                                       C.c_void_p]),
+    'die_agent_resolve': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
+                                    C.c_void_p]),
+    'die_step_reduce': (C.c_int, [_P(Agents), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_diffuse_decay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                    C.c_void_p]),
+    'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),
+    'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f'{LIB_PATH} is missing: build it with `python die_amd/build.py` '
+                          '(hipcc, --offload-arch=gfx950). die_amd has no CPU fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError here = the .so does not match include/die_hip.h
+        fn.restype = res
+        fn.argtypes = args
+    if lib.die_abi_version() != ABI_VERSION:
+        raise ImportError(f'libdie_hip.so ABI {lib.die_abi_version()} != binding ABI {ABI_VERSION}: rebuild')
+    return lib
+
+
+lib = _load()
+
+
+class DieError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = ''):
+    if rc != DIE_OK:
+        msg = lib.die_last_error().decode(errors='replace')
+        if rc == -3:
+            raise NotImplementedError(f'{what}: {msg}')
+        raise DieError(f'{what}: status {rc}: {msg}')

@@ -1,0 +1,126 @@
+"""GradientAgent / PhysarumAgent (reference core/agent/gradient.py:13-219): constructor
+signatures and `forward(obs) -> action` kept; the whole of `forward` is one launch of
+`die_gradient_forward` and the per-agent state (`_direction_rads`, `_prev_grad`) lives in HBM.
+"""
+import ctypes as C
+import math
+import os
+from typing import Any, Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..device_array import DeviceAction, _ptr, stream_ptr
+from .base import Agent, save_args
+
+
+class GradientAgent(Agent):
+    _kind = _lib.DIE_AGENT_GRADIENT
+
+    def __init__(self,
+                 max_agents: int = 10**6,
+                 scale: float = 0.01,
+                 deposit: float = 4.0,
+                 inertia: float = 0.9,
+                 sense_offset: float = 0.,
+                 noise_scale: float = 0.025,
+                 normalized_grad: bool = True,
+                 grad_clip: Optional[float] = 1e-5,
+                 seed: Optional[int] = None,
+                 ):
+        self._init_params = save_args(self.__init__, locals())
+        self._size = int(max_agents)
+        self._seed = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
+        self._noise_scale = noise_scale
+        self._scale = scale
+        self._deposit = deposit
+        self._inertia = inertia
+        self._sense_offset_scale = sense_offset
+        self._normalized = normalized_grad
+        self._grad_clip = grad_clip
+        self._turn_radians = 0.0
+        self._sense_radians = 0.0
+        self._rtol = 0.0
+        self._calls = 0
+        self._direction_rads: Optional[torch.Tensor] = None     # allocated on first forward (needs the device)
+        self._prev_grad: Optional[torch.Tensor] = None
+        self._turn_sign: Optional[torch.Tensor] = None            # test hook: per-slot ±1 instead of Philox
+
+    @property
+    def init_params(self) -> Dict[str, Any]:
+        return self._init_params
+
+    def _alloc_state(self, device):
+        """__init__ state of the reference (:42-43,163): heading from N(0, .4) noise."""
+        self._direction_rads = torch.empty(self._size, dtype=torch.float32, device=device)
+        if self._inertia != 0:
+            self._prev_grad = torch.empty((2, self._size), dtype=torch.float32, device=device)
+        pg = self._prev_grad
+        _lib.check(_lib.lib.die_init_heading(_ptr(self._direction_rads), _ptr(pg[0]) if pg is not None else None,
+                                             _ptr(pg[1]) if pg is not None else None, self._size,
+                                             float(self._turn_radians), self._seed & 0xFFFFFFFFFFFFFFFF,
+                                             stream_ptr(device)), 'die_init_heading')
+
+    def set_state(self, direction_rads: np.ndarray, prev_grad: Optional[np.ndarray] = None, device='cuda:0'):
+        """Load `_direction_rads` (and `_prev_grad`) from host arrays."""
+        self._direction_rads = torch.from_numpy(np.asarray(direction_rads, dtype=np.float32)).to(device)
+        assert self._direction_rads.numel() == self._size
+        if prev_grad is not None:
+            self._prev_grad = torch.from_numpy(np.ascontiguousarray(prev_grad, dtype=np.float32)).to(device)
+        elif self._inertia != 0:
+            self._prev_grad = torch.zeros((2, self._size), dtype=torch.float32, device=device)
+
+    def set_turn_signs(self, signs: Optional[np.ndarray], device='cuda:0'):
+        """Replace the random ±1 turn choice (core/agent/gradient.py:183) by given values."""
+        self._turn_sign = None if signs is None else torch.from_numpy(np.asarray(signs).astype(np.int8)).to(device)
+
+    def forward(self, obs) -> DeviceAction:
+        """:96-124."""
+        agents, medium = obs
+        if agents.N != self._size:
+            raise ValueError(f'agent built for max_agents={self._size}, observation has {agents.N} slots')
+        dev = agents.device
+        if self._direction_rads is None:
+            self._alloc_state(dev)
+        action = DeviceAction(agents.N, dev)
+        pg = self._prev_grad
+        g = _lib.GradientAgent(
+            self._kind, int(bool(self._normalized)), self._scale, self._deposit, self._inertia,
+            self._sense_offset_scale, self._noise_scale, -1.0 if self._grad_clip is None else self._grad_clip,
+            self._turn_radians, self._sense_radians, self._rtol, 0, _ptr(self._direction_rads),
+            _ptr(pg[0]) if pg is not None else None, _ptr(pg[1]) if pg is not None else None,
+            _ptr(self._turn_sign), self._seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF, 0)
+        m, a, u = medium.c_struct(), agents.c_struct(), action.c_struct()
+        _lib.check(_lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(g), C.byref(u), stream_ptr(dev)),
+                   'die_gradient_forward')
+        self._calls += 1
+        return action
+
+    def render(self) -> Sequence[np.ndarray]:
+        return [np.ones((1, 1, 3))]
+
+
+class PhysarumAgent(GradientAgent):
+    _kind = _lib.DIE_AGENT_PHYSARUM
+
+    def __init__(self,
+                 max_agents: int = 10**6,
+                 scale: float = 0.005,
+                 deposit: float = 4.0,
+                 inertia: float = 0.0,
+                 sense_offset: float = 0.03,
+                 noise_scale: float = 0.0,
+                 normalized_grad: bool = True,
+                 grad_clip: Optional[float] = 1e-5,
+                 turn_angle: int = 30,
+                 sense_angle: int = 90,
+                 turn_tolerance: float = 0.1,
+                 seed: Optional[int] = None,
+                 ):
+        super().__init__(max_agents, scale, deposit, inertia, sense_offset, noise_scale, normalized_grad, grad_clip,
+                         seed)
+        self._init_params = save_args(self.__init__, locals())
+        self._turn_radians = math.radians(turn_angle)
+        self._sense_radians = math.radians(sense_angle)
+        self._rtol = turn_tolerance

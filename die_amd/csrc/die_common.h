@@ -1,0 +1,70 @@
+// Shared device/host helpers for libdie_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/die_hip.h"
+
+#define DIE_WAVE 64
+#define DIE_BLOCK 256
+
+void die_set_error(const char* fmt, ...);
+
+#define DIE_REQUIRE(cond, ...)                      \
+    do {                                            \
+        if (!(cond)) {                              \
+            die_set_error(__VA_ARGS__);             \
+            return DIE_ERR_ARG;                     \
+        }                                           \
+    } while (0)
+
+#define DIE_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            die_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return DIE_ERR_HIP;                                                       \
+        }                                                                             \
+    } while (0)
+
+static inline int die_grid_for(int64_t n, int block = DIE_BLOCK) { return (int)((n + block - 1) / block); }
+
+// ---- field element access (f32 / f16 planes) ---------------------------------------------
+__device__ __forceinline__ float die_ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ float die_ld(const __half* p, int64_t i) { return __half2float(p[i]); }
+__device__ __forceinline__ void die_st(float* p, int64_t i, float v) { p[i] = v; }
+__device__ __forceinline__ void die_st(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
+
+// ---- Q0.32 fixed-point coordinates -------------------------------------------------------
+// nearest label of linspace(0, 1, n) to X / 2^32, P may lie outside [0, 2^32) (probe offsets):
+// clamp like pandas get_indexer(method='nearest') does (core/utils.py:39-54).
+__device__ __forceinline__ int die_cell(int64_t P, int n) {
+    int64_t c = (P * (int64_t)(n - 1) + (int64_t)0x80000000LL) >> 32;   // arithmetic shift == floor
+    c = c < 0 ? 0 : c;
+    c = c > (int64_t)(n - 1) ? (int64_t)(n - 1) : c;
+    return (int)c;
+}
+
+// float displacement (fraction of the unit square) → Q0.32 increment
+__device__ __forceinline__ int64_t die_q32(float v) { return (int64_t)__double2ll_rn((double)v * 4294967296.0); }
+
+__device__ __forceinline__ uint32_t die_owner_word(int epoch, int64_t slot) {
+    return ((uint32_t)epoch << DIE_OWNER_EPOCH_SHIFT) | (uint32_t)(slot + 1);
+}
+__device__ __forceinline__ bool die_owner_occupied(uint32_t w, int epoch) {
+    return (w >> DIE_OWNER_EPOCH_SHIFT) == (uint32_t)epoch;
+}
+
+// ---- wave / block reductions -------------------------------------------------------------
+__device__ __forceinline__ double die_wave_sum(double v) {
+#pragma unroll
+    for (int o = DIE_WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, DIE_WAVE);
+    return v;
+}
+__device__ __forceinline__ long long die_wave_sum(long long v) {
+#pragma unroll
+    for (int o = DIE_WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, DIE_WAVE);
+    return v;
+}

@@ -1,0 +1,363 @@
+// Env.step kernels (gfx950) — core/env.py:101-131.
+//
+//   k_move_claim   _agent_move (:163-172) + ownership claim for _agent_deposit_and_layout (:204-215)
+//                  + _agent_feed (:220-243) for alive slots (their own cell is occupied by definition)
+//   k_resolve      winner of each occupied cell writes chem += deposit and food -= rate·food;
+//                  dead slots finish their feed (they consume iff somebody alive owns their cell);
+//                  _agent_lifecycle (:245-261) when agents_die; alive count
+//   k_reduce       fixed-order sum of the per-block partials → die_step_result (deterministic)
+//   k_diffuse      _medium_diffuse_decay (:136-145): separable gaussian, periodic, × (1 − decay)
+//
+// Why two agent passes: every slot on a cell must read the food value from BEFORE the step's
+// consumption (co-located agents each get the full amount, :224-225), so all reads of `food`
+// (pass 1) are separated from the single write per occupied cell (pass 2) by a kernel boundary.
+// "Last writer wins" of the fancy-index assignment at :211 is an atomicMax on the slot id.
+#include "die_common.h"
+
+#define DIE_MAX_PARTIALS 8192
+
+struct StepArgs {
+    int W, H, epoch;
+    int64_t N;
+    uint32_t* owner;
+    void* food;
+    void* chem;
+    uint32_t* x;
+    uint32_t* y;
+    uint8_t* alive;
+    float* agent_food;
+    const float* dx;
+    const float* dy;
+    const float* dep;
+    float rate_feed, w_dep, w_dist;
+    int boundary, cost, food_infinite, agents_die, has_dead;
+    float* stash;          // N floats, only when has_dead
+    double* part_gain;     // gridDim.x doubles
+    long long* part_alive; // gridDim.x
+};
+
+__device__ __forceinline__ float action_cost(const StepArgs& a, float dx, float dy, float dep) {
+    // linear_action_cost (core/env.py:29-35) or zero_cost (:38-39)
+    return a.cost == DIE_COST_LINEAR ? a.w_dep * fabsf(dep) + a.w_dist * sqrtf(dx * dx + dy * dy) : 0.f;
+}
+
+__device__ __forceinline__ void block_sum_store(double g, long long c, double* pg, long long* pc) {
+    __shared__ double sg[DIE_BLOCK / DIE_WAVE];
+    __shared__ long long sc[DIE_BLOCK / DIE_WAVE];
+    g = die_wave_sum(g);
+    c = die_wave_sum(c);
+    const int lane = threadIdx.x & (DIE_WAVE - 1), wv = threadIdx.x / DIE_WAVE;
+    if (lane == 0) { sg[wv] = g; sc[wv] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tg = 0.0;
+        long long tc = 0;
+        for (int i = 0; i < DIE_BLOCK / DIE_WAVE; ++i) { tg += sg[i]; tc += sc[i]; }
+        if (pg) pg[blockIdx.x] = tg;
+        if (pc) pc[blockIdx.x] = tc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
+    const T* food = (const T*)a.food;
+    double gsum = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
+        const float dx = a.dx[n], dy = a.dy[n];
+        uint32_t X = a.x[n], Y = a.y[n];
+        if (a.boundary == DIE_BOUNDARY_WRAP) {            // (xy + dxdy) % 1.
+            X += (uint32_t)die_q32(dx);
+            Y += (uint32_t)die_q32(dy);
+        } else {                                          // clip(0, 1); 1.0 is held as 2^32 − 1
+            int64_t px = (int64_t)X + die_q32(dx), py = (int64_t)Y + die_q32(dy);
+            X = (uint32_t)(px < 0 ? 0 : (px > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : px));
+            Y = (uint32_t)(py < 0 ? 0 : (py > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : py));
+        }
+        a.x[n] = X;
+        a.y[n] = Y;
+        const int64_t c = (int64_t)die_cell((int64_t)X, a.W) * a.H + die_cell((int64_t)Y, a.H);
+        const float consumed = a.rate_feed * die_ld(food, c);
+        if (a.alive[n]) {
+            atomicMax(&a.owner[c], die_owner_word(a.epoch, n));
+            const float gained = consumed - action_cost(a, dx, dy, a.dep[n]);
+            a.agent_food[n] += gained;
+            gsum += (double)gained;
+        } else if (a.has_dead) {
+            a.stash[n] = consumed;
+        }
+    }
+    block_sum_store(gsum, 0, a.part_gain, nullptr);
+}
+
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
+    T* food = (T*)a.food;
+    T* chem = (T*)a.chem;
+    double gsum = 0.0;
+    long long alive_cnt = 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
+        const uint32_t X = a.x[n], Y = a.y[n];
+        const int64_t c = (int64_t)die_cell((int64_t)X, a.W) * a.H + die_cell((int64_t)Y, a.H);
+        bool alive = a.alive[n] != 0;
+        if (alive) {
+            if (a.owner[c] == die_owner_word(a.epoch, n)) {       // highest alive slot on the cell
+                die_st(chem, c, die_ld(chem, c) + a.dep[n]);
+                if (!a.food_infinite) {
+                    const float f = die_ld(food, c);
+                    die_st(food, c, f - a.rate_feed * f);
+                }
+            }
+        } else if (a.has_dead) {
+            const float consumed = die_owner_occupied(a.owner[c], a.epoch) ? a.stash[n] : 0.f;
+            const float gained = consumed - action_cost(a, a.dx[n], a.dy[n], a.dep[n]);
+            a.agent_food[n] += gained;
+            gsum += (double)gained;
+        }
+        if (a.agents_die && !(a.agent_food[n] > 1e-4f)) {         // where(have_food, 0): every channel
+            a.x[n] = 0; a.y[n] = 0; a.alive[n] = 0; a.agent_food[n] = 0.f;
+            alive = false;
+        }
+        alive_cnt += alive ? 1 : 0;
+    }
+    block_sum_store(gsum, alive_cnt, a.part_gain, a.part_alive);
+}
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_reduce(const double* pa, int na, const double* pb, int nb,
+                                                       const long long* pc, int nc, die_step_result* out) {
+    // one block; each thread sums a fixed strided subset, then a fixed tree: run-to-run deterministic
+    __shared__ double sg[DIE_BLOCK];
+    __shared__ long long sc[DIE_BLOCK];
+    double g = 0.0;
+    long long c = 0;
+    for (int i = threadIdx.x; i < na; i += DIE_BLOCK) g += pa[i];
+    for (int i = threadIdx.x; i < nb; i += DIE_BLOCK) g += pb[i];
+    for (int i = threadIdx.x; i < nc; i += DIE_BLOCK) c += pc[i];
+    sg[threadIdx.x] = g;
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = DIE_BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { sg[threadIdx.x] += sg[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out->reward = sg[0]; out->num_alive = sc[0]; }
+}
+
+// ---- diffusion --------------------------------------------------------------------------
+#define DIF_TX 16      // tile rows (x, stride H)
+#define DIF_TY 256     // tile columns (y, contiguous)
+#define DIF_MAXR 8
+
+struct DiffuseArgs {
+    const void* src;
+    void* dst;
+    int W, H;
+    float keep;                 // 1 − decay
+    float w[2 * DIF_MAXR + 1];  // w[k + R], k = −R..R
+};
+
+__device__ __forceinline__ int wrap_idx(int v, int n) {
+    v %= n;
+    return v < 0 ? v + n : v;
+}
+
+// LDS-tiled separable gaussian on the torus: the (TX+2R)×(TY+2R) input tile is staged once,
+// filtered along x (axis 0, as scipy does first) into a second LDS plane, then along y.
+template <typename T, int R>
+__global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
+    constexpr int LW = DIF_TY + 2 * R + 1;    // odd pitch: bank-conflict-free column walks
+    constexpr int LH = DIF_TX + 2 * R;
+    __shared__ float s_in[LH * LW];
+    __shared__ float s_mid[DIF_TX * LW];
+    const T* src = (const T*)a.src;
+    T* dst = (T*)a.dst;
+    const int x0 = blockIdx.y * DIF_TX, y0 = blockIdx.x * DIF_TY;
+    const int H = a.H, W = a.W;
+    constexpr int LWV = DIF_TY + 2 * R;       // valid columns
+    for (int idx = threadIdx.x; idx < LH * LWV; idx += DIE_BLOCK) {
+        const int li = idx / LWV, lj = idx - li * LWV;
+        const int gx = wrap_idx(x0 - R + li, W), gy = wrap_idx(y0 - R + lj, H);
+        s_in[li * LW + lj] = die_ld(src, (int64_t)gx * H + gy);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < DIF_TX * LWV; idx += DIE_BLOCK) {
+        const int i = idx / LWV, j = idx - i * LWV;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k <= 2 * R; ++k) t += a.w[k] * s_in[(i + k) * LW + j];
+        s_mid[i * LW + j] = t;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < DIF_TX * DIF_TY; idx += DIE_BLOCK) {
+        const int i = idx / DIF_TY, j = idx - i * DIF_TY;
+        const int gx = x0 + i, gy = y0 + j;
+        if (gx < W && gy < H) {
+            float o = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; ++k) o += a.w[k] * s_mid[i * LW + j + k];
+            die_st(dst, (int64_t)gx * H + gy, o * a.keep);
+        }
+    }
+}
+
+template <typename T>
+static int launch_diffuse(const DiffuseArgs& a, int R, hipStream_t s) {
+    dim3 grid((a.H + DIF_TY - 1) / DIF_TY, (a.W + DIF_TX - 1) / DIF_TX);
+    switch (R) {
+        case 1: k_diffuse<T, 1><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 2: k_diffuse<T, 2><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 3: k_diffuse<T, 3><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 4: k_diffuse<T, 4><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 5: k_diffuse<T, 5><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 6: k_diffuse<T, 6><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 7: k_diffuse<T, 7><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 8: k_diffuse<T, 8><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        default: die_set_error("die_diffuse_decay: radius %d not supported (sigma too large)", R); return DIE_ERR_UNSUPPORTED;
+    }
+    return DIE_OK;
+}
+
+extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma,
+                                 float decay, void* stream) {
+    DIE_REQUIRE(src && dst && src != dst, "die_diffuse_decay: src/dst must be distinct non-null planes");
+    DIE_REQUIRE(W >= 1 && H >= 1, "die_diffuse_decay: bad size %dx%d", W, H);
+    DIE_REQUIRE(sigma > 0.f, "die_diffuse_decay: sigma must be positive");
+    DIE_REQUIRE(dtype == DIE_F32 || dtype == DIE_F16, "die_diffuse_decay: bad dtype %d", dtype);
+    // scipy.ndimage._gaussian_kernel1d: radius int(4σ + .5), exp(−x²/2σ²) normalised
+    const int R = (int)(4.0 * (double)sigma + 0.5);
+    DIE_REQUIRE(R >= 1, "die_diffuse_decay: sigma %g gives an empty kernel", (double)sigma);
+    if (R > DIF_MAXR) {
+        die_set_error("die_diffuse_decay: sigma %g needs radius %d > %d", (double)sigma, R, DIF_MAXR);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    DiffuseArgs a;
+    a.src = src; a.dst = dst; a.W = W; a.H = H;
+    a.keep = (float)(1.0 - (double)decay);
+    double w[2 * DIF_MAXR + 1], sum = 0.0;
+    for (int k = -R; k <= R; ++k) { w[k + R] = exp(-0.5 / ((double)sigma * (double)sigma) * k * k); sum += w[k + R]; }
+    for (int k = 0; k <= 2 * R; ++k) a.w[k] = (float)(w[k] / sum);
+    int rc = dtype == DIE_F32 ? launch_diffuse<float>(a, R, (hipStream_t)stream)
+                              : launch_diffuse<__half>(a, R, (hipStream_t)stream);
+    if (rc != DIE_OK) return rc;
+    DIE_CHECK_LAUNCH("die_diffuse_decay");
+    return DIE_OK;
+}
+
+// ---- step driver ----------------------------------------------------------------------
+static int step_grid(int64_t N) {
+    int64_t g = (N + DIE_BLOCK - 1) / DIE_BLOCK;
+    return (int)(g < DIE_MAX_PARTIALS ? (g > 0 ? g : 1) : DIE_MAX_PARTIALS);
+}
+
+// workspace layout: [part_gain_a | part_gain_b | part_alive | scan scratch (die_init) | stash (N floats)]
+static const int64_t WS_PARTS = (int64_t)DIE_MAX_PARTIALS * 8 * 3;
+
+int64_t die_ws_scan_bytes(int32_t W, int32_t H);   // die_init.hip
+
+extern "C" int64_t die_workspace_bytes(int32_t W, int32_t H, int64_t N) {
+    if (W < 1 || H < 1 || N < 0) return -1;
+    int64_t b = WS_PARTS + die_ws_scan_bytes(W, H) + N * (int64_t)sizeof(float);
+    return (b + 255) & ~(int64_t)255;
+}
+
+static int fill_args(StepArgs& k, const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                     void* ws, int64_t ws_bytes, const char* who) {
+    DIE_REQUIRE(m && a && d && ws, "%s: null argument", who);
+    DIE_REQUIRE(m->W >= 1 && m->H >= 1 && a->N > 0, "%s: bad sizes", who);
+    DIE_REQUIRE((int64_t)a->N <= (int64_t)DIE_OWNER_SLOT_MASK - 1, "%s: too many slots for the ownership word", who);
+    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "%s: epoch %d outside 1..%d", who, m->epoch,
+                DIE_OWNER_EPOCH_MAX);
+    DIE_REQUIRE(m->owner && m->food && m->chem && a->x && a->y && a->alive && a->agent_food, "%s: null device pointer", who);
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad field dtype %d", who, m->dtype);
+    DIE_REQUIRE(ws_bytes >= die_workspace_bytes(m->W, m->H, a->N), "%s: workspace too small (%lld < %lld)", who,
+                (long long)ws_bytes, (long long)die_workspace_bytes(m->W, m->H, a->N));
+    if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
+        die_set_error("%s: boundary %d (pass-through) leaves [0,1) and is not representable in Q0.32", who, d->boundary);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    DIE_REQUIRE(d->cost == DIE_COST_LINEAR || d->cost == DIE_COST_ZERO, "%s: bad cost operator %d", who, d->cost);
+    if (act) {
+        DIE_REQUIRE(act->N == a->N && act->dx && act->dy && act->deposit, "%s: bad action array", who);
+        k.dx = act->dx; k.dy = act->dy; k.dep = act->deposit;
+    } else {
+        k.dx = k.dy = k.dep = nullptr;
+    }
+    k.W = m->W; k.H = m->H; k.epoch = m->epoch; k.N = a->N;
+    k.owner = m->owner; k.food = m->food; k.chem = m->chem;
+    k.x = a->x; k.y = a->y; k.alive = a->alive; k.agent_food = a->agent_food;
+    k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
+    k.boundary = d->boundary; k.cost = d->cost; k.food_infinite = d->food_infinite; k.agents_die = d->agents_die;
+    k.has_dead = d->has_dead_slots || d->agents_die;
+    char* w = (char*)ws;
+    k.part_gain = nullptr; k.part_alive = nullptr;
+    k.stash = (float*)(w + WS_PARTS + die_ws_scan_bytes(m->W, m->H));
+    return DIE_OK;
+}
+
+extern "C" int die_agent_move_claim(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                                    void* ws, int64_t ws_bytes, void* stream) {
+    StepArgs k;
+    int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_move_claim");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(act, "die_agent_move_claim: null action");
+    k.part_gain = (double*)ws;
+    const int grid = step_grid(a->N);
+    if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    else k_move_claim<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    DIE_CHECK_LAUNCH("die_agent_move_claim");
+    return DIE_OK;
+}
+
+extern "C" int die_agent_resolve(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                                 void* ws, int64_t ws_bytes, void* stream) {
+    StepArgs k;
+    int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_resolve");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(act, "die_agent_resolve: null action");
+    k.part_gain = (double*)ws + DIE_MAX_PARTIALS;
+    k.part_alive = (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS);
+    const int grid = step_grid(a->N);
+    if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    else k_resolve<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    DIE_CHECK_LAUNCH("die_agent_resolve");
+    return DIE_OK;
+}
+
+extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_step_result* result, void* ws,
+                               int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(a && d && result && ws, "die_step_reduce: null argument");
+    DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_step_reduce: workspace too small");
+    const int g = step_grid(a->N);
+    k_reduce<<<1, DIE_BLOCK, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS, g,
+                                                       (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS), g,
+                                                       result);
+    DIE_CHECK_LAUNCH("die_step_reduce");
+    return DIE_OK;
+}
+
+extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                            die_step_result* result, void* ws, int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(m && a && act && d && result, "die_env_step: null argument");
+    DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_env_step: chem_next must be a second plane");
+    int rc = die_agent_move_claim(m, a, act, d, ws, ws_bytes, stream);
+    if (rc != DIE_OK) return rc;
+    rc = die_agent_resolve(m, a, act, d, ws, ws_bytes, stream);
+    if (rc != DIE_OK) return rc;
+    rc = die_step_reduce(a, d, result, ws, ws_bytes, stream);
+    if (rc != DIE_OK) return rc;
+    return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
+}
+
+// ---- error plumbing ---------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void die_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* die_last_error(void) { return g_err; }
+extern "C" int die_abi_version(void) { return DIE_ABI_VERSION; }

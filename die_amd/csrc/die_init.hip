@@ -1,0 +1,210 @@
+// DataInitializer on device (gfx950) — core/data_init.py:92-253 as used by Env._init_data
+// (core/env.py:74-86) and the agent constructors (core/agent/gradient.py:42-43,163).
+//
+//   k_init_medium   with_agents(ratio) (:222-226) + synthetic with_food (:228-231) + zero chem
+//   k_count / k_scan_blocks / k_scatter
+//                   agents_from_medium (:133-150): stream compaction of the occupied cells in
+//                   row-major order into slots [0, K) — three passes, 4096 cells per workgroup
+//   k_init_heading  _get_some_noise → get_radians → discretize
+#include "die_common.h"
+#include "die_rng.h"
+
+#define SCAN_ITEMS 16
+#define SCAN_TILE (DIE_BLOCK * SCAN_ITEMS)
+
+struct FoodArgs {
+    int n_waves;
+    float scale;
+    double fx[8], fy[8], phase[8], amp[8];
+};
+
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(int W, int H, uint32_t* owner, T* food, T* chem, double ratio,
+                                                           uint64_t seed, FoodArgs fa) {
+    const int64_t C = (int64_t)W * H;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += stride) {
+        // ceil(u·[0 ≤ u ≤ ratio]) with u = random_sample().round(3): occupied iff 0 < u ≤ ratio
+        const int r = die_round3_units(die_draw(seed, 0, (uint64_t)c, DIE_STREAM_INIT_AGENTS).v[0]);
+        const double u = r / 1000.0;
+        owner[c] = (r > 0 && u <= ratio) ? 1u : 0u;        // provisional flag; k_scatter writes the ownership word
+        const int ix = (int)(c / H), iy = (int)(c - (int64_t)ix * H);
+        const double x = (double)ix / W, y = (double)iy / H;
+        double s = 0.0;
+        for (int k = 0; k < fa.n_waves; ++k)
+            s += fa.amp[k] * sin(6.283185307179586476925 * (fa.fx[k] * x + fa.fy[k] * y) + fa.phase[k]);
+        s = 2.0 * (double)fa.scale * s;
+        s = s < 0.0 ? 0.0 : (s > (double)fa.scale ? (double)fa.scale : s);
+        die_st(food, c, (float)(rint(s * 1000.0) / 1000.0));   // .round(3) (:196)
+        die_st(chem, c, 0.f);
+    }
+}
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_count(const uint32_t* flag, int64_t C, int32_t* block_sum) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) cnt += (base + i < C && flag[base + i] != 0) ? 1 : 0;
+    __shared__ int s[DIE_BLOCK];
+    s[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = DIE_BLOCK / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sum[blockIdx.x] = s[0];
+}
+
+// single workgroup: exclusive scan of nb block sums → block_off (int64), total → *total
+__global__ __launch_bounds__(DIE_BLOCK) void k_scan_blocks(const int32_t* block_sum, int nb, int64_t* block_off,
+                                                            int64_t* total, int64_t capacity) {
+    __shared__ long long s[DIE_BLOCK];
+    const int per = (nb + DIE_BLOCK - 1) / DIE_BLOCK;
+    const int lo = threadIdx.x * per, hi = min(lo + per, nb);
+    long long t = 0;
+    for (int i = lo; i < hi; ++i) t += block_sum[i];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int i = 0; i < DIE_BLOCK; ++i) { long long v = s[i]; s[i] = run; run += v; }
+        total[0] = run < capacity ? run : capacity;
+        total[1] = run > capacity ? 1 : 0;           // overflow flag: more agents than slots
+    }
+    __syncthreads();
+    long long run = s[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { block_off[i] = run; run += block_sum[i]; }
+}
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_scatter(int W, int H, uint32_t* owner, const int64_t* block_off, int64_t N,
+                                                       uint32_t* x, uint32_t* y, uint8_t* alive, float* agent_food,
+                                                       uint64_t seed) {
+    const int64_t C = (int64_t)W * H;
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    int flags = 0, cnt = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < C && owner[base + i] != 0) { flags |= 1 << i; ++cnt; }
+    __shared__ int s[DIE_BLOCK];
+    s[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < DIE_BLOCK; o <<= 1) {          // Hillis–Steele inclusive scan
+        int v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int64_t k = block_off[blockIdx.x] + (s[threadIdx.x] - cnt);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        const int64_t c = base + i;
+        if (c >= C) break;
+        if (flags & (1 << i)) {
+            if (k < N) {
+                const int ix = (int)(c / H), iy = (int)(c - (int64_t)ix * H);
+                // x = linspace(0, 1, W)[ix] in Q0.32; the last label 1.0 is held as 2^32 − 1
+                const double qx = W > 1 ? (double)ix / (double)(W - 1) * 4294967296.0 : 0.0;
+                const double qy = H > 1 ? (double)iy / (double)(H - 1) * 4294967296.0 : 0.0;
+                const long long X = __double2ll_rn(qx), Y = __double2ll_rn(qy);
+                x[k] = (uint32_t)(X > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : X);
+                y[k] = (uint32_t)(Y > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : Y);
+                alive[k] = 1;
+                // get_random(K, 0.1, 1.0) = 0.9·u.round(3) + 0.1 (:140, :168-169)
+                const int r = die_round3_units(die_draw(seed, 0, (uint64_t)k, DIE_STREAM_INIT_AGENT_FOOD).v[0]);
+                agent_food[k] = (float)(0.9 * (r / 1000.0) + 0.1);
+                owner[c] = die_owner_word(1, k);
+            } else {
+                owner[c] = 0;
+            }
+            ++k;
+        }
+    }
+}
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_zero_tail(const int64_t* total, int64_t N, uint32_t* x, uint32_t* y,
+                                                         uint8_t* alive, float* agent_food) {
+    const int64_t K = total[0];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = K + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        x[n] = 0; y[n] = 0; alive[n] = 0; agent_food[n] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_init_heading(float* heading, float* pgx, float* pgy, int64_t N, double turn,
+                                                            uint64_t seed) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        const die_u32x4 r = die_draw(seed, 0, (uint64_t)n, DIE_STREAM_INIT_HEADING);
+        // Box–Muller pair: its polar angle is 2π·u2, wrapped to (−π, π] like np.angle
+        const double u1 = ((double)r.v[0] + 1.0) * (1.0 / 4294967296.0);
+        const double u2 = (double)r.v[1] * (1.0 / 4294967296.0);
+        const double rad = 0.4 * sqrt(-2.0 * log(u1));
+        const double gx = rad * cos(6.283185307179586476925 * u2), gy = rad * sin(6.283185307179586476925 * u2);
+        double ang = atan2(gy, gx);
+        if (turn > 0.0) ang = floor(ang / turn) * turn;      // discretize (core/utils.py:183-184)
+        heading[n] = (float)ang;
+        if (pgx) { pgx[n] = (float)gx; pgy[n] = (float)gy; }
+    }
+}
+
+static int init_grid(int64_t n) {
+    int64_t g = (n + DIE_BLOCK - 1) / DIE_BLOCK;
+    return (int)(g < 8192 ? (g > 0 ? g : 1) : 8192);
+}
+
+int64_t die_ws_scan_bytes(int32_t W, int32_t H) {
+    const int64_t nb = ((int64_t)W * H + SCAN_TILE - 1) / SCAN_TILE;
+    return ((nb * 4 + 255) & ~(int64_t)255) + ((nb * 8 + 255) & ~(int64_t)255);
+}
+
+extern "C" int die_init_medium(const die_medium* m, double agent_ratio, uint64_t seed, const die_food_spec* food,
+                               void* stream) {
+    DIE_REQUIRE(m && food, "die_init_medium: null argument");
+    DIE_REQUIRE(m->W >= 1 && m->H >= 1 && m->owner && m->food && m->chem, "die_init_medium: bad medium");
+    DIE_REQUIRE(food->n_waves >= 0 && food->n_waves <= 8, "die_init_medium: n_waves %d outside 0..8", food->n_waves);
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "die_init_medium: bad dtype %d", m->dtype);
+    FoodArgs fa;
+    fa.n_waves = food->n_waves;
+    fa.scale = food->scale;
+    for (int i = 0; i < 8; ++i) { fa.fx[i] = food->fx[i]; fa.fy[i] = food->fy[i]; fa.phase[i] = food->phase[i]; fa.amp[i] = food->amp[i]; }
+    const int grid = init_grid((int64_t)m->W * m->H);
+    if (m->dtype == DIE_F32)
+        k_init_medium<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(m->W, m->H, m->owner, (float*)m->food,
+                                                                           (float*)m->chem, agent_ratio, seed, fa);
+    else
+        k_init_medium<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(m->W, m->H, m->owner, (__half*)m->food,
+                                                                            (__half*)m->chem, agent_ratio, seed, fa);
+    DIE_CHECK_LAUNCH("die_init_medium");
+    return DIE_OK;
+}
+
+extern "C" int die_init_agents(const die_medium* m, const die_agents* a, uint64_t seed, int64_t* num_alive_dev, void* ws,
+                               int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(m && a && num_alive_dev && ws, "die_init_agents: null argument");
+    DIE_REQUIRE(m->W >= 1 && m->H >= 1 && m->owner, "die_init_agents: bad medium");
+    DIE_REQUIRE(a->N > 0 && a->x && a->y && a->alive && a->agent_food, "die_init_agents: bad agents");
+    DIE_REQUIRE(ws_bytes >= die_workspace_bytes(m->W, m->H, a->N), "die_init_agents: workspace too small");
+    const int64_t C = (int64_t)m->W * m->H;
+    const int64_t nb = (C + SCAN_TILE - 1) / SCAN_TILE;
+    DIE_REQUIRE(nb < (1ll << 31), "die_init_agents: field too large");
+    char* w = (char*)ws + (int64_t)8192 * 8 * 3;        // after the step partials (die_env.hip WS_PARTS)
+    int32_t* block_sum = (int32_t*)w;
+    int64_t* block_off = (int64_t*)(w + ((nb * 4 + 255) & ~(int64_t)255));
+    hipStream_t s = (hipStream_t)stream;
+    k_count<<<(int)nb, DIE_BLOCK, 0, s>>>(m->owner, C, block_sum);
+    k_scan_blocks<<<1, DIE_BLOCK, 0, s>>>(block_sum, (int)nb, block_off, num_alive_dev, a->N);
+    k_scatter<<<(int)nb, DIE_BLOCK, 0, s>>>(m->W, m->H, m->owner, block_off, a->N, a->x, a->y, a->alive, a->agent_food, seed);
+    k_zero_tail<<<init_grid(a->N), DIE_BLOCK, 0, s>>>(num_alive_dev, a->N, a->x, a->y, a->alive, a->agent_food);
+    DIE_CHECK_LAUNCH("die_init_agents");
+    return DIE_OK;
+}
+
+extern "C" int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, float turn_radians,
+                                uint64_t seed, void* stream) {
+    DIE_REQUIRE(heading && N > 0, "die_init_heading: bad arguments");
+    DIE_REQUIRE((prev_gx == nullptr) == (prev_gy == nullptr), "die_init_heading: prev_gx/prev_gy must come together");
+    k_init_heading<<<init_grid(N), DIE_BLOCK, 0, (hipStream_t)stream>>>(heading, prev_gx, prev_gy, N, (double)turn_radians,
+                                                                          seed);
+    DIE_CHECK_LAUNCH("die_init_heading");
+    return DIE_OK;
+}

@@ -1,0 +1,182 @@
+"""Device-resident stand-ins for the reference's xarray objects (core/base_types.py:6-10):
+`medium` (3, W, H), `agents` (4, N) and `action` (3, N).  Each holds one torch tensor per
+channel in HBM and hands raw device pointers to libdie_hip.so; `.to_numpy()` gives the
+float64 array the reference would hold, `.sel(channel=...)` one channel.
+
+torch is plumbing here (allocation, streams, host copies); no torch op is on the step path.
+"""
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .base_types import DataChannels
+
+Q32 = 4294967296.0
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def stream_ptr(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def to_q32(v: np.ndarray) -> np.ndarray:
+    """[0, 1] float coordinates → Q0.32 words (1.0 saturates to 2^32 − 1)."""
+    q = np.rint(np.asarray(v, dtype=np.float64) * Q32)
+    return np.clip(q, 0, Q32 - 1).astype(np.uint64).astype(np.uint32)
+
+
+def from_q32(q: np.ndarray) -> np.ndarray:
+    return q.astype(np.float64) / Q32
+
+
+class DeviceMedium:
+    """(3, W, H) field: channels ('agents', 'env_food', 'chem1')."""
+    channels = DataChannels.medium
+
+    def __init__(self, field_size, device, dtype=torch.float32):
+        W, H = int(field_size[0]), int(field_size[1])
+        if dtype not in (torch.float32, torch.float16):
+            raise ValueError('field dtype must be float32 or float16')
+        self.W, self.H, self.device, self.dtype = W, H, torch.device(device), dtype
+        self.owner = torch.zeros((W, H), dtype=torch.int32, device=device)   # uint32 ownership words
+        self.food = torch.zeros((W, H), dtype=dtype, device=device)
+        self.chem = torch.zeros((W, H), dtype=dtype, device=device)
+        self.chem_next = torch.empty((W, H), dtype=dtype, device=device)
+        self.epoch = 1
+
+    @property
+    def shape(self):
+        return (3, self.W, self.H)
+
+    def c_struct(self) -> _lib.Medium:
+        return _lib.Medium(self.W, self.H, _lib.DIE_F32 if self.dtype == torch.float32 else _lib.DIE_F16, self.epoch,
+                           _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next))
+
+    def next_epoch(self):
+        """Advance the ownership epoch; zero the plane when the 3-bit tag wraps."""
+        self.epoch += 1
+        if self.epoch > _lib.OWNER_EPOCH_MAX:
+            self.owner.zero_()
+            self.epoch = 1
+
+    def swap_chem(self):
+        self.chem, self.chem_next = self.chem_next, self.chem
+
+    def occupied(self) -> torch.Tensor:
+        """Boolean (W, H): the 'agents' channel > 0."""
+        tag = (self.owner.to(torch.int64) & 0xFFFFFFFF) >> _lib.OWNER_EPOCH_SHIFT
+        return tag == self.epoch
+
+    def owner_slots(self) -> torch.Tensor:
+        """int64 (W, H): owning slot id, −1 for empty cells."""
+        w = self.owner.to(torch.int64) & 0xFFFFFFFF
+        return torch.where((w >> _lib.OWNER_EPOCH_SHIFT) == self.epoch, (w & _lib.OWNER_SLOT_MASK) - 1,
+                           torch.full_like(w, -1))
+
+    def sel(self, channel: str) -> torch.Tensor:
+        if channel == 'agents':
+            return self.occupied().to(torch.float32)
+        if channel == 'env_food':
+            return self.food
+        if channel == 'chem1':
+            return self.chem
+        raise KeyError(channel)
+
+    def to_numpy(self) -> np.ndarray:
+        return np.stack([self.sel(c).to(torch.float64).cpu().numpy() for c in self.channels])
+
+    def upload(self, medium: np.ndarray):
+        """Load a (3, W, H) array; occupied cells get an ownership word of the current epoch."""
+        medium = np.asarray(medium)
+        assert medium.shape == self.shape, (medium.shape, self.shape)
+        occ = medium[0] > 0
+        words = np.where(occ, (self.epoch << _lib.OWNER_EPOCH_SHIFT) | 1, 0).astype(np.uint32)
+        self.owner.copy_(torch.from_numpy(words.view(np.int32)))
+        self.food.copy_(torch.from_numpy(np.ascontiguousarray(medium[1], dtype=np.float32)))
+        self.chem.copy_(torch.from_numpy(np.ascontiguousarray(medium[2], dtype=np.float32)))
+
+    def upload_channel(self, channel: str, data: np.ndarray):
+        t = {'env_food': self.food, 'chem1': self.chem}[channel]
+        t.copy_(torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)))
+
+
+class DeviceAgents:
+    """(4, N) agent array: channels ('x', 'y', 'alive', 'agent_food'); x, y are Q0.32."""
+    channels = DataChannels.agents
+
+    def __init__(self, num_slots: int, device):
+        N = int(num_slots)
+        self.N, self.device = N, torch.device(device)
+        self.x = torch.zeros(N, dtype=torch.int32, device=device)
+        self.y = torch.zeros(N, dtype=torch.int32, device=device)
+        self.alive = torch.zeros(N, dtype=torch.uint8, device=device)
+        self.agent_food = torch.zeros(N, dtype=torch.float32, device=device)
+
+    @property
+    def shape(self):
+        return (4, self.N)
+
+    def c_struct(self) -> _lib.Agents:
+        return _lib.Agents(self.N, _ptr(self.x), _ptr(self.y), _ptr(self.alive), _ptr(self.agent_food))
+
+    def sel(self, channel: str) -> torch.Tensor:
+        if channel in ('x', 'y'):
+            q = getattr(self, channel).to(torch.int64) & 0xFFFFFFFF
+            return q.to(torch.float64) / Q32
+        if channel == 'alive':
+            return self.alive.to(torch.float32)
+        if channel == 'agent_food':
+            return self.agent_food
+        raise KeyError(channel)
+
+    def to_numpy(self) -> np.ndarray:
+        return np.stack([self.sel(c).to(torch.float64).cpu().numpy() for c in self.channels])
+
+    def q32_numpy(self):
+        """Raw coordinate words as uint32 arrays."""
+        return self.x.cpu().numpy().view(np.uint32), self.y.cpu().numpy().view(np.uint32)
+
+    def upload(self, agents: np.ndarray):
+        agents = np.asarray(agents, dtype=np.float64)
+        assert agents.shape == self.shape, (agents.shape, self.shape)
+        self.x.copy_(torch.from_numpy(to_q32(agents[0]).view(np.int32)))
+        self.y.copy_(torch.from_numpy(to_q32(agents[1]).view(np.int32)))
+        self.alive.copy_(torch.from_numpy((agents[2] > 0).astype(np.uint8)))
+        self.agent_food.copy_(torch.from_numpy(agents[3].astype(np.float32)))
+
+
+class DeviceAction:
+    """(3, N) action array: channels ('dx', 'dy', 'deposit1')."""
+    channels = DataChannels.actions
+
+    def __init__(self, num_slots: int, device):
+        N = int(num_slots)
+        self.N, self.device = N, torch.device(device)
+        self.data = torch.empty((3, N), dtype=torch.float32, device=device)
+
+    @property
+    def shape(self):
+        return (3, self.N)
+
+    def c_struct(self) -> _lib.Action:
+        return _lib.Action(self.N, _ptr(self.data[0]), _ptr(self.data[1]), _ptr(self.data[2]))
+
+    def sel(self, channel: str) -> torch.Tensor:
+        return self.data[self.channels.index(channel)]
+
+    def to_numpy(self) -> np.ndarray:
+        return self.data.to(torch.float64).cpu().numpy()
+
+    @staticmethod
+    def from_numpy(action: np.ndarray, device) -> 'DeviceAction':
+        action = np.asarray(action)
+        assert action.ndim == 2 and action.shape[0] == 3, action.shape
+        a = DeviceAction(action.shape[1], device)
+        a.data.copy_(torch.from_numpy(np.ascontiguousarray(action, dtype=np.float32)))
+        return a

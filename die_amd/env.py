@@ -1,0 +1,244 @@
+"""Env / Dynamics with the reference's Gymnasium-style API (core/env.py:24-311), state in
+HBM and every substep of `step` executed by libdie_hip.so.
+
+Differences a caller can observe, all deliberate:
+  * `medium`, `agents`, actions and observations are device-array handles
+    (die_amd/device_array.py), not xarray objects; `.to_numpy()` gives the reference layout.
+  * the observation is a live view of the state, not a per-step copy (core/env.py:292-293).
+  * `Env(..., max_agents=...)`: the reference always allocates W·H agent slots
+    (core/data_init.py:143-144) and moves / burns / rewards the dead ones too; that is the
+    default here as well.  `max_agents='alive'` allocates only the seeded agents.
+  * `reset(seed=...)` honours the seed (the reference ignores it, core/env.py:94-99).
+"""
+import ctypes as C
+import logging
+import os
+from dataclasses import dataclass
+from enum import Enum
+from typing import Callable, Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data_init import DataInitializer
+from .device_array import DeviceAction, DeviceAgents, DeviceMedium, _ptr, stream_ptr
+
+try:                                    # the reference subclasses gym.Env but defines no spaces
+    import gymnasium as _gym
+    _EnvBase = _gym.Env
+except ImportError:                     # gymnasium is optional
+    _EnvBase = object
+
+
+class BoundaryCondition(Enum):
+    """core/env.py:24-26."""
+    wrap = 'wrap'
+    limit = 'limit'
+
+
+def linear_action_cost(action, weights=(0.02, 0.01)):
+    """core/env.py:29-35 — marker for the device cost operator (evaluated in k_move_claim);
+    callable on a (3, N) numpy array for host-side use."""
+    a = action.to_numpy() if hasattr(action, 'to_numpy') else np.asarray(action)
+    return weights[0] * np.abs(a[2]) + weights[1] * np.linalg.norm(a[:2], axis=0)
+
+
+def zero_cost(action):
+    """core/env.py:38-39."""
+    return np.zeros(action.shape[1:])
+
+
+def _identity_food_flow(x):
+    return x
+
+
+@dataclass
+class Dynamics:
+    """core/env.py:42-61, same field names and defaults."""
+    op_action_cost: Callable = linear_action_cost
+    op_food_flow: Callable = _identity_food_flow
+    rate_feed: float = 0.1
+    rate_decay_chem: float = 0.1
+    boundary: BoundaryCondition = BoundaryCondition.wrap
+    diffuse_mode: str = 'wrap'
+    diffuse_sigma: float = .5
+    apply_sense_mask: bool = False
+    strict_cost: bool = True
+    food_infinite: bool = False
+    agents_die: bool = False
+    agents_born: bool = False
+    init_agent_ratio: float = 0.1
+
+
+class Env(_EnvBase):
+    def __init__(self, field_size: Tuple[int, int], dynamics: Optional[Dynamics] = None, *,
+                 max_agents: Union[None, int, str] = None, seed: Optional[int] = None,
+                 field_dtype: torch.dtype = torch.float32, device: Union[str, torch.device, None] = None,
+                 sync: bool = True):
+        if not torch.cuda.is_available():
+            raise RuntimeError('die_amd.Env needs a ROCm GPU (MI355X); there is no CPU path')
+        self._field_size = (int(field_size[0]), int(field_size[1]))
+        self.dynamics = dynamics or Dynamics()
+        self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
+        self._max_agents = max_agents
+        self._field_dtype = field_dtype
+        self._sync = sync
+        self._seed = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
+        self._renderer = None
+        self.last_result = None
+        self._check_dynamics()
+        self._init_data(self._field_size)
+
+    # ------------------------------------------------------------------ construction
+    def _check_dynamics(self):
+        d = self.dynamics
+        if d.diffuse_mode != 'wrap':
+            raise NotImplementedError(f"diffuse_mode={d.diffuse_mode!r}: only 'wrap' is implemented on device")
+        if d.apply_sense_mask:
+            raise NotImplementedError('apply_sense_mask is not implemented on device')
+        if d.op_action_cost not in (linear_action_cost, zero_cost):
+            raise NotImplementedError('op_action_cost must be linear_action_cost or zero_cost on device')
+        if self._field_size[0] < 2 or self._field_size[1] < 2:
+            raise ValueError('field must be at least 2x2')
+
+    def _init_data(self, field_size):
+        """core/env.py:74-86."""
+        self.medium = DataInitializer.init_field_array(field_size, self.device, self._field_dtype)
+        DataInitializer.init_medium(self.medium, self.dynamics.init_agent_ratio, self._seed)
+        self.agents, self._num_seeded = DataInitializer.agents_from_medium(self.medium, self._max_agents, self._seed)
+        self._after_state_change()
+
+    def _after_state_change(self):
+        self._workspace = DataInitializer.workspace(self._field_size, self.agents.N, self.device)
+        self._all_alive = bool(self.agents.alive.all().item())
+
+    @classmethod
+    def from_numpy(cls, medium: np.ndarray, agents: np.ndarray, dynamics: Optional[Dynamics] = None, **kw) -> 'Env':
+        """Build an Env around given (3, W, H) / (4, N) arrays (tests, checkpoints)."""
+        env = cls.__new__(cls)
+        if not torch.cuda.is_available():
+            raise RuntimeError('die_amd.Env needs a ROCm GPU (MI355X); there is no CPU path')
+        medium = np.asarray(medium)
+        env._field_size = (medium.shape[1], medium.shape[2])
+        env.dynamics = dynamics or Dynamics()
+        env.device = torch.device(kw.get('device') or f'cuda:{torch.cuda.current_device()}')
+        env._max_agents = agents.shape[1]
+        env._field_dtype = kw.get('field_dtype', torch.float32)
+        env._sync = kw.get('sync', True)
+        env._seed = int(kw.get('seed', 0))
+        env._renderer = None
+        env.last_result = None
+        env._check_dynamics()
+        env.medium = DeviceMedium(env._field_size, env.device, env._field_dtype)
+        env.medium.upload(medium)
+        env.agents = DeviceAgents(agents.shape[1], env.device)
+        env.agents.upload(agents)
+        env._num_seeded = int((np.asarray(agents)[2] > 0).sum())
+        env._after_state_change()
+        return env
+
+    def reset(self, *, seed: Optional[int] = None, options: Optional[dict] = None):
+        """core/env.py:94-99."""
+        if seed is not None:
+            self._seed = int(seed)
+        else:
+            self._seed = (self._seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        self._init_data(self._field_size)
+        return self._get_current_obs, {}
+
+    # ------------------------------------------------------------------ step
+    def _c_dynamics(self) -> _lib.Dynamics:
+        d = self.dynamics
+        if isinstance(d.boundary, BoundaryCondition):
+            boundary = _lib.DIE_BOUNDARY_WRAP if d.boundary == BoundaryCondition.wrap else _lib.DIE_BOUNDARY_LIMIT
+        else:
+            logging.warning(f'Unfamiliar boundary condition: {d.boundary}!')      # core/env.py:158-161
+            boundary = _lib.DIE_BOUNDARY_NONE
+        cost = _lib.DIE_COST_LINEAR if d.op_action_cost is linear_action_cost else _lib.DIE_COST_ZERO
+        return _lib.Dynamics(d.rate_feed, d.rate_decay_chem, d.diffuse_sigma, boundary, cost, 0.02, 0.01,
+                             int(d.food_infinite), int(d.agents_die), int(not self._all_alive))
+
+    def _as_action(self, action) -> DeviceAction:
+        if isinstance(action, DeviceAction):
+            act = action
+        else:
+            act = DeviceAction.from_numpy(action.to_numpy() if hasattr(action, 'to_numpy') else action, self.device)
+        if act.N != self.agents.N:
+            raise ValueError(f'action has {act.N} slots, env has {self.agents.N}')
+        return act
+
+    def step(self, action):
+        """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
+        act = self._as_action(action)
+        self.medium.next_epoch()
+        result = torch.empty(2, dtype=torch.float64, device=self.device)
+        m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), act.c_struct(), self._c_dynamics()
+        _lib.check(_lib.lib.die_env_step(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(result),
+                                         _ptr(self._workspace), self._workspace.numel(), stream_ptr(self.device)),
+                   'die_env_step')
+        self.medium.swap_chem()
+        if self.dynamics.op_food_flow is not _identity_food_flow:
+            self._host_food_flow()
+        self.last_result = result
+        if not self._sync:
+            return self._get_current_obs, result, False, False, {}
+        reward, num_agents = self.read_result(result)
+        if self.dynamics.agents_die:
+            self._all_alive = False
+        mean_gain = reward / num_agents if num_agents > 0 else 0.
+        info = {'num_agents': num_agents, 'reward': np.round(reward, 3), 'mean_reward': np.round(mean_gain, 5)}
+        return self._get_current_obs, reward, num_agents == 0, False, info
+
+    @staticmethod
+    def read_result(result: torch.Tensor) -> Tuple[float, int]:
+        """(reward, num_agents) of a die_step_result buffer (synchronises)."""
+        host = result.cpu()
+        return float(host[0]), int(host.view(torch.int64)[1])
+
+    def _host_food_flow(self):
+        """core/env.py:147-150 for arbitrary Python operators: host round trip."""
+        food = self.medium.food.to(torch.float64).cpu().numpy()
+        self.medium.upload_channel('env_food', np.asarray(self.dynamics.op_food_flow(food)))
+
+    # substeps, for custom update cycles (examples/simple_agents.py:16-30)
+    def _stage(self, fn_name, action):
+        act = self._as_action(action)
+        m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), act.c_struct(), self._c_dynamics()
+        _lib.check(getattr(_lib.lib, fn_name)(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(self._workspace),
+                                              self._workspace.numel(), stream_ptr(self.device)), fn_name)
+
+    def _medium_diffuse_decay(self):
+        d = self.dynamics
+        m = self.medium
+        _lib.check(_lib.lib.die_diffuse_decay(_ptr(m.chem), _ptr(m.chem_next), m.W, m.H, m.c_struct().dtype,
+                                              d.diffuse_sigma, d.rate_decay_chem, stream_ptr(self.device)),
+                   'die_diffuse_decay')
+        m.swap_chem()
+
+    # ------------------------------------------------------------------ observation / render
+    @property
+    def _num_alive_agents(self) -> int:
+        return int(self.agents.alive.sum().item())
+
+    @property
+    def _get_agent_mask(self) -> torch.Tensor:
+        return self.medium.occupied()
+
+    @property
+    def _get_current_obs(self):
+        """core/env.py:296-298 (live handles, not copies)."""
+        return self.agents, self.medium
+
+    @property
+    def coordgrid(self) -> np.ndarray:
+        """core/utils.py:113-118."""
+        xcs = [np.linspace(0., 1., num=size) for size in reversed(self._field_size)]
+        return np.stack(np.meshgrid(*xcs))
+
+    def render(self):
+        """core/env.py:133-134: [medium RGB (W, H, 3), agent-trace RGBA, agents RGBA]."""
+        from .render import EnvRenderer
+        if self._renderer is None:
+            self._renderer = EnvRenderer(self._field_size)
+        return self._renderer.render(self.medium.to_numpy(), self.agents.to_numpy())

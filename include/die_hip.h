@@ -1,0 +1,197 @@
+/* die_hip.h — C ABI of libdie_hip.so: the MI355X (gfx950) implementation of the grid-update
+ * hot path of gkirgizov/die (Env.step field dynamics + Agent.forward + data_init allocation).
+ *
+ * The reference has no FFI: the boundary it offers is the Python class API of core/env.py,
+ * core/agent/ (all modules) and core/data_init.py.  The host side of this project
+ * (the die_amd package) keeps those classes and calls the entry points below through ctypes; each
+ * entry point names the reference function(s) it replaces.  Paths are relative to the
+ * reference checkout.
+ *
+ * Conventions
+ *   - plain C, no exceptions; every call returns DIE_OK (0) or a negative die_status and
+ *     leaves a message for die_last_error() (thread-local).
+ *   - all pointers in the structs are DEVICE pointers (HBM) owned by the caller; the library
+ *     allocates nothing and keeps no state.  `stream` is a hipStream_t (NULL = default
+ *     stream); every call only enqueues work on it and returns without synchronising.
+ *   - field planes are W×H row-major, element (ix, iy) at ix*H + iy — the (channel, x, y)
+ *     layout of core/data_init.py:95-112 with one plane per channel.
+ *   - agent coordinates are Q0.32 fixed point: x = X / 2^32 in [0, 1).  The nearest-cell
+ *     lookup of core/utils.py:39-54 is then exact integer arithmetic,
+ *     cell = clamp((X*(W-1) + 2^31) >> 32, 0, W-1), and the `% 1.` wrap of
+ *     core/env.py:155 is the natural 32-bit overflow.
+ *   - the 'agents' medium channel (core/base_types.py:32) is held as an ownership word per
+ *     cell: (epoch << 29) | (slot + 1) of the highest-index alive agent standing on the cell
+ *     in step `epoch`; a cell is occupied iff word >> 29 == current epoch (epoch in 1..7,
+ *     the caller zeroes the plane when it wraps).  Highest slot wins == the "last writer
+ *     wins" of core/env.py:211.
+ */
+#ifndef DIE_HIP_H
+#define DIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DIE_ABI_VERSION 1
+
+typedef enum die_status {
+    DIE_OK = 0,
+    DIE_ERR_ARG = -1,         /* null pointer, bad size, unsupported enum value */
+    DIE_ERR_HIP = -2,         /* a HIP runtime call or kernel launch failed */
+    DIE_ERR_UNSUPPORTED = -3  /* valid in the reference, not implemented on device */
+} die_status;
+
+typedef enum die_dtype { DIE_F32 = 0, DIE_F16 = 1 } die_dtype;
+
+/* core/env.py:24-26 BoundaryCondition; anything else passes coordinates through (:158-161) */
+typedef enum die_boundary { DIE_BOUNDARY_WRAP = 0, DIE_BOUNDARY_LIMIT = 1, DIE_BOUNDARY_NONE = 2 } die_boundary;
+
+/* core/env.py:29-39 action-cost operators available on device */
+typedef enum die_cost { DIE_COST_LINEAR = 0, DIE_COST_ZERO = 1 } die_cost;
+
+/* core/agent/gradient.py: which forward() a call computes */
+typedef enum die_agent_kind { DIE_AGENT_GRADIENT = 0, DIE_AGENT_PHYSARUM = 1 } die_agent_kind;
+
+#define DIE_OWNER_EPOCH_SHIFT 29
+#define DIE_OWNER_EPOCH_MAX 7
+#define DIE_OWNER_SLOT_MASK 0x1FFFFFFFu
+
+/* The (3, W, H) medium of core/env.py:75-79 / core/base_types.py:32. */
+typedef struct die_medium {
+    int32_t W, H;
+    int32_t dtype;       /* die_dtype of food / chem / chem_next */
+    int32_t epoch;       /* current ownership epoch, 1..DIE_OWNER_EPOCH_MAX */
+    uint32_t* owner;     /* 'agents' channel, W*H ownership words (see header comment) */
+    void* food;          /* 'env_food', W*H */
+    void* chem;          /* 'chem1', W*H, current */
+    void* chem_next;     /* W*H, receives the diffused plane; the caller swaps after die_env_step */
+} die_medium;
+
+/* The (4, N) agent array of core/data_init.py:114-150, structure of arrays. */
+typedef struct die_agents {
+    int64_t N;           /* slots (alive or not) */
+    uint32_t* x;         /* Q0.32 */
+    uint32_t* y;         /* Q0.32 */
+    uint8_t* alive;      /* 1 / 0 */
+    float* agent_food;
+} die_agents;
+
+/* The (3, N) action array of core/data_init.py:152-157. */
+typedef struct die_action {
+    int64_t N;
+    float* dx;
+    float* dy;
+    float* deposit;
+} die_action;
+
+/* core/env.py:42-61 Dynamics, the fields the device path honours. */
+typedef struct die_dynamics {
+    float rate_feed;
+    float rate_decay_chem;
+    float diffuse_sigma;
+    int32_t boundary;        /* die_boundary */
+    int32_t cost;            /* die_cost */
+    float cost_w_deposit;    /* 0.02 (core/env.py:29) */
+    float cost_w_dist;       /* 0.01 */
+    int32_t food_infinite;
+    int32_t agents_die;
+    int32_t has_dead_slots;  /* 0: caller guarantees every slot is alive (skips the dead-slot feed pass) */
+} die_dynamics;
+
+/* core/agent/gradient.py:19-28,139-151 constructor arguments + per-agent state. */
+typedef struct die_gradient_agent {
+    int32_t kind;            /* die_agent_kind */
+    int32_t normalized_grad;
+    float scale;
+    float deposit;
+    float inertia;
+    float sense_offset;
+    float noise_scale;
+    float grad_clip;         /* < 0: None */
+    float turn_radians;      /* physarum only */
+    float sense_radians;
+    float turn_tolerance;
+    int32_t reserved;
+    float* heading;          /* N, _direction_rads (state, read and written) */
+    float* prev_gx;          /* N, _prev_grad[0]; may be NULL when inertia == 0 */
+    float* prev_gy;          /* N */
+    const int8_t* turn_sign; /* N entries ±1 replacing the random turn, or NULL → Philox(seed, step, slot) */
+    uint64_t seed;
+    uint32_t step;           /* forward-call counter, the Philox step word */
+    uint32_t reserved2;
+} die_gradient_agent;
+
+/* Device-resident result of one die_env_step (read it back after synchronising). */
+typedef struct die_step_result {
+    double reward;           /* sum of `gained` over every slot (core/env.py:119-120) */
+    int64_t num_alive;       /* core/env.py:263-265 */
+} die_step_result;
+
+int die_abi_version(void);
+const char* die_last_error(void);
+
+/* Bytes of scratch die_env_step / die_init_agents need for this problem size. */
+int64_t die_workspace_bytes(int32_t W, int32_t H, int64_t N);
+
+/* ---- Agent.forward ------------------------------------------------------------------
+ * GradientAgent.forward / PhysarumAgent.forward (core/agent/gradient.py:96-124, 168-219):
+ * one forward probe of the normalised np.gradient of chem1 (4 taps around the probe cell,
+ * :55-76), discrete turn, momentum, deposit; writes the action and updates agent state.
+ * Every slot acts, alive or not, as in the reference. */
+int die_gradient_forward(const die_medium* m, const die_agents* a, die_gradient_agent* g,
+                         die_action* out, void* stream);
+
+/* BrownianAgent.forward (core/agent/static.py:40-50): (b-a)*u.round(3)+a per channel, × alive. */
+int die_brownian_forward(const die_agents* a, float move_scale, float deposit_scale,
+                         uint64_t seed, uint32_t step, die_action* out, void* stream);
+
+/* ConstAgent.forward (core/agent/static.py:20-27). */
+int die_const_forward(int64_t N, float dx, float dy, float deposit, die_action* out, void* stream);
+
+/* ---- Env.step -------------------------------------------------------------------------
+ * core/env.py:101-131 in one call: _agent_move (:163-172), _agent_deposit_and_layout
+ * (:204-215), _agent_feed (:220-243), _agent_lifecycle (:245-261, agents_die only),
+ * _medium_diffuse_decay (:136-145) and the reward / num_agents reductions (:117-126).
+ * `m->epoch` must already be the new step's epoch.  On return (stream order) the diffused
+ * plane is in m->chem_next.  `result` is a device pointer. */
+int die_env_step(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                 die_step_result* result, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* The stages of die_env_step, individually (tests and custom update cycles such as
+ * examples/simple_agents.py:16-30 `_manual_step`). */
+int die_agent_move_claim(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+int die_agent_resolve(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                      void* workspace, int64_t workspace_bytes, void* stream);
+int die_step_reduce(const die_agents* a, const die_dynamics* d, die_step_result* result,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+/* gaussian(sigma, mode='wrap') × (1 − decay): src → dst, W×H planes of `dtype`. */
+int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype,
+                      float sigma, float decay, void* stream);
+
+/* ---- DataInitializer (core/data_init.py:92-253, core/env.py:74-86) ------------------- */
+typedef struct die_food_spec {   /* synthetic stand-in for the Perlin food field (:190-196) */
+    int32_t n_waves;             /* <= 8 */
+    float scale;
+    double fx[8], fy[8], phase[8], amp[8];
+} die_food_spec;
+
+/* with_agents(ratio) + with_food(...) + zero chem: fills owner (epoch 1), food, chem. */
+int die_init_medium(const die_medium* m, double agent_ratio, uint64_t seed, const die_food_spec* food,
+                    void* stream);
+/* agents_from_medium (:133-150): occupied cells in row-major order → slots [0, K); slots
+ * >= K are zeroed.  K is written to *num_alive_dev (device int64).  Fails at run time
+ * (K clipped, flag in num_alive_dev[1]) when K > a->N. */
+int die_init_agents(const die_medium* m, const die_agents* a, uint64_t seed, int64_t* num_alive_dev,
+                    void* workspace, int64_t workspace_bytes, void* stream);
+/* GradientAgent/PhysarumAgent.__init__ state (:42-43,163): heading from N(0,.4) noise,
+ * discretised to the turn lattice when turn_radians > 0. */
+int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, float turn_radians,
+                     uint64_t seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIE_HIP_H */

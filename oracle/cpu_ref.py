@@ -314,7 +314,7 @@ class RefGradientAgent:
         if turn_sign is None:
             turn_sign = orng.turn_signs(self._seed, step, N)
         if noise is None:
-            noise = orng.normals2(self._seed, step + 1, N, orng.STREAM_NOISE) if self._noise_scale != 0 \
+            noise = orng.normals2(self._seed, step, N, orng.STREAM_NOISE) if self._noise_scale != 0 \
                 else np.zeros((2, N))
         action = np.zeros((3, N))
         grad_field = gradient_field(medium[M_CHEM], self._normalized, self._grad_clip)

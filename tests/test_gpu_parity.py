@@ -1,0 +1,466 @@
+"""Parity of the HIP path (libdie_hip.so through die_amd's host classes) against the CPU
+oracle on identical inputs.  Integer / index work (cells, ownership, alive counts,
+coordinates in Q0.32) must be bit-exact; float fields and per-agent floats must agree within
+the north-star tolerance of 1e-5 relative (fp32) — the exact rtol/atol is written at each
+assert.  Discrete decisions that sit on a float threshold may differ for a vanishing
+fraction of slots; every such slot must be *explained* by an oracle margin below 1e-4.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import cpu_ref as R          # noqa: E402
+from oracle import rng as orng           # noqa: E402
+
+RTOL = 1e-5          # north_star: "within 1e-5 relative fp32"
+
+
+@pytest.fixture(scope='module')
+def die():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import die_amd
+    return die_amd
+
+
+def q32(v):
+    from die_amd.device_array import from_q32, to_q32
+    return from_q32(to_q32(v))
+
+
+def f32(v):
+    return np.asarray(v, dtype=np.float32).astype(np.float64)
+
+
+def random_state(W, H, N, K, rs, collide=0.3, chem_scale=1.0):
+    """Random medium + agents, representable exactly on the device (f32 fields, Q0.32 coords)."""
+    xs, ys = np.linspace(0, 1, W), np.linspace(0, 1, H)
+    chem = rs.rand(W, H) * chem_scale
+    chem = R.diffuse_decay(chem, 1.0, 0.0)            # smooth, so that gradients are meaningful
+    chem[: W // 4, : H // 4] = 0.                        # a flat patch: zero gradient → masked
+    food = np.round(rs.rand(W, H) * 0.5 * (rs.rand(W, H) < 0.6), 3)
+    medium = np.stack([np.zeros((W, H)), f32(food), f32(chem)])
+    agents = np.zeros((4, N))
+    agents[0] = q32(rs.rand(N) * 0.999999)
+    agents[1] = q32(rs.rand(N) * 0.999999)
+    nc = int(collide * N)
+    if nc > 1:                                           # forced collisions: copy positions around
+        src = rs.randint(0, N, nc)
+        dst = rs.randint(0, N, nc)
+        agents[0, dst] = agents[0, src]
+        agents[1, dst] = agents[1, src]
+    alive = np.zeros(N)
+    alive[rs.permutation(N)[:K]] = 1.
+    agents[2] = alive
+    agents[3] = f32(0.1 + 0.9 * rs.rand(N)) * alive + f32(rs.randn(N) * 0.01) * (1 - alive)
+    ix, iy = R.cell(agents[0], W), R.cell(agents[1], H)
+    medium[0][ix[alive > 0], iy[alive > 0]] = 1.
+    return medium, agents
+
+
+def ref_dyn(dyn):
+    return R.RefDynamics(op_action_cost=R.zero_cost if dyn.op_action_cost.__name__ == 'zero_cost' else R.linear_action_cost,
+                         rate_feed=dyn.rate_feed, rate_decay_chem=dyn.rate_decay_chem, boundary=dyn.boundary.value,
+                         diffuse_sigma=dyn.diffuse_sigma, food_infinite=dyn.food_infinite, agents_die=dyn.agents_die)
+
+
+# ------------------------------------------------------------------------------------ diffusion
+@pytest.mark.parametrize('W,H', [(6, 6), (2, 2), (5, 3), (37, 23), (256, 256), (300, 520), (16, 1024), (1030, 17)])
+@pytest.mark.parametrize('sigma', [0.5, 0.8, 1.5])
+def test_diffuse_decay_parity(die, W, H, sigma):
+    from die_amd import _lib
+    from die_amd.device_array import _ptr
+    rs = np.random.RandomState(W * 1000 + H)
+    chem = f32(rs.rand(W, H) * (rs.rand(W, H) < 0.5))
+    src = torch.from_numpy(chem.astype(np.float32)).cuda()
+    dst = torch.empty_like(src)
+    _lib.check(_lib.lib.die_diffuse_decay(_ptr(src), _ptr(dst), W, H, _lib.DIE_F32, sigma, 0.1, None), 'diffuse')
+    want = R.diffuse_decay(chem, float(np.float32(sigma)), float(np.float32(0.1)))
+    got = dst.cpu().numpy().astype(np.float64)
+    assert np.allclose(got, want, rtol=RTOL, atol=1e-7)
+    # mass conservation on the torus: sum(out) = (1 − decay)·sum(in)
+    assert np.isclose(got.sum(), 0.9 * chem.sum(), rtol=1e-5)
+
+
+def test_diffuse_impulse_kat(die):
+    """Impulse at the torus corner = wrapped outer product of the 5 taps (SURVEY §8c KAT)."""
+    from die_amd import _lib
+    from die_amd.device_array import _ptr
+    src = torch.zeros((6, 6), device='cuda')
+    src[0, 0] = 1.0
+    dst = torch.empty_like(src)
+    _lib.check(_lib.lib.die_diffuse_decay(_ptr(src), _ptr(dst), 6, 6, 0, 0.5, 0.1, None), 'diffuse')
+    w = R.gaussian_weights(0.5)
+    k = np.zeros(6)
+    for i, o in enumerate(range(-2, 3)):
+        k[o % 6] += w[i]
+    assert np.allclose(dst.cpu().numpy(), 0.9 * np.outer(k, k), rtol=RTOL, atol=1e-9)
+
+
+def test_diffuse_f16_fields(die):
+    from die_amd import _lib
+    from die_amd.device_array import _ptr
+    rs = np.random.RandomState(2)
+    chem = rs.rand(64, 96).astype(np.float16)
+    src = torch.from_numpy(chem).cuda()
+    dst = torch.empty_like(src)
+    _lib.check(_lib.lib.die_diffuse_decay(_ptr(src), _ptr(dst), 64, 96, _lib.DIE_F16, 0.5, 0.1, None), 'diffuse')
+    want = R.diffuse_decay(chem.astype(np.float64), 0.5, float(np.float32(0.1)))
+    # f16 storage: half a unit in the 11-bit significand
+    assert np.allclose(dst.cpu().numpy().astype(np.float64), want, rtol=1e-3, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ forward
+def physarum_margins(agent_ref, agents, medium, dir0, W, H):
+    """Distance of every slot from each float threshold of the forward pass (oracle, f64)."""
+    off = np.stack(R.polar2xy(agent_ref._sense_offset_scale, dir0))
+    fx = (agents[0] + off[0]) * (W - 1) + 0.5
+    fy = (agents[1] + off[1]) * (H - 1) + 0.5
+    m_cell = np.minimum(np.abs(fx - np.round(fx)), np.abs(fy - np.round(fy)))
+    grad = np.stack(np.gradient(medium[R.M_CHEM]))
+    px, py = R.cell(agents[0] + off[0], W), R.cell(agents[1] + off[1], H)
+    g = grad[:, px, py]
+    norm = np.hypot(g[0], g[1])
+    m_clip = np.abs(norm - agent_ref._grad_clip) / max(agent_ref._grad_clip, 1e-30)
+    drads = np.arctan2(g[1], g[0]) * (norm >= agent_ref._grad_clip)
+    delta = R.renormalize_radians(dir0 - drads)
+    atol = agent_ref._turn_radians * agent_ref._rtol
+    m_turn = np.abs(np.abs(delta) - atol / 0.99)
+    m_sense = np.abs(np.abs(delta) - agent_ref._sense_radians)
+    m_pi = np.abs(np.abs(dir0 - drads) - np.pi)
+    m_zero = np.where(norm >= agent_ref._grad_clip, np.abs(drads), 1.0)      # |drads| ≈ 0 with a live gradient
+    return np.minimum.reduce([m_cell, m_clip, m_turn, m_sense, m_pi, m_zero])
+
+
+@pytest.mark.parametrize('W,H,N', [(16, 12, 50), (64, 64, 3000), (200, 333, 40000), (2, 2, 7), (1024, 1024, 200000)])
+@pytest.mark.parametrize('cfg', ['default', 'wide'])
+def test_physarum_forward_parity(die, W, H, N, cfg):
+    rs = np.random.RandomState(W + H + N)
+    medium, agents = random_state(W, H, N, K=int(0.8 * N), rs=rs)
+    kw = dict(scale=1.53 / (W - 1), sense_offset=min(0.3, 10.2 / (W - 1)), turn_angle=30, sense_angle=90,
+              turn_tolerance=0.1) if cfg == 'default' else \
+        dict(scale=0.0075, sense_offset=0.03, turn_angle=35, sense_angle=120, turn_tolerance=0.05, deposit=4.5)
+    turn = np.radians(kw['turn_angle'])
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    sign = rs.randint(0, 2, N) * 2.0 - 1.0
+
+    ref = R.RefPhysarumAgent(N, init_noise=np.ones((2, N)), **kw)
+    ref._direction_rads = dir0.copy()
+    want = ref.forward((agents, medium), turn_sign=sign)
+    margins = physarum_margins(ref, agents, medium, dir0, W, H)
+
+    env = die.Env.from_numpy(medium, agents)
+    dev = die.PhysarumAgent(max_agents=N, **kw)
+    dev.set_state(dir0)
+    dev.set_turn_signs(sign)
+    got = dev.forward(env._get_current_obs).to_numpy()
+    got_dir = dev._direction_rads.cpu().numpy().astype(np.float64)
+
+    # a slot disagrees if its heading differs (mod 2π) or its action is out of tolerance
+    ddir = np.abs(R.renormalize_radians(got_dir - ref._direction_rads))
+    atol = 4e-7 * kw['scale']                   # cos/sin near a zero crossing: f32 angle rounding × scale
+    ok = (ddir < 1e-5) & np.isclose(got[0], want[0], rtol=RTOL, atol=atol) & \
+        np.isclose(got[1], want[1], rtol=RTOL, atol=atol) & np.isclose(got[2], want[2], rtol=RTOL, atol=1e-9)
+    bad = ~ok
+    assert bad.mean() <= 1e-4, f'{bad.sum()} of {N} slots differ'
+    assert (margins[bad] < 1e-4).all(), f'unexplained mismatches: margins {margins[bad]}'
+
+
+def test_physarum_forward_with_reference_made_vectors(die, golden_dir):
+    """The turn logic on device vs outputs of the reference's own _discrete_turn
+    (tests/golden/ref_helpers.npz, case 0 = default parameters): build a chem field whose
+    gradient at each agent's probe cell is the golden sampled gradient."""
+    import os
+    G = np.load(os.path.join(golden_dir, 'ref_helpers.npz'))
+    g_in, dir0, rand01 = G['turn0_grad_in'], G['turn0_dir0'], G['turn0_rand01']
+    want_g, want_mask = G['turn0_grad_out'], G['turn0_deposit_mask']
+    n = 1000                                    # includes the zero-gradient, +x and threshold cases
+    sel = np.r_[0:200, 400:450, 500:1100, 2000:2150][:n]
+    n = len(sel)
+    # one agent per 3x3 block of a (3n)x3 field, chem = linear ramp a·x + b·y inside the block
+    W, H = 3 * n, 3
+    chem = np.zeros((W, H))
+    for k, s in enumerate(sel):
+        gx, gy = g_in[:, s]
+        for i in range(3):
+            for j in range(3):
+                chem[3 * k + i, j] = 1.0 + 0.25 * (gx * (i - 1) + gy * (j - 1))
+    agents = np.zeros((4, n))
+    agents[0] = q32((3 * np.arange(n) + 1) / (W - 1))
+    agents[1] = q32(np.full(n, 0.5))
+    agents[2] = 1
+    medium = np.stack([np.zeros((W, H)), np.full((W, H), 0.25), f32(chem)])
+    env = die.Env.from_numpy(medium, agents)
+    dev = die.PhysarumAgent(max_agents=n, scale=1.0, sense_offset=0.0)
+    dev.set_state(f32(dir0[sel]))
+    dev.set_turn_signs((rand01[sel] - 0.5) * 2)
+    got = dev.forward(env._get_current_obs).to_numpy()
+    # the field stores the ramp in f32, so sampled directions carry ~1e-7 noise: compare away from thresholds
+    atol_t = np.radians(30) * 0.1
+    drads = np.arctan2(g_in[1, sel], g_in[0, sel])
+    delta = R.renormalize_radians(dir0[sel] - drads)
+    safe = (np.abs(np.abs(delta) - atol_t / 0.99) > 1e-5) & (np.abs(np.abs(delta) - np.pi / 2) > 1e-5) & \
+           ((np.abs(drads) > 1e-5) | (np.hypot(g_in[0, sel], g_in[1, sel]) == 0) | (g_in[1, sel] == 0))
+    assert safe.mean() > 0.6
+    assert np.allclose(got[0][safe], want_g[0, sel][safe], rtol=RTOL, atol=2e-6)
+    assert np.allclose(got[1][safe], want_g[1, sel][safe], rtol=RTOL, atol=2e-6)
+    want_dep = 4.0 * 0.25 * np.clip(want_mask[sel], 0.1, 1.0)
+    assert np.allclose(got[2][safe], want_dep[safe], rtol=RTOL)
+
+
+@pytest.mark.parametrize('inertia,noise', [(0.9, 0.025), (0.0, 0.05), (0.95, 0.0)])
+def test_gradient_agent_forward_parity(die, inertia, noise):
+    W, H, N = 96, 80, 5000
+    rs = np.random.RandomState(11)
+    medium, agents = random_state(W, H, N, K=N, rs=rs)
+    prev = f32(rs.normal(0, .4, (2, N)))
+    kw = dict(scale=0.01, deposit=4.5, inertia=inertia, sense_offset=0.03, noise_scale=noise)
+    ref = R.RefGradientAgent(N, init_noise=prev, seed=77, **kw)
+    ref._direction_rads = f32(ref._direction_rads)
+    dir0 = ref._direction_rads.copy()
+    want = ref.forward((agents, medium))
+    env = die.Env.from_numpy(medium, agents)
+    dev = die.GradientAgent(max_agents=N, seed=77, **kw)
+    dev.set_state(dir0, prev)
+    got = dev.forward(env._get_current_obs).to_numpy()
+    # Box–Muller in f32 on device vs f64 in the oracle: absolute 1e-6 on O(1) normals × noise_scale
+    assert np.mean(~np.isclose(got[:2], want[:2], rtol=RTOL, atol=2e-8 + 2e-6 * noise * 0.01)) < 2e-3
+    assert np.allclose(got[2], want[2], rtol=RTOL, atol=1e-9)
+    if inertia:
+        assert np.mean(~np.isclose(dev._prev_grad.cpu().numpy(), ref._prev_grad, rtol=RTOL, atol=2e-6)) < 2e-3
+
+
+def test_brownian_and_const_forward_parity(die):
+    N = 10000
+    rs = np.random.RandomState(5)
+    medium, agents = random_state(32, 32, N, K=6000, rs=rs)
+    env = die.Env.from_numpy(medium, agents)
+    b = die.BrownianAgent(move_scale=0.01, deposit_scale=0.5, seed=99)
+    rb = R.RefBrownianAgent(move_scale=0.01, deposit_scale=0.5, seed=99)
+    for _ in range(3):                          # the step counter advances the stream
+        got = b.forward(env._get_current_obs).to_numpy()
+        want = rb.forward((agents, medium))
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-9)
+        assert (got[:, agents[2] == 0] == 0).all()
+    c = die.ConstAgent(delta_xy=(-0.01, 0.005), deposit=0.1).forward(env._get_current_obs).to_numpy()
+    assert np.allclose(c, R.RefConstAgent((-0.01, 0.005), 0.1).forward((agents, medium)), rtol=1e-7)
+
+
+# ------------------------------------------------------------------------------------ env.step
+def quantised_action(N, rs, scale):
+    """Random action whose displacements are exactly representable in Q0.32 AND f32."""
+    dx = np.rint(f32(rs.uniform(-scale, scale, N)) * 2 ** 32) / 2 ** 32
+    dy = np.rint(f32(rs.uniform(-scale, scale, N)) * 2 ** 32) / 2 ** 32
+    dx, dy = f32(dx), f32(dy)
+    assert np.array_equal(np.rint(dx * 2 ** 32) / 2 ** 32, dx)
+    return np.stack([dx, dy, f32(rs.rand(N) * 2.0)])
+
+
+STEP_CASES = [
+    dict(W=16, H=12, N=60, K=40),
+    dict(W=64, H=64, N=4096, K=600),                         # reference layout: N = W·H, mostly dead slots
+    dict(W=200, H=333, N=30000, K=30000),                    # compact: no dead slots
+    dict(W=2, H=2, N=9, K=5),
+    dict(W=128, H=128, N=5000, K=0),                         # nobody alive
+    dict(W=64, H=64, N=2000, K=1500, boundary='limit'),
+    dict(W=64, H=64, N=2000, K=1500, food_infinite=True),
+    dict(W=64, H=64, N=2000, K=1500, agents_die=True),
+    dict(W=64, H=64, N=2000, K=1500, zero_cost=True),
+    dict(W=96, H=40, N=3000, K=2500, sigma=0.8, rate_feed=0.3, decay=0.05),
+    dict(W=1024, H=1024, N=157286, K=157286),
+]
+
+
+@pytest.mark.parametrize('case', STEP_CASES, ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items()))
+def test_env_step_parity(die, case):
+    W, H, N, K = case['W'], case['H'], case['N'], case['K']
+    rs = np.random.RandomState(W * 7 + N)
+    medium, agents = random_state(W, H, N, K, rs)
+    if case.get('agents_die'):
+        agents[3, ::3] = 1e-5 * agents[2, ::3]              # some agents starve this step
+    dyn = die.Dynamics(boundary=die.BoundaryCondition(case.get('boundary', 'wrap')),
+                       food_infinite=case.get('food_infinite', False), agents_die=case.get('agents_die', False),
+                       op_action_cost=die.zero_cost if case.get('zero_cost') else die.linear_action_cost,
+                       diffuse_sigma=case.get('sigma', 0.5), rate_feed=case.get('rate_feed', 0.1),
+                       rate_decay_chem=case.get('decay', 0.1))
+    scale = 3.0 / W if case.get('boundary') != 'limit' else 0.6      # 'limit': many agents hit the walls
+    action = quantised_action(N, rs, scale)
+
+    rd = ref_dyn(dyn)
+    for f in ('rate_feed', 'rate_decay_chem', 'diffuse_sigma'):       # the C struct carries them as f32
+        setattr(rd, f, float(np.float32(getattr(rd, f))))
+    ref = R.RefEnv(medium, agents, rd)
+    _, want_reward, want_term, _, want_info = ref.step(action)
+
+    env = die.Env.from_numpy(medium, agents, dyn)
+    obs, reward, term, trunc, info = env.step(die.DeviceAction.from_numpy(action, env.device))
+    got_agents = env.agents.to_numpy()
+    got_medium = env.medium.to_numpy()
+
+    # integer / index work: bit-exact
+    if case.get('boundary') == 'limit':                     # 1.0 is stored as 1 − 2^-32
+        assert np.abs(got_agents[:2] - ref.agents[:2]).max() <= 2.0 ** -32
+    else:
+        assert np.array_equal(got_agents[:2], ref.agents[:2])
+    assert np.array_equal(got_agents[2], ref.agents[2])
+    assert np.array_equal(got_medium[0], ref.medium[0])
+    assert info['num_agents'] == want_info['num_agents'] and term == want_term and trunc is False
+    # ownership: the highest alive slot standing on each occupied cell
+    alive = agents[2] > 0
+    ix, iy = R.cell(ref.agents[0], W), R.cell(ref.agents[1], H)
+    if not case.get('agents_die'):
+        want_owner = np.full((W, H), -1, dtype=np.int64)
+        idx = np.nonzero(alive)[0]
+        want_owner[ix[idx], iy[idx]] = idx                  # ascending order: the last (highest) write stays
+        assert np.array_equal(env.medium.owner_slots().cpu().numpy(), want_owner)
+    # floats: 1e-5 relative
+    assert np.allclose(got_agents[3], ref.agents[3], rtol=RTOL, atol=1e-7)
+    assert np.allclose(got_medium[1], ref.medium[1], rtol=RTOL, atol=1e-8)
+    assert np.allclose(got_medium[2], ref.medium[2], rtol=RTOL, atol=1e-7)
+    assert abs(reward - want_reward) <= RTOL * np.abs(ref.last_gained).sum() + 1e-9
+    assert obs[0] is env.agents and obs[1] is env.medium
+
+
+def test_step_kat_collisions_and_dead_slots(die):
+    """Hand-checkable case (tests/test_oracle_kat.py): last writer wins, feed duplication,
+    dead slot on an occupied cell consumes, reward counts every slot."""
+    xy = [(0.2, 0.2), (0.21, 0.19), (0.8, 0.6), (0.2, 0.21), (0.2, 0.2), (0.6, 0.0)]
+    alive = [1, 1, 1, 1, 0, 0]
+    agents = np.zeros((4, 6))
+    agents[0], agents[1] = q32([p[0] for p in xy]), q32([p[1] for p in xy])
+    agents[2] = alive
+    agents[3] = 0.5
+    medium = np.zeros((3, 6, 6))
+    medium[1] = 0.5
+    medium[2] = 1.0
+    act = np.zeros((3, 6))
+    act[2] = [10., 20., 30., 40., 50., 60.]
+    env = die.Env.from_numpy(medium, agents, die.Dynamics(op_action_cost=die.zero_cost))
+    env._stage('die_agent_move_claim', act)
+    env.medium.epoch = env.medium.epoch            # same epoch as uploaded: claims join the uploaded words
+    env._stage('die_agent_resolve', act)
+    m = env.medium.to_numpy()
+    assert m[2][1, 1] == 41.0 and m[2][4, 3] == 31.0 and m[2].sum() == 36 + 70
+    assert m[0].sum() == 2
+    assert np.isclose(m[1][1, 1], 0.45) and np.isclose(m[1][4, 3], 0.45) and np.isclose(m[1].sum(), 18 - 0.1)
+    a = env.agents.to_numpy()
+    assert np.allclose(a[3], [0.55, 0.55, 0.55, 0.55, 0.55, 0.5])
+
+
+def test_epoch_wrap_and_multi_step_free_run(die):
+    """20 free-running steps (crosses the 7-step ownership-epoch wrap twice) with seeded
+    Philox turn bits on both sides.  fp32 vs fp64 trajectories may part at a threshold, so
+    the bar is statistical: ≥ 99 % of agents in the same cell, fields close in the L1 sense."""
+    W = H = 64
+    medium, agents = R.synthetic_init(W, H, 0.15, seed=1234)
+    medium[1] = f32(medium[1])
+    agents[:2] = q32(agents[:2])
+    agents[3] = f32(agents[3])
+    N = agents.shape[1]
+    kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    ref_env = R.RefEnv(medium, agents)
+    ref_agent = R.RefPhysarumAgent(N, seed=42, **kw)
+    dir0 = f32(ref_agent._direction_rads)
+    ref_agent._direction_rads = dir0.copy()
+    env = die.Env.from_numpy(medium, agents)
+    dev = die.PhysarumAgent(max_agents=N, seed=42, **kw)
+    dev.set_state(dir0)
+    obs, robs = env._get_current_obs, ref_env.obs
+    rewards = []
+    for _ in range(20):
+        obs, rew, *_ = env.step(dev.forward(obs))
+        robs, rrew, *_ = ref_env.step(ref_agent.forward(robs))
+        rewards.append((rew, rrew))
+    a, m = env.agents.to_numpy(), env.medium.to_numpy()
+    K = int(agents[2].sum())
+    same_cell = (R.cell(a[0, :K], W) == R.cell(ref_env.agents[0, :K], W)) & \
+                (R.cell(a[1, :K], H) == R.cell(ref_env.agents[1, :K], H))
+    assert same_cell.mean() >= 0.99
+    assert np.abs(m[2] - ref_env.medium[2]).sum() <= 0.02 * np.abs(ref_env.medium[2]).sum()
+    assert np.abs(m[1] - ref_env.medium[1]).sum() <= 0.01 * np.abs(ref_env.medium[1]).sum()
+    assert (m[0] != ref_env.medium[0]).mean() <= 0.01
+    r = np.array(rewards)
+    assert np.allclose(r[:, 0], r[:, 1], rtol=0.02, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------ data_init
+@pytest.mark.parametrize('W,H,ratio', [(16, 12, 0.15), (64, 64, 0.05), (300, 200, 0.15), (1024, 1024, 0.15)])
+def test_init_parity(die, W, H, ratio):
+    seed = 1234
+    want_m, want_a = R.synthetic_init(W, H, ratio, seed)
+    env = die.Env((W, H), die.Dynamics(init_agent_ratio=ratio), seed=seed)
+    m, a = env.medium.to_numpy(), env.agents.to_numpy()
+    assert np.array_equal(m[0], want_m[0])                   # seeded cells: integer logic, exact
+    K = int(want_m[0].sum())
+    assert env._num_seeded == K and a.shape == (4, W * H)
+    assert np.abs(a[:2] - want_a[:2]).max() <= 2.0 ** -32    # Q0.32 of linspace labels
+    assert np.array_equal(a[2], want_a[2])
+    assert np.allclose(a[3], want_a[3], rtol=1e-6)
+    assert (m[2] == 0).all()
+    # food: f32 of a 3-decimal value; device sin() may round an exact .0005 tie differently
+    diff = np.abs(m[1] - want_m[1])
+    assert (diff > 1e-6).mean() <= 1e-5 and diff.max() <= 1.001e-3
+    # ownership words name the slot seeded on each cell (row-major order)
+    own = env.medium.owner_slots().cpu().numpy()
+    ix, iy = want_m[0].nonzero()
+    assert np.array_equal(own[ix, iy], np.arange(K)) and (own[want_m[0] == 0] == -1).all()
+    # compact allocation
+    env2 = die.Env((W, H), die.Dynamics(init_agent_ratio=ratio), seed=seed, max_agents='alive')
+    assert env2.agents.N == K and env2._all_alive
+    assert np.array_equal(env2.agents.to_numpy(), a[:, :K])
+
+
+def test_heading_init_parity(die):
+    N = 20000
+    dev = die.PhysarumAgent(max_agents=N, seed=7)
+    dev._alloc_state('cuda:0')
+    ref = R.RefPhysarumAgent(N, seed=7)
+    got = dev._direction_rads.cpu().numpy().astype(np.float64)
+    assert np.mean(np.abs(got - ref._direction_rads) > 1e-6) <= 1e-4      # lattice-boundary ties only
+    lattice = got / np.radians(30)
+    assert np.abs(lattice - np.round(lattice)).max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------ full size
+def test_full_size_properties_4096(die):
+    """BASELINE config 3 (4096², ratio .15): size-independent invariants instead of the oracle."""
+    W = H = 4096
+    env = die.Env((W, H), die.Dynamics(init_agent_ratio=0.15), seed=1234, max_agents='alive')
+    K = env.agents.N
+    assert abs(K / (W * H) - 0.15) < 0.002
+    agent = die.PhysarumAgent(max_agents=K, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), seed=3)
+    obs = env._get_current_obs
+    for step in range(9):
+        food0 = env.medium.food.double().sum().item()
+        af0 = env.agents.agent_food.double().sum().item()
+        chem0 = env.medium.chem.double().sum().item()
+        action = agent.forward(obs)
+        obs, reward, term, _, info = env.step(action)
+        a = action.data.double()
+        occ = env.medium.occupied()
+        # every alive agent stands on an occupied cell; no more occupied cells than agents
+        n_occ = int(occ.sum().item())
+        assert 0.85 * K < n_occ <= K and info['num_agents'] == K and not term
+        # move: |step| = scale for a normalised Physarum action
+        assert torch.allclose(torch.hypot(a[0], a[1]), torch.full_like(a[0], 1.53 / (W - 1)), rtol=1e-4)
+        # reward == Σ Δagent_food; food lost by the field == rate·Σ food over occupied cells (once per cell)
+        af1 = env.agents.agent_food.double().sum().item()
+        assert abs((af1 - af0) - reward) <= 1e-5 * abs(af0)
+        food1 = env.medium.food.double().sum().item()
+        lost = food0 - food1
+        assert lost >= 0 and abs(lost - (env.medium.food.double() * occ).sum().item() * (0.1 / 0.9)) <= 1e-4 * food0
+        # chem: Σ after = 0.9·(Σ before + Σ winner deposits); winners = owners of occupied cells
+        owners = env.medium.owner_slots()[occ]
+        dep = a[2][owners].sum().item()
+        chem1 = env.medium.chem.double().sum().item()
+        assert abs(chem1 - 0.9 * (chem0 + dep)) <= 1e-4 * max(chem1, 1.0)
+    # owners are alive slots standing on their cell
+    x, y = env.agents.q32_numpy()
+    own = env.medium.owner_slots().cpu().numpy()
+    ix = ((x.astype(np.uint64) * np.uint64(W - 1) + np.uint64(2 ** 31)) >> np.uint64(32)).astype(np.int64)
+    iy = ((y.astype(np.uint64) * np.uint64(H - 1) + np.uint64(2 ** 31)) >> np.uint64(32)).astype(np.int64)
+    assert (own[ix, iy] >= np.arange(K)).all()                 # the owner of my cell is me or a higher slot
+    o = own[own >= 0]
+    assert (ix[o] * H + iy[o] == np.nonzero(own.ravel() >= 0)[0]).all()

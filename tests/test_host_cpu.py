@@ -1,0 +1,108 @@
+"""CPU-only checks of the boundary and the host logic: the C-ABI library loads and exports
+every symbol include/die_hip.h declares, struct layouts agree, host helpers agree with the
+oracle.  No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def built_lib():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('die_build', os.path.join(ROOT, 'die_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.build()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, 'include', 'die_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(die_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_header_symbols_exported(built_lib):
+    lib = C.CDLL(built_lib)
+    names = _declared_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/die_hip.h but not exported'
+    from die_amd import _lib
+    assert sorted(_lib.EXPORTS) == names
+    assert _lib.lib.die_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layouts_match_header(built_lib):
+    from die_amd import _lib
+    # sizes follow from the field lists in include/die_hip.h under the x86-64 SysV ABI
+    assert C.sizeof(_lib.Medium) == 4 * 4 + 4 * 8
+    assert C.sizeof(_lib.Agents) == 8 + 4 * 8
+    assert C.sizeof(_lib.Action) == 8 + 3 * 8
+    assert C.sizeof(_lib.Dynamics) == 10 * 4
+    assert C.sizeof(_lib.GradientAgent) == 12 * 4 + 4 * 8 + 8 + 4 + 4
+    assert C.sizeof(_lib.FoodSpec) == 8 + 4 * 8 * 8
+
+
+def test_argument_validation_without_gpu(built_lib):
+    """Bad arguments are rejected on the host before anything touches a device."""
+    from die_amd import _lib
+    assert _lib.lib.die_workspace_bytes(0, 4, 4) == -1
+    assert _lib.lib.die_workspace_bytes(4096, 4096, 4096 * 4096) >= 4096 * 4096 * 4
+    rc = _lib.lib.die_diffuse_decay(None, None, 8, 8, 0, 0.5, 0.1, None)
+    assert rc == -1 and b'non-null' in _lib.lib.die_last_error()
+    m = _lib.Medium(1, 1, 0, 1, None, None, None, None)
+    a = _lib.Agents(0, None, None, None, None)
+    g = _lib.GradientAgent()
+    u = _lib.Action(0, None, None, None)
+    assert _lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(g), C.byref(u), None) == -1
+    with pytest.raises(_lib.DieError):
+        _lib.check(-1, 'x')
+
+
+def test_q32_roundtrip_and_cell_formula():
+    from die_amd.device_array import from_q32, to_q32
+    from oracle import cpu_ref as R
+    v = np.array([0., 0.25, 1 / 3, 0.999999999, 1.0])
+    q = to_q32(v)
+    assert q.dtype == np.uint32 and q[0] == 0 and q[1] == 2 ** 30 and q[-1] == 2 ** 32 - 1
+    assert np.abs(from_q32(q) - v).max() <= 2.0 ** -32
+    n = 4096
+    cells = ((q.astype(np.uint64) * np.uint64(n - 1) + np.uint64(2 ** 31)) >> np.uint64(32)).astype(np.int64)
+    assert (cells == R.cell(from_q32(q), n)).all()
+
+
+def test_host_food_spec_matches_oracle():
+    from die_amd.data_init import food_spec_from_seed
+    from oracle import cpu_ref as R
+    for seed in (0, 1234, 2 ** 40 + 17):
+        s = food_spec_from_seed(seed)
+        o = R.FoodSpec.from_seed(seed)
+        assert s.n_waves == len(o.fx)
+        for i in range(s.n_waves):
+            assert s.fx[i] == o.fx[i] and s.fy[i] == o.fy[i]
+            assert np.isclose(s.phase[i], o.phase[i], rtol=0, atol=1e-15) and np.isclose(s.amp[i], o.amp[i], rtol=1e-15)
+
+
+def test_env_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import die_amd
+    with pytest.raises(RuntimeError, match='no CPU path'):
+        die_amd.Env((8, 8))
+
+
+def test_agent_save_load_roundtrip(tmp_path):
+    import die_amd
+    a = die_amd.PhysarumAgent(max_agents=64, scale=0.006, turn_angle=30, sense_offset=0.04, seed=5)
+    f = tmp_path / 'agent.json'
+    a.save(f)
+    b = die_amd.PhysarumAgent.load(f)
+    assert b.init_params == a.init_params and b.init_params['sense_offset'] == 0.04
+    c = die_amd.BrownianAgent(move_scale=0.02)
+    assert c.init_params == {'move_scale': 0.02, 'deposit_scale': 0.5, 'seed': None}
