@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — env steps/sec of the Physarum grid step (agent.forward + env.step) on MI355X.
+
+Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON
+line on rank 0.  A "step" is one PhysarumAgent.forward + one Env.step (action handed over in
+HBM, as the Gym API does) over a synthetic 4096x4096 fp32 grid (BASELINE.json configs[2]) with
+the state already resident in HBM.  Next to it: `roofline` for the dominant kernel (HIP-event
+timed here, algorithmic bytes from DESIGN.md §5) and `cpu_baseline` (the float64 numpy oracle,
+a *port*, timed on this box's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=200)
+    p.add_argument('--warmup', type=int, default=20)
+    p.add_argument('--size', type=int, default=4096)
+    p.add_argument('--ratio', type=float, default=0.15)
+    p.add_argument('--seed', type=int, default=1234)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-steps', type=int, default=3)
+    p.add_argument('--kernel-reps', type=int, default=20)
+    return p.parse_args()
+
+
+def algorithmic_bytes(C, K):
+    """DESIGN.md §5 / SURVEY.md §8(d), fp32 fields: B = 12·C + 104·K per env step, split by kernel."""
+    return {
+        'k_gradient_forward': 48 * K,     # x,y,heading R 12 + heading W 4 + action W 12 + 5 gathers 20
+        'k_move_claim': 44 * K,           # x,y RW 16 + agent_food RW 8 + action R 12 + food gather 4 + claim 4
+        'k_resolve': 20 * K,              # chem RMW 8 + food RMW 8 + agents mark 4 (winner scatter)
+        'k_diffuse': 8 * C,               # chem R + W
+        'step': 12 * C + 104 * K,
+    }
+
+
+def time_kernels(env, agent, reps):
+    """Average launch duration (µs) of each kernel of the step, HIP events on the launch stream."""
+    import torch
+    from die_amd import _lib
+    obs = env._get_current_obs
+    out = {}
+
+    def timed(fn):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for a, b in ev:
+            a.record()
+            fn()
+            b.record()
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in ev) / reps * 1e3
+
+    action = agent.forward(obs)
+    out['k_gradient_forward'] = timed(lambda: agent.forward(obs))
+
+    def move():
+        env.medium.next_epoch()
+        env._stage('die_agent_move_claim', action)
+    out['k_move_claim'] = timed(move)
+    out['k_resolve'] = timed(lambda: env._stage('die_agent_resolve', action))
+    out['k_diffuse'] = timed(env._medium_diffuse_decay)
+    return out
+
+
+def cpu_baseline(env, agent_kw, n_steps, seed):
+    """The float64 numpy/scipy oracle on the same initial state (downloaded from the device)."""
+    import numpy as np
+    from oracle import cpu_ref as R
+    medium, agents = env.medium.to_numpy(), env.agents.to_numpy()
+    ref_env = R.RefEnv(medium, agents)
+    ref_agent = R.RefPhysarumAgent(agents.shape[1], seed=seed, **agent_kw)
+    obs = ref_env.obs
+    obs, *_ = ref_env.step(ref_agent.forward(obs))       # warm-up step (first-touch, caches)
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        obs, *_ = ref_env.step(ref_agent.forward(obs))
+    dt = time.perf_counter() - t0
+    return n_steps / dt, dt
+
+
+def main():
+    args = parse()
+    import torch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+    elif args.gpus > 1:
+        sys.exit('launch N>1 with torch.distributed.run (one rank per GPU)')
+    device = torch.device(f'cuda:{local_rank}')
+    torch.cuda.set_device(device)
+
+    import die_amd
+    W = H = args.size
+    # weak scaling: every rank steps its own W×H torus (replicas), seeds differ per rank
+    env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
+                      max_agents='alive', device=device, sync=False)
+    K = env.agents.N
+    agent_kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), turn_angle=30, sense_angle=90,
+                    turn_tolerance=0.1, deposit=4.0)
+    agent = die_amd.PhysarumAgent(max_agents=K, seed=args.seed + rank, **agent_kw)
+
+    obs = env._get_current_obs
+    results = []
+
+    def one_step():
+        nonlocal obs
+        obs, res, *_ = env.step(agent.forward(obs))
+        return res
+
+    for _ in range(args.warmup):
+        one_step()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        results.append(one_step())
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last_reward, last_alive = env.read_result(results[-1])
+
+    steps_per_s = args.steps / dt * world          # whole job: every rank advanced its own grid
+    line = {
+        'metric': 'env steps/sec on 4096^2 Physarum grid', 'value': round(steps_per_s, 2), 'unit': 'env steps/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'PhysarumAgent {W}x{H} fp32 fields, agent ratio {args.ratio} (BASELINE configs[2]); '
+                               'step = PhysarumAgent.forward + Env.step with the action handed over in HBM',
+                   'grid': [W, H], 'alive_agents': K, 'agent_slots': K, 'steps_per_rank': args.steps,
+                   'parallelism': 'single GPU' if world == 1 else f'{world} independent grid replicas (no collective)',
+                   'last_reward': round(last_reward, 3), 'last_num_agents': last_alive},
+    }
+    if rank == 0:
+        C = W * H
+        B = algorithmic_bytes(C, K)
+        kt = time_kernels(env, agent, args.kernel_reps)
+        dom = max(kt, key=kt.get)
+        ach = B[dom] / (kt[dom] * 1e-6) / 1e9
+        line['roofline'] = {
+            'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+            'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
+            'kernels_us': {k: round(v, 2) for k, v in kt.items()},
+            'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},
+            'step': {'algorithmic_bytes': B['step'],
+                     'achieved': round(B['step'] / (dt / args.steps) / 1e9, 1),
+                     'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            v, cpu_dt = cpu_baseline(env, agent_kw, args.cpu_steps, args.seed)
+            line['cpu_baseline'] = {
+                'value': round(v, 4), 'unit': 'env steps/s', 'cores': 1, 'kind': 'port',
+                'sample': f'{args.cpu_steps} steps of the same {W}x{H} workload ({K} alive-only slots) after 1 warm-up '
+                          f'step, {cpu_dt:.1f} s; float64 numpy/scipy oracle (index arithmetic instead of the '
+                          "reference's pandas label lookups, so faster than the reference itself); host has "
+                          f'{os.cpu_count()} cores, numpy/scipy kernels on this path run on 1 thread'}
+        print(json.dumps(line), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -3,6 +3,11 @@ library is missing or does not load, importing this module raises."""
 import ctypes as C
 import os
 
+# torch first: it brings its own copy of the HIP runtime (soname libamdhip64.so.7).  Loaded
+# before libdie_hip.so, that copy also satisfies our NEEDED entry, so kernels launched here
+# and torch's allocations share one runtime; the other order puts two runtimes in the process.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libdie_hip.so')
 

@@ -164,8 +164,8 @@ def test_physarum_forward_parity(die, W, H, N, cfg):
     ok = (ddir < 1e-5) & np.isclose(got[0], want[0], rtol=RTOL, atol=atol) & \
         np.isclose(got[1], want[1], rtol=RTOL, atol=atol) & np.isclose(got[2], want[2], rtol=RTOL, atol=1e-9)
     bad = ~ok
-    assert bad.mean() <= 1e-4, f'{bad.sum()} of {N} slots differ'
-    assert (margins[bad] < 1e-4).all(), f'unexplained mismatches: margins {margins[bad]}'
+    assert (margins[bad] < 1e-4).all(), f'unexplained mismatches: slots {np.nonzero(bad)[0]}, margins {margins[bad]}'
+    assert bad.sum() <= max(3, 1e-4 * N), f'{bad.sum()} of {N} slots differ'
 
 
 def test_physarum_forward_with_reference_made_vectors(die, golden_dir):
@@ -349,40 +349,64 @@ def test_step_kat_collisions_and_dead_slots(die):
     assert np.allclose(a[3], [0.55, 0.55, 0.55, 0.55, 0.55, 0.5])
 
 
+def _free_run(die, medium, agents, kw, steps, seed=42):
+    N = agents.shape[1]
+    ref_env = R.RefEnv(medium, agents)
+    ref_agent = R.RefPhysarumAgent(N, seed=seed, **kw)
+    dir0 = f32(ref_agent._direction_rads)
+    ref_agent._direction_rads = dir0.copy()
+    env = die.Env.from_numpy(medium, agents)
+    dev = die.PhysarumAgent(max_agents=N, seed=seed, **kw)
+    dev.set_state(dir0)
+    obs, robs = env._get_current_obs, ref_env.obs
+    rewards = []
+    for _ in range(steps):
+        obs, rew, *_ = env.step(dev.forward(obs))
+        robs, rrew, *_ = ref_env.step(ref_agent.forward(robs))
+        rewards.append((rew, rrew))
+    return env, ref_env, np.array(rewards)
+
+
 def test_epoch_wrap_and_multi_step_free_run(die):
     """20 free-running steps (crosses the 7-step ownership-epoch wrap twice) with seeded
-    Philox turn bits on both sides.  fp32 vs fp64 trajectories may part at a threshold, so
-    the bar is statistical: ≥ 99 % of agents in the same cell, fields close in the L1 sense."""
+    Philox turn bits on both sides, from a generic state (off-lattice positions, smooth random
+    chem, sense angle off the 30° heading lattice so that no decision sits exactly on a
+    threshold).  fp32 and fp64 trajectories can then only part through a rare threshold flip:
+    ≥ 99 % of agents must end in the same cell and the fields must agree closely."""
+    W = H = 64
+    rs = np.random.RandomState(8)
+    medium, agents = random_state(W, H, 700, 600, rs, collide=0.05)
+    kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
+    env, ref_env, r = _free_run(die, medium, agents, kw, steps=20)
+    a, m = env.agents.to_numpy(), env.medium.to_numpy()
+    same_cell = (R.cell(a[0], W) == R.cell(ref_env.agents[0], W)) & (R.cell(a[1], H) == R.cell(ref_env.agents[1], H))
+    assert same_cell.mean() >= 0.99
+    assert np.abs(m[2] - ref_env.medium[2]).sum() <= 0.01 * np.abs(ref_env.medium[2]).sum()
+    assert np.abs(m[1] - ref_env.medium[1]).sum() <= 0.005 * np.abs(ref_env.medium[1]).sum()
+    assert (m[0] != ref_env.medium[0]).mean() <= 0.005
+    assert np.allclose(r[:, 0], r[:, 1], rtol=0.01, atol=1e-3)
+
+
+def test_free_run_default_parameters_statistics(die):
+    """The reference's default start (agents on cell centres, chem = 0, sense angle 90° on a
+    30° lattice) is full of EXACT ties — e.g. a probe on the symmetry axis of an isolated
+    deposit sees a gradient exactly 90° off the heading, |delta| == sense_radians up to the
+    last bit — which float64 and float32 resolve differently (and the reference itself by
+    rounding noise).  Trajectories therefore differ early; the populations must not."""
     W = H = 64
     medium, agents = R.synthetic_init(W, H, 0.15, seed=1234)
     medium[1] = f32(medium[1])
     agents[:2] = q32(agents[:2])
     agents[3] = f32(agents[3])
-    N = agents.shape[1]
     kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
-    ref_env = R.RefEnv(medium, agents)
-    ref_agent = R.RefPhysarumAgent(N, seed=42, **kw)
-    dir0 = f32(ref_agent._direction_rads)
-    ref_agent._direction_rads = dir0.copy()
-    env = die.Env.from_numpy(medium, agents)
-    dev = die.PhysarumAgent(max_agents=N, seed=42, **kw)
-    dev.set_state(dir0)
-    obs, robs = env._get_current_obs, ref_env.obs
-    rewards = []
-    for _ in range(20):
-        obs, rew, *_ = env.step(dev.forward(obs))
-        robs, rrew, *_ = ref_env.step(ref_agent.forward(robs))
-        rewards.append((rew, rrew))
+    env, ref_env, r = _free_run(die, medium, agents, kw, steps=40)
     a, m = env.agents.to_numpy(), env.medium.to_numpy()
-    K = int(agents[2].sum())
-    same_cell = (R.cell(a[0, :K], W) == R.cell(ref_env.agents[0, :K], W)) & \
-                (R.cell(a[1, :K], H) == R.cell(ref_env.agents[1, :K], H))
-    assert same_cell.mean() >= 0.99
-    assert np.abs(m[2] - ref_env.medium[2]).sum() <= 0.02 * np.abs(ref_env.medium[2]).sum()
-    assert np.abs(m[1] - ref_env.medium[1]).sum() <= 0.01 * np.abs(ref_env.medium[1]).sum()
-    assert (m[0] != ref_env.medium[0]).mean() <= 0.01
-    r = np.array(rewards)
-    assert np.allclose(r[:, 0], r[:, 1], rtol=0.02, atol=1e-3)
+    assert np.array_equal(a[2], ref_env.agents[2])
+    assert np.isclose(m[2].sum(), ref_env.medium[2].sum(), rtol=0.15)
+    assert np.isclose(m[1].sum(), ref_env.medium[1].sum(), rtol=0.03)
+    assert np.isclose(m[0].sum(), ref_env.medium[0].sum(), rtol=0.05)
+    assert np.isclose(a[3].sum(), ref_env.agents[3].sum(), rtol=0.02)
+    assert np.isclose(r[:, 0].sum(), r[:, 1].sum(), rtol=0.1, atol=0.5)
 
 
 # ------------------------------------------------------------------------------------ data_init
