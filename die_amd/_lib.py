@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdie_hip.so')
+LIB_PATH = os.environ.get('DIE_AMD_LIB') or os.path.join(_HERE, 'libdie_hip.so')   # override: kernel experiments
 
 DIE_OK = 0
 DIE_F32, DIE_F16 = 0, 1

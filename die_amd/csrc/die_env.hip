@@ -124,20 +124,20 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
     block_sum_store(gsum, alive_cnt, a.part_gain, a.part_alive);
 }
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_reduce(const double* pa, int na, const double* pb, int nb,
-                                                       const long long* pc, int nc, die_step_result* out) {
-    // one block; each thread sums a fixed strided subset, then a fixed tree: run-to-run deterministic
-    __shared__ double sg[DIE_BLOCK];
-    __shared__ long long sc[DIE_BLOCK];
+__global__ __launch_bounds__(1024) void k_reduce(const double* pa, int na, const double* pb, int nb,
+                                                  const long long* pc, int nc, die_step_result* out) {
+    // one block; fixed assignment of partials to threads and a fixed tree: run-to-run deterministic
+    __shared__ double sg[1024];
+    __shared__ long long sc[1024];
     double g = 0.0;
     long long c = 0;
-    for (int i = threadIdx.x; i < na; i += DIE_BLOCK) g += pa[i];
-    for (int i = threadIdx.x; i < nb; i += DIE_BLOCK) g += pb[i];
-    for (int i = threadIdx.x; i < nc; i += DIE_BLOCK) c += pc[i];
+    for (int i = threadIdx.x; i < na; i += 1024) g += pa[i];
+    for (int i = threadIdx.x; i < nb; i += 1024) g += pb[i];
+    for (int i = threadIdx.x; i < nc; i += 1024) c += pc[i];
     sg[threadIdx.x] = g;
     sc[threadIdx.x] = c;
     __syncthreads();
-    for (int o = DIE_BLOCK / 2; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) { sg[threadIdx.x] += sg[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
@@ -247,7 +247,8 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
 // ---- step driver ----------------------------------------------------------------------
 static int step_grid(int64_t N) {
     int64_t g = (N + DIE_BLOCK - 1) / DIE_BLOCK;
-    return (int)(g < DIE_MAX_PARTIALS ? (g > 0 ? g : 1) : DIE_MAX_PARTIALS);
+    const int64_t cap = 2048;          // ≤ DIE_MAX_PARTIALS partial sums for k_reduce; 8 blocks per CU
+    return (int)(g < cap ? (g > 0 ? g : 1) : cap);
 }
 
 // workspace layout: [part_gain_a | part_gain_b | part_alive | scan scratch (die_init) | stash (N floats)]
@@ -329,7 +330,7 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
     DIE_REQUIRE(a && d && result && ws, "die_step_reduce: null argument");
     DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_step_reduce: workspace too small");
     const int g = step_grid(a->N);
-    k_reduce<<<1, DIE_BLOCK, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS, g,
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS, g,
                                                        (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS), g,
                                                        result);
     DIE_CHECK_LAUNCH("die_step_reduce");

@@ -405,7 +405,7 @@ def test_free_run_default_parameters_statistics(die):
     assert np.isclose(m[2].sum(), ref_env.medium[2].sum(), rtol=0.15)
     assert np.isclose(m[1].sum(), ref_env.medium[1].sum(), rtol=0.03)
     assert np.isclose(m[0].sum(), ref_env.medium[0].sum(), rtol=0.05)
-    assert np.isclose(a[3].sum(), ref_env.agents[3].sum(), rtol=0.02)
+    assert np.isclose(a[3].sum(), ref_env.agents[3].sum(), rtol=0.05)
     assert np.isclose(r[:, 0].sum(), r[:, 1].sum(), rtol=0.1, atol=0.5)
 
 
