@@ -32,6 +32,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-steps', type=int, default=3)
     p.add_argument('--kernel-reps', type=int, default=20)
+    p.add_argument('--sort-every', type=int, default=8)
     return p.parse_args()
 
 
@@ -40,8 +41,7 @@ def algorithmic_bytes(C, K):
     return {
         'k_gradient_forward': 48 * K,     # x,y,heading R 12 + heading W 4 + action W 12 + 5 gathers 20
         'k_move_claim': 44 * K,           # x,y RW 16 + agent_food RW 8 + action R 12 + food gather 4 + claim 4
-        'k_resolve': 20 * K,              # chem RMW 8 + food RMW 8 + agents mark 4 (winner scatter)
-        'k_diffuse': 8 * C,               # chem R + W
+        'k_diffuse_rows_fused': 8 * C + 20 * K,   # chem R + W per cell; per agent chem RMW 8 + food RMW 8 + mark 4
         'step': 12 * C + 104 * K,
     }
 
@@ -62,6 +62,8 @@ def time_kernels(env, agent, reps):
         torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in ev) / reps * 1e3
 
+    env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
+    obs = env._get_current_obs
     action = agent.forward(obs)
     out['k_gradient_forward'] = timed(lambda: agent.forward(obs))
 
@@ -69,8 +71,7 @@ def time_kernels(env, agent, reps):
         env.medium.next_epoch()
         env._stage('die_agent_move_claim', action)
     out['k_move_claim'] = timed(move)
-    out['k_resolve'] = timed(lambda: env._stage('die_agent_resolve', action))
-    out['k_diffuse'] = timed(env._medium_diffuse_decay)
+    out['k_diffuse_rows_fused'] = timed(env._medium_deposit_feed_diffuse)
     return out
 
 
@@ -110,7 +111,7 @@ def main():
     W = H = args.size
     # weak scaling: every rank steps its own W×H torus (replicas), seeds differ per rank
     env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
-                      max_agents='alive', device=device, sync=False)
+                      max_agents='alive', device=device, sync=False, sort_every=args.sort_every)
     K = env.agents.N
     agent_kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), turn_angle=30, sense_angle=90,
                     turn_tolerance=0.1, deposit=4.0)

@@ -17,7 +17,7 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 
 class Medium(C.Structure):
@@ -27,7 +27,7 @@ class Medium(C.Structure):
 
 class Agents(C.Structure):
     _fields_ = [('N', C.c_int64), ('x', C.c_void_p), ('y', C.c_void_p), ('alive', C.c_void_p),
-                ('agent_food', C.c_void_p)]
+                ('agent_food', C.c_void_p), ('slot', C.c_void_p)]
 
 
 class Action(C.Structure):
@@ -71,11 +71,15 @@ _SIGNATURES = {
     'die_agent_resolve': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                     C.c_void_p]),
     'die_step_reduce': (C.c_int, [_P(Agents), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_medium_deposit_feed_diffuse': (C.c_int, [_P(Medium), _P(Dynamics), C.c_void_p]),
     'die_diffuse_decay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                     C.c_void_p]),
     'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),
     'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
+    'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
+    'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
+                                  C.c_int64, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -46,6 +46,7 @@ class GradientAgent(Agent):
         self._direction_rads: Optional[torch.Tensor] = None     # allocated on first forward (needs the device)
         self._prev_grad: Optional[torch.Tensor] = None
         self._turn_sign: Optional[torch.Tensor] = None            # test hook: per-slot ±1 instead of Philox
+        self._order: Optional[torch.Tensor] = None                # slot tensor the state arrays are aligned with
 
     @property
     def init_params(self) -> Dict[str, Any]:
@@ -62,8 +63,44 @@ class GradientAgent(Agent):
                                              float(self._turn_radians), self._seed & 0xFFFFFFFFFFFFFFFF,
                                              stream_ptr(device)), 'die_init_heading')
 
+    # -- per-slot state follows the agents' array order (Env.sort_agents) ---------------------
+    def _die_state_tensors(self, agents):
+        if self._direction_rads is None or self._order is not agents.slot:
+            return []
+        ts = [self._direction_rads]
+        if self._prev_grad is not None:
+            ts += [self._prev_grad[0], self._prev_grad[1]]
+        return ts
+
+    def _die_state_permuted(self, tensors, slot):
+        self._direction_rads = tensors[0]
+        if self._prev_grad is not None:
+            self._prev_grad = torch.stack([tensors[1], tensors[2]])
+        self._order = slot
+
+    def _align_to(self, slot):
+        """Bring the state arrays from order `self._order` to order `slot` (rare path)."""
+        from ..device_array import unpermute
+        def move(t):
+            v = unpermute(t, self._order)
+            return v if slot is None else v[..., slot.to(torch.int64)].contiguous()
+        self._direction_rads = move(self._direction_rads)
+        if self._prev_grad is not None:
+            self._prev_grad = move(self._prev_grad)
+        self._order = slot
+
+    def direction_rads_numpy(self) -> np.ndarray:
+        """`_direction_rads` in slot order (float64)."""
+        from ..device_array import unpermute
+        return unpermute(self._direction_rads, self._order).to(torch.float64).cpu().numpy()
+
+    def prev_grad_numpy(self) -> np.ndarray:
+        from ..device_array import unpermute
+        return unpermute(self._prev_grad, self._order).to(torch.float64).cpu().numpy()
+
     def set_state(self, direction_rads: np.ndarray, prev_grad: Optional[np.ndarray] = None, device='cuda:0'):
-        """Load `_direction_rads` (and `_prev_grad`) from host arrays."""
+        """Load `_direction_rads` (and `_prev_grad`) from host arrays given in slot order."""
+        self._order = None
         self._direction_rads = torch.from_numpy(np.asarray(direction_rads, dtype=np.float32)).to(device)
         assert self._direction_rads.numel() == self._size
         if prev_grad is not None:
@@ -83,7 +120,10 @@ class GradientAgent(Agent):
         dev = agents.device
         if self._direction_rads is None:
             self._alloc_state(dev)
-        action = DeviceAction(agents.N, dev)
+        if self._order is not agents.slot:
+            self._align_to(agents.slot)
+        agents.attach(self)
+        action = DeviceAction(agents.N, dev, agents.slot)
         pg = self._prev_grad
         g = _lib.GradientAgent(
             self._kind, int(bool(self._normalized)), self._scale, self._deposit, self._inertia,

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdie_hip.so')
-SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip']
+SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip']
 HEADERS = ['die_common.h', 'die_rng.h', os.path.join('..', '..', 'include', 'die_hip.h')]
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 

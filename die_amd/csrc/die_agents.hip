@@ -15,6 +15,7 @@ struct FwdArgs {
     const void* food;
     const uint32_t* x;
     const uint32_t* y;
+    const uint32_t* slot;
     float* heading;
     float* pgx;
     float* pgy;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
     for (int64_t base = (int64_t)blockIdx.x * chunk; base < a.N; base += (int64_t)gridDim.x * chunk) {
         int64_t n[U];
         bool live[U];
-        uint32_t X[U], Y[U];
+        uint32_t X[U], Y[U], sid[U];
         float d[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
             live[u] = n[u] < a.N;
             const int64_t m = live[u] ? n[u] : 0;
             X[u] = a.x[m]; Y[u] = a.y[m]; d[u] = a.heading[m];
+            sid[u] = a.slot ? a.slot[m] : (uint32_t)m;          // reference slot id: keys the random streams
         }
         float cxm[U], cxp[U], cym[U], cyp[U], f_own[U], wx[U], wy[U];
 #pragma unroll
@@ -142,8 +144,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
                 const bool und = und_grad || und_turn || unseen;
                 float sgn;
                 if (und) {
-                    if (a.turn_sign) sgn = live[u] ? (float)a.turn_sign[n[u]] : 1.f;
-                    else sgn = (die_draw(a.seed, a.step, (uint64_t)n[u], DIE_STREAM_TURN).v[0] & 1u) ? 1.f : -1.f;
+                    if (a.turn_sign) sgn = live[u] ? (float)a.turn_sign[sid[u]] : 1.f;
+                    else sgn = (die_draw(a.seed, a.step, (uint64_t)sid[u], DIE_STREAM_TURN).v[0] & 1u) ? 1.f : -1.f;
                 } else {
                     sgn = delta > atol ? -1.f : 1.f;  // right (clockwise) / left
                 }
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
             if (a.inertia != 0.f || a.noise_scale != 0.f) {
                 float nx = 0.f, ny = 0.f;
                 if (a.noise_scale != 0.f) {
-                    const die_u32x4 r = die_draw(a.seed, a.step, (uint64_t)n[u], DIE_STREAM_NOISE);
+                    const die_u32x4 r = die_draw(a.seed, a.step, (uint64_t)sid[u], DIE_STREAM_NOISE);
                     const float u1 = ((float)r.v[0] + 1.0f) * 2.3283064365386963e-10f;
                     const float u2 = (float)r.v[1] * 2.3283064365386963e-10f;
                     const float rad = 0.4f * sqrtf(-2.0f * logf(u1));
@@ -191,12 +193,12 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
     }
 }
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_brownian_forward(int64_t N, const uint8_t* alive, double s, double dep,
+__global__ __launch_bounds__(DIE_BLOCK) void k_brownian_forward(int64_t N, const uint8_t* alive, const uint32_t* slot, double s, double dep,
                                                                  uint64_t seed, uint32_t step, float* dx, float* dy,
                                                                  float* dp) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
-        const die_u32x4 r = die_draw(seed, step, (uint64_t)n, DIE_STREAM_BROWNIAN);
+        const die_u32x4 r = die_draw(seed, step, (uint64_t)(slot ? slot[n] : (uint32_t)n), DIE_STREAM_BROWNIAN);
         const double m = alive[n] ? 1.0 : 0.0;
         // (b-a)*u.round(3)+a, × alive (core/data_init.py:168-169,248-253)
         dx[n] = (float)((2.0 * s * (die_round3_units(r.v[0]) / 1000.0) - s) * m);
@@ -242,7 +244,7 @@ extern "C" int die_gradient_forward(const die_medium* m, const die_agents* a, di
     DIE_REQUIRE(g->inertia == 0.f || (g->prev_gx && g->prev_gy), "die_gradient_forward: inertia needs prev_gx/prev_gy");
     FwdArgs k;
     k.W = m->W; k.H = m->H; k.N = a->N;
-    k.chem = m->chem; k.food = m->food; k.x = a->x; k.y = a->y;
+    k.chem = m->chem; k.food = m->food; k.x = a->x; k.y = a->y; k.slot = a->slot;
     k.heading = g->heading; k.pgx = g->prev_gx; k.pgy = g->prev_gy; k.turn_sign = g->turn_sign;
     k.dx = out->dx; k.dy = out->dy; k.dep = out->deposit;
     k.scale = g->scale; k.deposit = g->deposit; k.inertia = g->inertia; k.sense_offset = g->sense_offset;
@@ -269,7 +271,7 @@ extern "C" int die_brownian_forward(const die_agents* a, float move_scale, float
                 (long long)out->N, (long long)a->N);
     DIE_REQUIRE(a->alive && out->dx && out->dy && out->deposit, "die_brownian_forward: null device pointer");
     k_brownian_forward<<<agent_grid(a->N), DIE_BLOCK, 0, (hipStream_t)stream>>>(
-        a->N, a->alive, (double)move_scale, (double)deposit_scale, seed, step, out->dx, out->dy, out->deposit);
+        a->N, a->alive, a->slot, (double)move_scale, (double)deposit_scale, seed, step, out->dx, out->dy, out->deposit);
     DIE_CHECK_LAUNCH("die_brownian_forward");
     return DIE_OK;
 }

@@ -56,6 +56,14 @@ __device__ __forceinline__ uint32_t die_owner_word(int epoch, int64_t slot) {
 __device__ __forceinline__ bool die_owner_occupied(uint32_t w, int epoch) {
     return (w >> DIE_OWNER_EPOCH_SHIFT) == (uint32_t)epoch;
 }
+// 64-bit claim: ownership word above the fp32 bits of the claimant's deposit
+__device__ __forceinline__ unsigned long long die_claim(int epoch, int64_t slot, float deposit) {
+    return ((unsigned long long)die_owner_word(epoch, slot) << 32) | (unsigned long long)__float_as_uint(deposit);
+}
+__device__ __forceinline__ bool die_claim_occupied(unsigned long long k, int epoch) {
+    return (uint32_t)(k >> 61) == (uint32_t)epoch;
+}
+__device__ __forceinline__ float die_claim_deposit(unsigned long long k) { return __uint_as_float((uint32_t)k); }
 
 // ---- wave / block reductions -------------------------------------------------------------
 __device__ __forceinline__ double die_wave_sum(double v) {

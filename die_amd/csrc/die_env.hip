@@ -13,17 +13,19 @@
 // (pass 1) are separated from the single write per occupied cell (pass 2) by a kernel boundary.
 // "Last writer wins" of the fancy-index assignment at :211 is an atomicMax on the slot id.
 #include "die_common.h"
+#include <stdlib.h>
 
 #define DIE_MAX_PARTIALS 8192
 
 struct StepArgs {
     int W, H, epoch;
     int64_t N;
-    uint32_t* owner;
+    unsigned long long* owner;
     void* food;
     void* chem;
     uint32_t* x;
     uint32_t* y;
+    const uint32_t* slot;  // reference slot ids (NULL = identity)
     uint8_t* alive;
     float* agent_food;
     const float* dx;
@@ -31,6 +33,7 @@ struct StepArgs {
     const float* dep;
     float rate_feed, w_dep, w_dist;
     int boundary, cost, food_infinite, agents_die, has_dead;
+    int skip_scatter;      // fused step: the winner's chem/food writes are done by k_diffuse_rows
     float* stash;          // N floats, only when has_dead
     double* part_gain;     // gridDim.x doubles
     long long* part_alive; // gridDim.x
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
         const int64_t c = (int64_t)die_cell((int64_t)X, a.W) * a.H + die_cell((int64_t)Y, a.H);
         const float consumed = a.rate_feed * die_ld(food, c);
         if (a.alive[n]) {
-            atomicMax(&a.owner[c], die_owner_word(a.epoch, n));
+            atomicMax(&a.owner[c], die_claim(a.epoch, a.slot ? (int64_t)a.slot[n] : n, a.dep[n]));
             const float gained = consumed - action_cost(a, dx, dy, a.dep[n]);
             a.agent_food[n] += gained;
             gsum += (double)gained;
@@ -101,16 +104,16 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
         const uint32_t X = a.x[n], Y = a.y[n];
         const int64_t c = (int64_t)die_cell((int64_t)X, a.W) * a.H + die_cell((int64_t)Y, a.H);
         bool alive = a.alive[n] != 0;
-        if (alive) {
-            if (a.owner[c] == die_owner_word(a.epoch, n)) {       // highest alive slot on the cell
+        if (alive && !a.skip_scatter) {
+            if ((uint32_t)(a.owner[c] >> 32) == die_owner_word(a.epoch, a.slot ? (int64_t)a.slot[n] : n)) {       // highest alive slot on the cell
                 die_st(chem, c, die_ld(chem, c) + a.dep[n]);
                 if (!a.food_infinite) {
                     const float f = die_ld(food, c);
                     die_st(food, c, f - a.rate_feed * f);
                 }
             }
-        } else if (a.has_dead) {
-            const float consumed = die_owner_occupied(a.owner[c], a.epoch) ? a.stash[n] : 0.f;
+        } else if (!alive && a.has_dead) {
+            const float consumed = die_claim_occupied(a.owner[c], a.epoch) ? a.stash[n] : 0.f;
             const float gained = consumed - action_cost(a, a.dx[n], a.dy[n], a.dep[n]);
             a.agent_food[n] += gained;
             gsum += (double)gained;
@@ -125,7 +128,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
 }
 
 __global__ __launch_bounds__(1024) void k_reduce(const double* pa, int na, const double* pb, int nb,
-                                                  const long long* pc, int nc, die_step_result* out) {
+                                                  const long long* pc, int nc, die_step_result* out,
+                                                  long long alive_const) {
     // one block; fixed assignment of partials to threads and a fixed tree: run-to-run deterministic
     __shared__ double sg[1024];
     __shared__ long long sc[1024];
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* pa, int na, const
         if ((int)threadIdx.x < o) { sg[threadIdx.x] += sg[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out->reward = sg[0]; out->num_alive = sc[0]; }
+    if (threadIdx.x == 0) { out->reward = sg[0]; out->num_alive = alive_const >= 0 ? alive_const : sc[0]; }
 }
 
 // ---- diffusion --------------------------------------------------------------------------
@@ -201,6 +205,162 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
     }
 }
 
+// ---- row-marching diffusion, optionally fused with deposit + feeding -----------------------
+// One wave owns a strip of 248 columns (62 lanes × 4 contiguous cells; lanes 0 and 63 only load
+// the 4-column halo to the left / right) and marches down DIF_ROWS rows.  Per row a lane loads its
+// 4 cells with one 16-byte access, keeps the last 2R+1 rows in registers (x pass = axis 0 first,
+// as scipy does), and gets the y-pass neighbours from the adjacent lanes with wave shuffles — no
+// LDS, no barrier.  FUSED: the same sweep reads the 64-bit claim of every cell it loads and adds the
+// winner's deposit before filtering (core/env.py:211) and, for the cells it owns, performs the
+// feeding update food −= rate·food on occupied cells (:222-228): the per-cell scatter of the step
+// becomes two coalesced streams.
+#define DIF_ROWS 32
+#define DIF_WCOLS 248          // output columns per wave
+
+struct RowsArgs {
+    const void* src;
+    void* dst;
+    const unsigned long long* claim;   // FUSED only
+    void* food;                        // FUSED only
+    int W, H, epoch, food_infinite;
+    float keep, rate_feed;
+    float w[2 * 4 + 1];
+};
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4<__half> {
+    static __device__ __forceinline__ void ld(const __half* p, float v[4]) {
+        const uint2 t = *(const uint2*)p;
+        const __half2 a = *(const __half2*)&t.x, b = *(const __half2*)&t.y;
+        v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+    }
+    static __device__ __forceinline__ void st(__half* p, const float v[4]) {
+        const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+        uint2 t; t.x = *(const uint32_t*)&a; t.y = *(const uint32_t*)&b;
+        *(uint2*)p = t;
+    }
+};
+
+template <typename T, int R, bool FUSED>
+__global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
+    static_assert(R >= 1 && R <= 4, "one halo lane of 4 columns per side");
+    const T* src = (const T*)a.src;
+    T* dst = (T*)a.dst;
+    T* food = (T*)a.food;
+    const int W = a.W, H = a.H;
+    const int lane = threadIdx.x & (DIE_WAVE - 1);
+    const int strip = blockIdx.x * (DIE_BLOCK / DIE_WAVE) + (threadIdx.x >> 6);
+    const int yb = strip * DIF_WCOLS;                       // first output column of this wave
+    if (yb >= H) return;                                    // whole wave idle (nothing below synchronises)
+    const int nout = min(DIF_WCOLS, H - yb) / 4;            // output lanes are 1..nout (H % 4 == 0)
+    const bool need = lane <= nout + 1;                     // + the two halo lanes
+    const bool outl = lane >= 1 && lane <= nout;
+    const int col = wrap_idx(yb + 4 * (lane - 1), H);       // 16-byte aligned since H % 4 == 0
+    const int x0 = blockIdx.y * DIF_ROWS;
+    const int rows = min(DIF_ROWS, W - x0);
+
+    float win[2 * R + 1][4];
+#pragma unroll
+    for (int k = 0; k <= 2 * R; ++k) { win[k][0] = win[k][1] = win[k][2] = win[k][3] = 0.f; }
+
+    auto load_row = [&](int i, float v[4]) {
+        v[0] = v[1] = v[2] = v[3] = 0.f;
+        if (!need) return;
+        const int r = wrap_idx(x0 + i, W);
+        const int64_t off = (int64_t)r * H + col;
+        Vec4<T>::ld(src + off, v);
+        if (FUSED) {
+            const ulonglong2 c01 = *(const ulonglong2*)(a.claim + off), c23 = *(const ulonglong2*)(a.claim + off + 2);
+            const unsigned long long c[4] = {c01.x, c01.y, c23.x, c23.y};
+            bool occ[4];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                occ[j] = die_claim_occupied(c[j], a.epoch);
+                if (occ[j]) v[j] += die_claim_deposit(c[j]);     // chem[cell] + deposit of the last writer
+                any |= occ[j];
+            }
+            // feeding: this wave owns rows [x0, x0+rows) × its output lanes
+            if (any && outl && i >= 0 && i < rows && !a.food_infinite) {
+                float f[4];
+                Vec4<T>::ld(food + off, f);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (occ[j]) f[j] = f[j] - a.rate_feed * f[j];
+                Vec4<T>::st(food + off, f);
+            }
+        }
+    };
+
+    float nxt[4];
+    load_row(-R, nxt);
+    for (int i = -R; i < rows + R; ++i) {
+        float cur[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+        if (i + 1 < rows + R) load_row(i + 1, nxt);            // prefetch one row ahead
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) win[k][j] = win[k + 1][j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) win[2 * R][j] = cur[j];
+        const int orow = i - R;                                // the window is centred on this row
+        if (orow < 0) continue;
+        float xf[4 + 2 * 4];                                   // [4 − R .. 4 + 4 + R): own 4 at [4..8)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k <= 2 * R; ++k) t += a.w[k] * win[k][j];
+            xf[4 + j] = t;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            xf[4 - R + j] = __shfl_up(xf[4 + 4 - R + j], 1, DIE_WAVE);      // left lane's last R cells
+            xf[8 + j] = __shfl_down(xf[4 + j], 1, DIE_WAVE);                 // right lane's first R cells
+        }
+        if (outl) {
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t = 0.f;
+#pragma unroll
+                for (int k = 0; k <= 2 * R; ++k) t += a.w[k] * xf[4 + j - R + k];
+                o[j] = t * a.keep;
+            }
+            Vec4<T>::st(dst + (int64_t)(x0 + orow) * H + col, o);
+        }
+    }
+}
+
+template <typename T, bool FUSED>
+static int launch_rows(const RowsArgs& a, int R, hipStream_t s) {
+    const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
+    dim3 grid((strips + 3) / 4, (a.W + DIF_ROWS - 1) / DIF_ROWS);
+    switch (R) {
+        case 1: k_diffuse_rows<T, 1, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 2: k_diffuse_rows<T, 2, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 3: k_diffuse_rows<T, 3, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 4: k_diffuse_rows<T, 4, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        default: return DIE_ERR_UNSUPPORTED;
+    }
+    return DIE_OK;
+}
+
+static bool rows_kernel_applies(int W, int H, int R) { return R <= 4 && H % 4 == 0 && H >= 4 && W >= 1; }
+
+static int gaussian_taps(float sigma, double* w) {
+    // scipy.ndimage._gaussian_kernel1d: radius int(4σ + .5), exp(−x²/2σ²) normalised
+    const int R = (int)(4.0 * (double)sigma + 0.5);
+    double sum = 0.0;
+    for (int k = -R; k <= R && R <= DIF_MAXR; ++k) { w[k + R] = exp(-0.5 / ((double)sigma * (double)sigma) * k * k); sum += w[k + R]; }
+    for (int k = 0; k <= 2 * R && R <= DIF_MAXR; ++k) w[k] /= sum;
+    return R;
+}
+
 template <typename T>
 static int launch_diffuse(const DiffuseArgs& a, int R, hipStream_t s) {
     dim3 grid((a.H + DIF_TY - 1) / DIF_TY, (a.W + DIF_TX - 1) / DIF_TX);
@@ -230,6 +390,19 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
     if (R > DIF_MAXR) {
         die_set_error("die_diffuse_decay: sigma %g needs radius %d > %d", (double)sigma, R, DIF_MAXR);
         return DIE_ERR_UNSUPPORTED;
+    }
+    if (rows_kernel_applies(W, H, R)) {
+        RowsArgs ra;
+        double wd[2 * DIF_MAXR + 1];
+        gaussian_taps(sigma, wd);
+        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0;
+        ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
+        for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
+        int rc2 = dtype == DIE_F32 ? launch_rows<float, false>(ra, R, (hipStream_t)stream)
+                                   : launch_rows<__half, false>(ra, R, (hipStream_t)stream);
+        if (rc2 != DIE_OK) return rc2;
+        DIE_CHECK_LAUNCH("die_diffuse_decay");
+        return DIE_OK;
     }
     DiffuseArgs a;
     a.src = src; a.dst = dst; a.W = W; a.H = H;
@@ -285,11 +458,12 @@ static int fill_args(StepArgs& k, const die_medium* m, const die_agents* a, cons
         k.dx = k.dy = k.dep = nullptr;
     }
     k.W = m->W; k.H = m->H; k.epoch = m->epoch; k.N = a->N;
-    k.owner = m->owner; k.food = m->food; k.chem = m->chem;
-    k.x = a->x; k.y = a->y; k.alive = a->alive; k.agent_food = a->agent_food;
+    k.owner = (unsigned long long*)m->owner; k.food = m->food; k.chem = m->chem;
+    k.x = a->x; k.y = a->y; k.slot = a->slot; k.alive = a->alive; k.agent_food = a->agent_food;
     k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
     k.boundary = d->boundary; k.cost = d->cost; k.food_infinite = d->food_infinite; k.agents_die = d->agents_die;
     k.has_dead = d->has_dead_slots || d->agents_die;
+    k.skip_scatter = 0;
     char* w = (char*)ws;
     k.part_gain = nullptr; k.part_alive = nullptr;
     k.stash = (float*)(w + WS_PARTS + die_ws_scan_bytes(m->W, m->H));
@@ -332,22 +506,78 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
     const int g = step_grid(a->N);
     k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS, g,
                                                        (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS), g,
-                                                       result);
+                                                       result, -1);
     DIE_CHECK_LAUNCH("die_step_reduce");
     return DIE_OK;
 }
 
+// winner-independent remainder of k_resolve: dead slots, lifecycle, alive count (fused path only
+// launches it when such slots can exist)
 extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                             die_step_result* result, void* ws, int64_t ws_bytes, void* stream) {
     DIE_REQUIRE(m && a && act && d && result, "die_env_step: null argument");
     DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_env_step: chem_next must be a second plane");
     int rc = die_agent_move_claim(m, a, act, d, ws, ws_bytes, stream);
     if (rc != DIE_OK) return rc;
-    rc = die_agent_resolve(m, a, act, d, ws, ws_bytes, stream);
+    const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
+    const bool fused = rows_kernel_applies(m->W, m->H, R) && R >= 1 && !getenv("DIE_NO_FUSED_STEP");
+    if (!fused) {
+        rc = die_agent_resolve(m, a, act, d, ws, ws_bytes, stream);
+        if (rc != DIE_OK) return rc;
+        rc = die_step_reduce(a, d, result, ws, ws_bytes, stream);
+        if (rc != DIE_OK) return rc;
+        return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
+    }
+    // fused path: deposits and feeding ride on the diffusion sweep; the per-agent second pass is only
+    // needed for dead slots / lifecycle (it then skips the winner's scatter)
+    const bool second_pass = d->has_dead_slots || d->agents_die;
+    if (second_pass) {
+        StepArgs k;
+        rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_env_step");
+        if (rc != DIE_OK) return rc;
+        k.part_gain = (double*)ws + DIE_MAX_PARTIALS;
+        k.part_alive = (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS);
+        k.skip_scatter = 1;
+        const int grid = step_grid(a->N);
+        if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+        else k_resolve<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+        DIE_CHECK_LAUNCH("die_env_step(dead slots)");
+    }
+    {
+        const int g = step_grid(a->N);
+        k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
+                                                      second_pass ? g : 0,
+                                                      (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
+                                                      second_pass ? g : 0, result, second_pass ? -1 : a->N);
+        DIE_CHECK_LAUNCH("die_env_step(reduce)");
+    }
+    return die_medium_deposit_feed_diffuse(m, d, stream);
+}
+
+extern "C" int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, void* stream) {
+    DIE_REQUIRE(m && d, "die_medium_deposit_feed_diffuse: null argument");
+    DIE_REQUIRE(m->owner && m->food && m->chem && m->chem_next && m->chem_next != m->chem,
+                "die_medium_deposit_feed_diffuse: null or aliased plane");
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "die_medium_deposit_feed_diffuse: bad dtype %d", m->dtype);
+    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "die_medium_deposit_feed_diffuse: bad epoch %d", m->epoch);
+    const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
+    if (!(rows_kernel_applies(m->W, m->H, R) && R >= 1)) {
+        die_set_error("die_medium_deposit_feed_diffuse: needs H %% 4 == 0 and radius 1..4 (H=%d, sigma=%g)", m->H,
+                      (double)d->diffuse_sigma);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    RowsArgs ra;
+    double wd[2 * DIF_MAXR + 1];
+    gaussian_taps(d->diffuse_sigma, wd);
+    ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.food = m->food;
+    ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite;
+    ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
+    for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
+    int rc = m->dtype == DIE_F32 ? launch_rows<float, true>(ra, R, (hipStream_t)stream)
+                                 : launch_rows<__half, true>(ra, R, (hipStream_t)stream);
     if (rc != DIE_OK) return rc;
-    rc = die_step_reduce(a, d, result, ws, ws_bytes, stream);
-    if (rc != DIE_OK) return rc;
-    return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
+    DIE_CHECK_LAUNCH("die_medium_deposit_feed_diffuse");
+    return DIE_OK;
 }
 
 // ---- error plumbing ---------------------------------------------------------------------

@@ -19,7 +19,7 @@ struct FoodArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(int W, int H, uint32_t* owner, T* food, T* chem, double ratio,
+__global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(int W, int H, uint64_t* owner, T* food, T* chem, double ratio,
                                                            uint64_t seed, FoodArgs fa) {
     const int64_t C = (int64_t)W * H;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -27,7 +27,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(int W, int H, uint32_
         // ceil(u·[0 ≤ u ≤ ratio]) with u = random_sample().round(3): occupied iff 0 < u ≤ ratio
         const int r = die_round3_units(die_draw(seed, 0, (uint64_t)c, DIE_STREAM_INIT_AGENTS).v[0]);
         const double u = r / 1000.0;
-        owner[c] = (r > 0 && u <= ratio) ? 1u : 0u;        // provisional flag; k_scatter writes the ownership word
+        owner[c] = (r > 0 && u <= ratio) ? 1ull : 0ull;    // provisional flag; k_scatter writes the claim word
         const int ix = (int)(c / H), iy = (int)(c - (int64_t)ix * H);
         const double x = (double)ix / W, y = (double)iy / H;
         double s = 0.0;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(int W, int H, uint32_
     }
 }
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_count(const uint32_t* flag, int64_t C, int32_t* block_sum) {
+__global__ __launch_bounds__(DIE_BLOCK) void k_count(const uint64_t* flag, int64_t C, int32_t* block_sum) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int cnt = 0;
 #pragma unroll
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_scan_blocks(const int32_t* block_
     for (int i = lo; i < hi; ++i) { block_off[i] = run; run += block_sum[i]; }
 }
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_scatter(int W, int H, uint32_t* owner, const int64_t* block_off, int64_t N,
+__global__ __launch_bounds__(DIE_BLOCK) void k_scatter(int W, int H, uint64_t* owner, const int64_t* block_off, int64_t N,
                                                        uint32_t* x, uint32_t* y, uint8_t* alive, float* agent_food,
                                                        uint64_t seed) {
     const int64_t C = (int64_t)W * H;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_scatter(int W, int H, uint32_t* o
                 // get_random(K, 0.1, 1.0) = 0.9·u.round(3) + 0.1 (:140, :168-169)
                 const int r = die_round3_units(die_draw(seed, 0, (uint64_t)k, DIE_STREAM_INIT_AGENT_FOOD).v[0]);
                 agent_food[k] = (float)(0.9 * (r / 1000.0) + 0.1);
-                owner[c] = die_owner_word(1, k);
+                owner[c] = die_claim(1, k, 0.f);
             } else {
                 owner[c] = 0;
             }

@@ -44,7 +44,7 @@ class DeviceMedium:
         if dtype not in (torch.float32, torch.float16):
             raise ValueError('field dtype must be float32 or float16')
         self.W, self.H, self.device, self.dtype = W, H, torch.device(device), dtype
-        self.owner = torch.zeros((W, H), dtype=torch.int32, device=device)   # uint32 ownership words
+        self.owner = torch.zeros((W, H), dtype=torch.int64, device=device)   # uint64 claim words
         self.food = torch.zeros((W, H), dtype=dtype, device=device)
         self.chem = torch.zeros((W, H), dtype=dtype, device=device)
         self.chem_next = torch.empty((W, H), dtype=dtype, device=device)
@@ -70,12 +70,11 @@ class DeviceMedium:
 
     def occupied(self) -> torch.Tensor:
         """Boolean (W, H): the 'agents' channel > 0."""
-        tag = (self.owner.to(torch.int64) & 0xFFFFFFFF) >> _lib.OWNER_EPOCH_SHIFT
-        return tag == self.epoch
+        return ((self.owner >> 61) & 7) == self.epoch
 
     def owner_slots(self) -> torch.Tensor:
         """int64 (W, H): owning slot id, −1 for empty cells."""
-        w = self.owner.to(torch.int64) & 0xFFFFFFFF
+        w = (self.owner >> 32) & 0xFFFFFFFF
         return torch.where((w >> _lib.OWNER_EPOCH_SHIFT) == self.epoch, (w & _lib.OWNER_SLOT_MASK) - 1,
                            torch.full_like(w, -1))
 
@@ -96,8 +95,8 @@ class DeviceMedium:
         medium = np.asarray(medium)
         assert medium.shape == self.shape, (medium.shape, self.shape)
         occ = medium[0] > 0
-        words = np.where(occ, (self.epoch << _lib.OWNER_EPOCH_SHIFT) | 1, 0).astype(np.uint32)
-        self.owner.copy_(torch.from_numpy(words.view(np.int32)))
+        words = np.where(occ, np.uint64(((self.epoch << _lib.OWNER_EPOCH_SHIFT) | 1) << 32), np.uint64(0)).astype(np.uint64)
+        self.owner.copy_(torch.from_numpy(words.view(np.int64)))
         self.food.copy_(torch.from_numpy(np.ascontiguousarray(medium[1], dtype=np.float32)))
         self.chem.copy_(torch.from_numpy(np.ascontiguousarray(medium[2], dtype=np.float32)))
 
@@ -106,8 +105,20 @@ class DeviceMedium:
         t.copy_(torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32)))
 
 
+def unpermute(values: torch.Tensor, slot: Optional[torch.Tensor]) -> torch.Tensor:
+    """Array order → reference slot order along the last axis."""
+    if slot is None:
+        return values
+    out = torch.empty_like(values)
+    out[..., slot.to(torch.int64)] = values
+    return out
+
+
 class DeviceAgents:
-    """(4, N) agent array: channels ('x', 'y', 'alive', 'agent_food'); x, y are Q0.32."""
+    """(4, N) agent array: channels ('x', 'y', 'alive', 'agent_food'); x, y are Q0.32.
+
+    The arrays may be held in a spatially sorted order (`slot[j]` = reference slot id of array
+    entry j, None = identity); everything a caller sees (`sel`, `to_numpy`) is in slot order."""
     channels = DataChannels.agents
 
     def __init__(self, num_slots: int, device):
@@ -117,34 +128,51 @@ class DeviceAgents:
         self.y = torch.zeros(N, dtype=torch.int32, device=device)
         self.alive = torch.zeros(N, dtype=torch.uint8, device=device)
         self.agent_food = torch.zeros(N, dtype=torch.float32, device=device)
+        self.slot: Optional[torch.Tensor] = None
+        self._attached = []          # weak references to objects holding per-slot state (Agent objects)
 
     @property
     def shape(self):
         return (4, self.N)
 
     def c_struct(self) -> _lib.Agents:
-        return _lib.Agents(self.N, _ptr(self.x), _ptr(self.y), _ptr(self.alive), _ptr(self.agent_food))
+        return _lib.Agents(self.N, _ptr(self.x), _ptr(self.y), _ptr(self.alive), _ptr(self.agent_food), _ptr(self.slot))
+
+    def attach(self, obj):
+        """Register an object whose per-slot arrays must follow re-orderings (see Env.sort_agents)."""
+        import weakref
+        if not any(r() is obj for r in self._attached):
+            self._attached.append(weakref.ref(obj))
+
+    def attached(self):
+        live = [r() for r in self._attached]
+        self._attached = [r for r, o in zip(self._attached, live) if o is not None]
+        return [o for o in live if o is not None]
 
     def sel(self, channel: str) -> torch.Tensor:
         if channel in ('x', 'y'):
             q = getattr(self, channel).to(torch.int64) & 0xFFFFFFFF
-            return q.to(torch.float64) / Q32
-        if channel == 'alive':
-            return self.alive.to(torch.float32)
-        if channel == 'agent_food':
-            return self.agent_food
-        raise KeyError(channel)
+            v = q.to(torch.float64) / Q32
+        elif channel == 'alive':
+            v = self.alive.to(torch.float32)
+        elif channel == 'agent_food':
+            v = self.agent_food
+        else:
+            raise KeyError(channel)
+        return unpermute(v, self.slot)
 
     def to_numpy(self) -> np.ndarray:
         return np.stack([self.sel(c).to(torch.float64).cpu().numpy() for c in self.channels])
 
     def q32_numpy(self):
-        """Raw coordinate words as uint32 arrays."""
-        return self.x.cpu().numpy().view(np.uint32), self.y.cpu().numpy().view(np.uint32)
+        """Raw coordinate words as uint32 arrays, slot order."""
+        return (unpermute(self.x, self.slot).cpu().numpy().view(np.uint32),
+                unpermute(self.y, self.slot).cpu().numpy().view(np.uint32))
 
     def upload(self, agents: np.ndarray):
         agents = np.asarray(agents, dtype=np.float64)
         assert agents.shape == self.shape, (agents.shape, self.shape)
+        self.slot = None
         self.x.copy_(torch.from_numpy(to_q32(agents[0]).view(np.int32)))
         self.y.copy_(torch.from_numpy(to_q32(agents[1]).view(np.int32)))
         self.alive.copy_(torch.from_numpy((agents[2] > 0).astype(np.uint8)))
@@ -152,13 +180,15 @@ class DeviceAgents:
 
 
 class DeviceAction:
-    """(3, N) action array: channels ('dx', 'dy', 'deposit1')."""
+    """(3, N) action array: channels ('dx', 'dy', 'deposit1'), in the array order of the agents it
+    was computed for (`slot` as in DeviceAgents); `to_numpy` / `sel` give slot order."""
     channels = DataChannels.actions
 
-    def __init__(self, num_slots: int, device):
+    def __init__(self, num_slots: int, device, slot: Optional[torch.Tensor] = None):
         N = int(num_slots)
         self.N, self.device = N, torch.device(device)
         self.data = torch.empty((3, N), dtype=torch.float32, device=device)
+        self.slot = slot
 
     @property
     def shape(self):
@@ -168,15 +198,25 @@ class DeviceAction:
         return _lib.Action(self.N, _ptr(self.data[0]), _ptr(self.data[1]), _ptr(self.data[2]))
 
     def sel(self, channel: str) -> torch.Tensor:
-        return self.data[self.channels.index(channel)]
+        return unpermute(self.data[self.channels.index(channel)], self.slot)
 
     def to_numpy(self) -> np.ndarray:
-        return self.data.to(torch.float64).cpu().numpy()
+        return unpermute(self.data, self.slot).to(torch.float64).cpu().numpy()
+
+    def in_order_of(self, slot: Optional[torch.Tensor]) -> 'DeviceAction':
+        """This action re-ordered for agents held in order `slot` (no copy when already so)."""
+        if self.slot is slot:
+            return self
+        out = DeviceAction(self.N, self.device, slot)
+        v = unpermute(self.data, self.slot)
+        out.data.copy_(v if slot is None else v[:, slot.to(torch.int64)])
+        return out
 
     @staticmethod
-    def from_numpy(action: np.ndarray, device) -> 'DeviceAction':
+    def from_numpy(action: np.ndarray, device, slot: Optional[torch.Tensor] = None) -> 'DeviceAction':
+        """Upload a (3, N) array given in slot order."""
         action = np.asarray(action)
         assert action.ndim == 2 and action.shape[0] == 3, action.shape
-        a = DeviceAction(action.shape[1], device)
+        a = DeviceAction(action.shape[1], device, None)
         a.data.copy_(torch.from_numpy(np.ascontiguousarray(action, dtype=np.float32)))
-        return a
+        return a.in_order_of(slot)

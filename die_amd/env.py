@@ -75,7 +75,7 @@ class Env(_EnvBase):
     def __init__(self, field_size: Tuple[int, int], dynamics: Optional[Dynamics] = None, *,
                  max_agents: Union[None, int, str] = None, seed: Optional[int] = None,
                  field_dtype: torch.dtype = torch.float32, device: Union[str, torch.device, None] = None,
-                 sync: bool = True):
+                 sync: bool = True, sort_every: int = 4):
         if not torch.cuda.is_available():
             raise RuntimeError('die_amd.Env needs a ROCm GPU (MI355X); there is no CPU path')
         self._field_size = (int(field_size[0]), int(field_size[1]))
@@ -84,6 +84,7 @@ class Env(_EnvBase):
         self._max_agents = max_agents
         self._field_dtype = field_dtype
         self._sync = sync
+        self._sort_every = int(sort_every)
         self._seed = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
         self._renderer = None
         self.last_result = None
@@ -112,6 +113,9 @@ class Env(_EnvBase):
     def _after_state_change(self):
         self._workspace = DataInitializer.workspace(self._field_size, self.agents.N, self.device)
         self._all_alive = bool(self.agents.alive.all().item())
+        self._steps = 0
+        self._shadow = None
+        self._sort_ws = None
 
     @classmethod
     def from_numpy(cls, medium: np.ndarray, agents: np.ndarray, dynamics: Optional[Dynamics] = None, **kw) -> 'Env':
@@ -126,6 +130,7 @@ class Env(_EnvBase):
         env._max_agents = agents.shape[1]
         env._field_dtype = kw.get('field_dtype', torch.float32)
         env._sync = kw.get('sync', True)
+        env._sort_every = int(kw.get('sort_every', 4))
         env._seed = int(kw.get('seed', 0))
         env._renderer = None
         env.last_result = None
@@ -166,7 +171,7 @@ class Env(_EnvBase):
             act = DeviceAction.from_numpy(action.to_numpy() if hasattr(action, 'to_numpy') else action, self.device)
         if act.N != self.agents.N:
             raise ValueError(f'action has {act.N} slots, env has {self.agents.N}')
-        return act
+        return act.in_order_of(self.agents.slot)
 
     def step(self, action):
         """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
@@ -180,6 +185,9 @@ class Env(_EnvBase):
         self.medium.swap_chem()
         if self.dynamics.op_food_flow is not _identity_food_flow:
             self._host_food_flow()
+        self._steps += 1
+        if self._sort_every > 0 and self._steps % self._sort_every == 0:
+            self.sort_agents()
         self.last_result = result
         if not self._sync:
             return self._get_current_obs, result, False, False, {}
@@ -201,12 +209,53 @@ class Env(_EnvBase):
         food = self.medium.food.to(torch.float64).cpu().numpy()
         self.medium.upload_channel('env_food', np.asarray(self.dynamics.op_food_flow(food)))
 
+    def sort_agents(self):
+        """Re-order the agent arrays so that array neighbours are grid neighbours (die_agents_sort).
+        Invisible to callers: slot ids travel with the agents, attached Agent objects have their
+        per-slot state permuted alongside."""
+        A = self.agents
+        if self._shadow is None:
+            self._shadow = [torch.empty_like(t) for t in (A.x, A.y, A.alive, A.agent_food)] + \
+                           [torch.empty(A.N, dtype=torch.int32, device=self.device)]
+            n = _lib.lib.die_sort_workspace_bytes(self.medium.W, self.medium.H, A.N)
+            self._sort_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+        ox, oy, oalive, ofood, oslot = self._shadow
+        owners, tensors = [], []
+        for obj in A.attached():
+            ts = obj._die_state_tensors(A)
+            if ts and len(tensors) + len(ts) <= 4:
+                owners.append((obj, len(ts)))
+                tensors += ts
+        outs = [torch.empty_like(t) for t in tensors]
+        ein = (C.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
+        eout = (C.c_void_p * max(len(outs), 1))(*[t.data_ptr() for t in outs])
+        m, a_in = self.medium.c_struct(), A.c_struct()
+        a_out = _lib.Agents(A.N, _ptr(ox), _ptr(oy), _ptr(oalive), _ptr(ofood), _ptr(oslot))
+        _lib.check(_lib.lib.die_agents_sort(C.byref(m), C.byref(a_in), C.byref(a_out), len(tensors), ein, eout,
+                                            _ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr(self.device)),
+                   'die_agents_sort')
+        old_slot = A.slot
+        self._shadow = [A.x, A.y, A.alive, A.agent_food,
+                        old_slot if old_slot is not None else torch.empty(A.N, dtype=torch.int32, device=self.device)]
+        A.x, A.y, A.alive, A.agent_food, A.slot = ox, oy, oalive, ofood, oslot
+        k = 0
+        for obj, n in owners:
+            obj._die_state_permuted(outs[k:k + n], A.slot)
+            k += n
+
     # substeps, for custom update cycles (examples/simple_agents.py:16-30)
     def _stage(self, fn_name, action):
         act = self._as_action(action)
         m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), act.c_struct(), self._c_dynamics()
         _lib.check(getattr(_lib.lib, fn_name)(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(self._workspace),
                                               self._workspace.numel(), stream_ptr(self.device)), fn_name)
+
+    def _medium_deposit_feed_diffuse(self):
+        """Deposit + feeding + diffusion in one field sweep (after `_stage('die_agent_move_claim')`)."""
+        m, d = self.medium.c_struct(), self._c_dynamics()
+        _lib.check(_lib.lib.die_medium_deposit_feed_diffuse(C.byref(m), C.byref(d), stream_ptr(self.device)),
+                   'die_medium_deposit_feed_diffuse')
+        self.medium.swap_chem()
 
     def _medium_diffuse_decay(self):
         d = self.dynamics

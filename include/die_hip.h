@@ -19,11 +19,13 @@
  *     lookup of core/utils.py:39-54 is then exact integer arithmetic,
  *     cell = clamp((X*(W-1) + 2^31) >> 32, 0, W-1), and the `% 1.` wrap of
  *     core/env.py:155 is the natural 32-bit overflow.
- *   - the 'agents' medium channel (core/base_types.py:32) is held as an ownership word per
- *     cell: (epoch << 29) | (slot + 1) of the highest-index alive agent standing on the cell
- *     in step `epoch`; a cell is occupied iff word >> 29 == current epoch (epoch in 1..7,
- *     the caller zeroes the plane when it wraps).  Highest slot wins == the "last writer
- *     wins" of core/env.py:211.
+ *   - the 'agents' medium channel (core/base_types.py:32) is held as a 64-bit claim per cell:
+ *     high word (epoch << 29) | (slot + 1) of the highest-index alive agent standing on the
+ *     cell in step `epoch`, low word the fp32 bits of that agent's deposit.  A cell is occupied
+ *     iff claim >> 61 == current epoch (epoch in 1..7, the caller zeroes the plane when it
+ *     wraps).  One 64-bit atomicMax per agent: highest slot wins == the "last writer wins" of
+ *     core/env.py:211, and the winner's deposit reaches the diffusion sweep without a second
+ *     per-agent pass.
  */
 #ifndef DIE_HIP_H
 #define DIE_HIP_H
@@ -34,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 1
+#define DIE_ABI_VERSION 3
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -63,7 +65,7 @@ typedef struct die_medium {
     int32_t W, H;
     int32_t dtype;       /* die_dtype of food / chem / chem_next */
     int32_t epoch;       /* current ownership epoch, 1..DIE_OWNER_EPOCH_MAX */
-    uint32_t* owner;     /* 'agents' channel, W*H ownership words (see header comment) */
+    uint64_t* owner;     /* 'agents' channel, W*H claim words (see header comment) */
     void* food;          /* 'env_food', W*H */
     void* chem;          /* 'chem1', W*H, current */
     void* chem_next;     /* W*H, receives the diffused plane; the caller swaps after die_env_step */
@@ -76,6 +78,10 @@ typedef struct die_agents {
     uint32_t* y;         /* Q0.32 */
     uint8_t* alive;      /* 1 / 0 */
     float* agent_food;
+    uint32_t* slot;      /* reference slot id of each array entry, or NULL = identity.  The arrays may be
+                            held in any order (die_agents_sort keeps them spatially sorted); Philox
+                            counters and ownership words always use the slot id, so results do not
+                            depend on the order. */
 } die_agents;
 
 /* The (3, N) action array of core/data_init.py:152-157. */
@@ -117,7 +123,7 @@ typedef struct die_gradient_agent {
     float* heading;          /* N, _direction_rads (state, read and written) */
     float* prev_gx;          /* N, _prev_grad[0]; may be NULL when inertia == 0 */
     float* prev_gy;          /* N */
-    const int8_t* turn_sign; /* N entries ±1 replacing the random turn, or NULL → Philox(seed, step, slot) */
+    const int8_t* turn_sign; /* N entries ±1 (indexed by SLOT id) replacing the random turn, or NULL → Philox(seed, step, slot) */
     uint64_t seed;
     uint32_t step;           /* forward-call counter, the Philox step word */
     uint32_t reserved2;
@@ -167,6 +173,12 @@ int die_agent_resolve(const die_medium* m, const die_agents* a, const die_action
                       void* workspace, int64_t workspace_bytes, void* stream);
 int die_step_reduce(const die_agents* a, const die_dynamics* d, die_step_result* result,
                     void* workspace, int64_t workspace_bytes, void* stream);
+/* The field half of a step in ONE sweep (what die_env_step runs after die_agent_move_claim when
+ * H % 4 == 0 and the gaussian radius is <= 4): every cell's claim is read, the winner's deposit
+ * added (core/env.py:211), occupied cells fed (food -= rate*food, :222-228), and the result
+ * diffused and decayed (:136-145) into m->chem_next.  Replaces die_agent_resolve's per-agent
+ * scatter + die_diffuse_decay; DIE_ERR_UNSUPPORTED for other shapes (use those two instead). */
+int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, void* stream);
 /* gaussian(sigma, mode='wrap') × (1 − decay): src → dst, W×H planes of `dtype`. */
 int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype,
                       float sigma, float decay, void* stream);
@@ -190,6 +202,16 @@ int die_init_agents(const die_medium* m, const die_agents* a, uint64_t seed, int
  * discretised to the turn lattice when turn_radians > 0. */
 int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, float turn_radians,
                      uint64_t seed, void* stream);
+
+/* ---- spatial re-ordering of the agent arrays (no reference counterpart; see die_sort.hip) ----
+ * Writes `in` permuted into `out` (different arrays, out->slot required) so that array
+ * neighbours are grid neighbours: stable sort by the (ix/8, iy/64) bucket of each agent's cell.
+ * Up to 4 further per-slot float arrays (agent-object state such as headings) are permuted
+ * alongside.  Results of forward/step are independent of the order. */
+int64_t die_sort_workspace_bytes(int32_t W, int32_t H, int64_t N);
+int die_agents_sort(const die_medium* m, const die_agents* in, const die_agents* out, int32_t n_extra,
+                    const float* const* extra_in, float* const* extra_out, void* workspace,
+                    int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void k_access(const uint32_t* idx, int64_t n, 
         if (MODE == 2) atomicMax(&utable[c], (uint32_t)i);       // scattered atomic max (no return)
         if (MODE == 3) table[c] = table[c] + 1.0f;               // scattered RMW
         if (MODE == 4) atomicAdd(&table[c], 1.0f);               // float atomic add
+        if (MODE == 6) atomicMax(&((unsigned long long*)table)[c], ((unsigned long long)i << 32) | 7ull);   // u64 atomic max, 8-B cells
         if (MODE == 5) acc += table[c] + table[c + 4096] + table[c + 8192] + table[c + 1] ; // 4 gathers 3 rows
     }
     if (MODE == 0 || MODE == 5) { if (acc == 12345.678f) out[0] = acc; }
@@ -56,17 +57,30 @@ int main() {
     // tile order: agents sorted by 64x64 tile, random inside the tile
     std::vector<uint32_t> tiled = ordered;
     std::stable_sort(tiled.begin(), tiled.end(), [&](uint32_t a, uint32_t b) { auto t = [&](uint32_t c) { return ((c / H) / 64) * (H / 64) + ((c % H) / 64); }; return t(a) < t(b); });
+    // bucket order: sort by (ix/8, iy/64) bucket, random inside the bucket; then displaced copies
+    auto bucket_sorted = [&](int disp) {
+        std::vector<uint32_t> v = ordered;
+        auto b = [&](uint32_t c) { return ((c / H) / 8) * (H / 64) + ((c % H) / 64); };
+        std::shuffle(v.begin(), v.end(), rng);
+        std::stable_sort(v.begin(), v.end(), [&](uint32_t a, uint32_t c2) { return b(a) < b(c2); });
+        if (disp) { std::uniform_int_distribution<int> d(-disp, disp); for (auto& c : v) { int ix = (int)(c / H) + d(rng), iy = (int)(c % H) + d(rng); ix = std::min(std::max(ix, 0), W - 4); iy = std::min(std::max(iy, 0), H - 2); c = (uint32_t)(ix * H + iy); } }
+        return v;
+    };
+    std::vector<uint32_t> bk0 = bucket_sorted(0), bk3 = bucket_sorted(3), bk6 = bucket_sorted(6), bk12 = bucket_sorted(12);
+    std::vector<uint32_t> ord3 = ordered; { std::uniform_int_distribution<int> d(-3, 3); for (auto& c : ord3) { int ix = (int)(c / H) + d(rng), iy = (int)(c % H) + d(rng); ix = std::min(std::max(ix, 0), W - 4); iy = std::min(std::max(iy, 0), H - 2); c = (uint32_t)(ix * H + iy); } }
     uint32_t *d_idx; float *table, *out;
-    CK(hipMalloc(&d_idx, n * 4)); CK(hipMalloc(&table, C * 4)); CK(hipMalloc(&out, 16)); CK(hipMemset(table, 0, C * 4));
+    CK(hipMalloc(&d_idx, n * 4)); CK(hipMalloc(&table, C * 8)); CK(hipMalloc(&out, 16)); CK(hipMemset(table, 0, C * 8));
     const char* names[] = {"gather", "store", "atomicMax", "rmw", "atomicAddF", "gather4"};
-    struct { const char* name; std::vector<uint32_t>* v; } sets[] = {{"ordered", &ordered}, {"tile64", &tiled}, {"local4096", &local}, {"random", &shuffled}};
-    for (int grid : {2048, 9838}) {
+    struct { const char* name; std::vector<uint32_t>* v; } sets[] = {{"ordered", &ordered}, {"ordered+-3", &ord3}, {"bucket8x64", &bk0}, {"bucket+-3", &bk3}, {"bucket+-6", &bk6}, {"bucket+-12", &bk12}, {"random", &shuffled}};
+    for (int grid : {2048}) {
         for (auto& s : sets) {
             CK(hipMemcpy(d_idx, s.v->data(), n * 4, hipMemcpyHostToDevice));
             float t[6];
             t[0] = run<0>(d_idx, n, table, out, grid); t[1] = run<1>(d_idx, n, table, out, grid); t[2] = run<2>(d_idx, n, table, out, grid);
             t[3] = run<3>(d_idx, n, table, out, grid); t[4] = run<4>(d_idx, n, table, out, grid); t[5] = run<5>(d_idx, n, table, out, grid);
-            printf("grid %5d %-10s n=%lld :", grid, s.name, (long long)n);
+            float t6 = run<6>(d_idx, n, table, out, grid);
+            { std::vector<uint32_t> h2(*s.v); CK(hipMemcpy(d_idx, h2.data(), n * 4, hipMemcpyHostToDevice)); }
+            printf("grid %5d %-10s n=%lld : atomicMax64 %.1f us ", grid, s.name, (long long)n, t6);
             for (int m = 0; m < 6; ++m) printf("  %s %.1f us (%.0f G/s)", names[m], t[m], n / t[m] * 1e-3 * (m == 5 ? 4 : 1));
             printf("\n");
         }

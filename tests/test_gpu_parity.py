@@ -156,7 +156,7 @@ def test_physarum_forward_parity(die, W, H, N, cfg):
     dev.set_state(dir0)
     dev.set_turn_signs(sign)
     got = dev.forward(env._get_current_obs).to_numpy()
-    got_dir = dev._direction_rads.cpu().numpy().astype(np.float64)
+    got_dir = dev.direction_rads_numpy()
 
     # a slot disagrees if its heading differs (mod 2π) or its action is out of tolerance
     ddir = np.abs(R.renormalize_radians(got_dir - ref._direction_rads))
@@ -229,7 +229,7 @@ def test_gradient_agent_forward_parity(die, inertia, noise):
     assert np.mean(~np.isclose(got[:2], want[:2], rtol=RTOL, atol=2e-8 + 2e-6 * noise * 0.01)) < 2e-3
     assert np.allclose(got[2], want[2], rtol=RTOL, atol=1e-9)
     if inertia:
-        assert np.mean(~np.isclose(dev._prev_grad.cpu().numpy(), ref._prev_grad, rtol=RTOL, atol=2e-6)) < 2e-3
+        assert np.mean(~np.isclose(dev.prev_grad_numpy(), ref._prev_grad, rtol=RTOL, atol=2e-6)) < 2e-3
 
 
 def test_brownian_and_const_forward_parity(die):
@@ -323,6 +323,39 @@ def test_env_step_parity(die, case):
     assert obs[0] is env.agents and obs[1] is env.medium
 
 
+@pytest.mark.parametrize('W,H,N,K', [(64, 64, 3000, 2000), (96, 40, 4000, 4000), (37, 24, 500, 300)])
+def test_fused_step_equals_staged_step(die, W, H, N, K):
+    """die_env_step's fused field sweep (deposit + feeding + diffusion in one pass) against the
+    stage-by-stage entry points on the same inputs: identical bits."""
+    rs = np.random.RandomState(W + N)
+    medium, agents = random_state(W, H, N, K, rs)
+    action = quantised_action(N, rs, 3.0 / W)
+    outs = []
+    for mode in ('step', 'staged', 'sweep'):
+        env = die.Env.from_numpy(medium, agents, sort_every=0)
+        if mode == 'step':
+            env.step(action)
+        else:
+            act = die.DeviceAction.from_numpy(action, env.device)
+            env.medium.next_epoch()
+            env._stage('die_agent_move_claim', act)
+            env._stage('die_agent_resolve', act)
+            if mode == 'staged':
+                env._medium_diffuse_decay()
+            else:                                   # resolve already applied deposits: undo by a fresh env
+                env = die.Env.from_numpy(medium, agents, sort_every=0)
+                env.medium.next_epoch()
+                env._stage('die_agent_move_claim', act)
+                env._medium_deposit_feed_diffuse()
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][0], outs[2][0])
+    assert np.array_equal(outs[0][1][:3], outs[1][1][:3])
+    if K == N:                                      # with dead slots the sweep-only variant skips their feed pass
+        assert np.array_equal(outs[0][1], outs[2][1])
+    assert np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_step_kat_collisions_and_dead_slots(die):
     """Hand-checkable case (tests/test_oracle_kat.py): last writer wins, feed duplication,
     dead slot on an occupied cell consumes, reward counts every slot."""
@@ -409,6 +442,54 @@ def test_free_run_default_parameters_statistics(die):
     assert np.isclose(r[:, 0].sum(), r[:, 1].sum(), rtol=0.1, atol=0.5)
 
 
+def test_agent_sort_is_a_bucket_ordered_permutation(die):
+    """die_agents_sort: output is a permutation (slot ids carried), non-decreasing in the
+    (ix/8, iy/64) bucket key, and invisible through the slot-order accessors."""
+    W, H, N = 300, 520, 50000
+    rs = np.random.RandomState(3)
+    medium, agents = random_state(W, H, N, K=40000, rs=rs)
+    env = die.Env.from_numpy(medium, agents, sort_every=0)
+    before = env.agents.to_numpy()
+    env.sort_agents()
+    slot = env.agents.slot.cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(slot), np.arange(N))
+    assert np.array_equal(env.agents.to_numpy(), before)
+    x = (env.agents.x.cpu().numpy().view(np.uint32).astype(np.float64)) / 2 ** 32
+    y = (env.agents.y.cpu().numpy().view(np.uint32).astype(np.float64)) / 2 ** 32
+    key = (R.cell(x, W) >> 3) * ((H + 63) // 64) + (R.cell(y, H) >> 6)
+    assert (np.diff(key) >= 0).all()
+    env.sort_agents()                                   # sorting a sorted array keeps it a permutation
+    assert np.array_equal(env.agents.to_numpy(), before)
+
+
+@pytest.mark.parametrize('sort_every', [1, 3])
+def test_results_do_not_depend_on_agent_order(die, sort_every):
+    """Same run with and without re-ordering: every per-agent quantity is keyed by the slot id, so
+    state must agree bit for bit (the f64 reward is summed in array order: last-bit differences)."""
+    W = H = 96
+    rs = np.random.RandomState(21)
+    medium, agents = random_state(W, H, 3000, 2400, rs, collide=0.2)
+    kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), inertia=0.3, noise_scale=0.01)
+    runs = []
+    for se in (0, sort_every):
+        env = die.Env.from_numpy(medium, agents, sort_every=se)
+        ag = die.PhysarumAgent(max_agents=3000, seed=5, **kw)
+        obs = env._get_current_obs
+        rewards = []
+        for i in range(10):
+            act = ag.forward(obs)
+            if i == 4:                                   # a host-side action must be re-ordered on upload
+                act = act.to_numpy()
+            obs, rew, *_ = env.step(act)
+            rewards.append(rew)
+        runs.append((env.agents.to_numpy(), env.medium.to_numpy(), ag.direction_rads_numpy(), ag.prev_grad_numpy(),
+                     np.array(rewards), env.medium.owner_slots().cpu().numpy()))
+    for a, b in zip(runs[0][:4], runs[1][:4]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(runs[0][5], runs[1][5])
+    assert np.allclose(runs[0][4], runs[1][4], rtol=1e-12, atol=1e-12)
+
+
 # ------------------------------------------------------------------------------------ data_init
 @pytest.mark.parametrize('W,H,ratio', [(16, 12, 0.15), (64, 64, 0.05), (300, 200, 0.15), (1024, 1024, 0.15)])
 def test_init_parity(die, W, H, ratio):
@@ -441,7 +522,7 @@ def test_heading_init_parity(die):
     dev = die.PhysarumAgent(max_agents=N, seed=7)
     dev._alloc_state('cuda:0')
     ref = R.RefPhysarumAgent(N, seed=7)
-    got = dev._direction_rads.cpu().numpy().astype(np.float64)
+    got = dev.direction_rads_numpy()
     assert np.mean(np.abs(got - ref._direction_rads) > 1e-6) <= 1e-4      # lattice-boundary ties only
     lattice = got / np.radians(30)
     assert np.abs(lattice - np.round(lattice)).max() < 1e-5
@@ -462,7 +543,8 @@ def test_full_size_properties_4096(die):
         chem0 = env.medium.chem.double().sum().item()
         action = agent.forward(obs)
         obs, reward, term, _, info = env.step(action)
-        a = action.data.double()
+        from die_amd.device_array import unpermute
+        a = unpermute(action.data, action.slot).double()
         occ = env.medium.occupied()
         # every alive agent stands on an occupied cell; no more occupied cells than agents
         n_occ = int(occ.sum().item())
