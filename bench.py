@@ -33,6 +33,7 @@ def parse():
     p.add_argument('--cpu-steps', type=int, default=3)
     p.add_argument('--kernel-reps', type=int, default=20)
     p.add_argument('--sort-every', type=int, default=8)
+    p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
 
@@ -97,11 +98,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     if dist_on:
+        import datetime
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device(f'cuda:{local_rank}'))
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local_rank}'),
+                                timeout=datetime.timedelta(seconds=300))
     elif args.gpus > 1:
         sys.exit('launch N>1 with torch.distributed.run (one rank per GPU)')
     device = torch.device(f'cuda:{local_rank}')
@@ -109,13 +114,34 @@ def main():
 
     import die_amd
     W = H = args.size
-    # weak scaling: every rank steps its own W×H torus (replicas), seeds differ per rank
-    env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
-                      max_agents='alive', device=device, sync=False, sort_every=args.sort_every)
-    K = env.agents.N
     agent_kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), turn_angle=30, sense_angle=90,
                     turn_tolerance=0.1, deposit=4.0)
-    agent = die_amd.PhysarumAgent(max_agents=K, seed=args.seed + rank, **agent_kw)
+    GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
+    mode, denv = 'single GPU', None
+    if dist_on:
+        # weak scaling: every rank owns one W×H tile of a (W·Px)×(H·Py) torus — 2-D domain decomposition with
+        # chem-halo exchange and agent migration over RCCL point-to-point (die_amd/dist.py)
+        grid = GRIDS.get(world) or (1, world)
+        try:
+            from die_amd.dist import DistEnv
+            gW, gH = W * grid[0], H * grid[1]
+            # same cell-unit parameters as the single-GPU workload (10.2-cell probe, 1.53-cell step)
+            agent_kw.update(scale=1.53 / (gW - 1), sense_offset=10.2 / (gW - 1))
+            denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
+                           device=device, seed=args.seed, sort_every=args.sort_every)
+            mode = f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, halo {denv.geo.h}, RCCL p2p'
+        except Exception as e:           # keep the scaling run alive: independent replicas, and say so
+            denv = None
+            mode = f'{world} independent grid replicas (decomposition unavailable: {type(e).__name__}: {e})'
+    if denv is not None:
+        env = denv
+        K = env.agents.N
+        agent = die_amd.PhysarumAgent(max_agents=env.capacity, seed=args.seed + rank, **agent_kw)
+    else:
+        env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
+                          max_agents='alive', device=device, sync=False, sort_every=args.sort_every)
+        K = env.agents.N
+        agent = die_amd.PhysarumAgent(max_agents=K, seed=args.seed + rank, **agent_kw)
 
     obs = env._get_current_obs
     results = []
@@ -143,7 +169,8 @@ def main():
         dt = float(t.item())
     last_reward, last_alive = env.read_result(results[-1])
 
-    steps_per_s = args.steps / dt * world          # whole job: every rank advanced its own grid
+    # whole job: the world is `world` tiles of W×H cells, so one world step = `world` 4096²-grid steps
+    steps_per_s = args.steps / dt * world
     line = {
         'metric': 'env steps/sec on 4096^2 Physarum grid', 'value': round(steps_per_s, 2), 'unit': 'env steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
@@ -151,10 +178,18 @@ def main():
         'config': {'workload': f'PhysarumAgent {W}x{H} fp32 fields, agent ratio {args.ratio} (BASELINE configs[2]); '
                                'step = PhysarumAgent.forward + Env.step with the action handed over in HBM',
                    'grid': [W, H], 'alive_agents': K, 'agent_slots': K, 'steps_per_rank': args.steps,
-                   'parallelism': 'single GPU' if world == 1 else f'{world} independent grid replicas (no collective)',
+                   'parallelism': mode,
                    'last_reward': round(last_reward, 3), 'last_num_agents': last_alive},
     }
-    if rank == 0:
+    if rank == 0 and denv is not None:
+        Kw = int(getattr(denv, 'world_agents', K * world))
+        Bw = (12 * W * H * world + 104 * Kw)
+        line['config'].update(alive_agents=Kw, agent_slots=Kw, alive_agents_rank0=K)
+        line['roofline'] = {'bound': 'hbm', 'kernel': 'whole step (all ranks)', 'achieved': round(Bw / (dt / args.steps) / 1e9, 1),
+                            'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': round(Bw / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
+                            'traffic': None, 'algorithmic_bytes_per_launch': Bw}
+        print(json.dumps(line), flush=True)
+    elif rank == 0:
         C = W * H
         B = algorithmic_bytes(C, K)
         kt = time_kernels(env, agent, args.kernel_reps)

@@ -17,12 +17,13 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class Medium(C.Structure):
     _fields_ = [('W', C.c_int32), ('H', C.c_int32), ('dtype', C.c_int32), ('epoch', C.c_int32),
-                ('owner', C.c_void_p), ('food', C.c_void_p), ('chem', C.c_void_p), ('chem_next', C.c_void_p)]
+                ('owner', C.c_void_p), ('food', C.c_void_p), ('chem', C.c_void_p), ('chem_next', C.c_void_p),
+                ('gW', C.c_int32), ('gH', C.c_int32), ('ox', C.c_int32), ('oy', C.c_int32)]
 
 
 class Agents(C.Structure):
@@ -68,10 +69,19 @@ _SIGNATURES = {
                                C.c_void_p]),
     'die_agent_move_claim': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                        C.c_void_p]),
+    'die_agent_move': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                 C.c_void_p]),
+    'die_agent_claim_feed': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
+                                       C.c_void_p]),
+    'die_diffuse_decay_tile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                         C.c_void_p]),
     'die_agent_resolve': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                     C.c_void_p]),
     'die_step_reduce': (C.c_int, [_P(Agents), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_medium_deposit_feed_diffuse': (C.c_int, [_P(Medium), _P(Dynamics), C.c_void_p]),
+    'die_medium_deposit_feed_diffuse_tile': (C.c_int, [_P(Medium), _P(Dynamics), C.c_int32, C.c_void_p]),
+    'die_agent_dead_slots': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
+                                       C.c_void_p]),
     'die_diffuse_decay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                     C.c_void_p]),
     'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),

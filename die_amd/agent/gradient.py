@@ -98,6 +98,12 @@ class GradientAgent(Agent):
         from ..device_array import unpermute
         return unpermute(self._prev_grad, self._order).to(torch.float64).cpu().numpy()
 
+    def set_state_local(self, agents, direction_rads: torch.Tensor, prev_grad: Optional[torch.Tensor] = None):
+        """Decomposed world: state already in the local array order of `agents` (capacity-sized)."""
+        self._direction_rads = direction_rads
+        self._prev_grad = prev_grad
+        self._order = agents.slot
+
     def set_state(self, direction_rads: np.ndarray, prev_grad: Optional[np.ndarray] = None, device='cuda:0'):
         """Load `_direction_rads` (and `_prev_grad`) from host arrays given in slot order."""
         self._order = None
@@ -115,15 +121,19 @@ class GradientAgent(Agent):
     def forward(self, obs) -> DeviceAction:
         """:96-124."""
         agents, medium = obs
-        if agents.N != self._size:
-            raise ValueError(f'agent built for max_agents={self._size}, observation has {agents.N} slots')
+        if agents.capacity != self._size:
+            raise ValueError(f'agent built for max_agents={self._size}, observation has {agents.capacity} slots')
         dev = agents.device
         if self._direction_rads is None:
             self._alloc_state(dev)
         if self._order is not agents.slot:
-            self._align_to(agents.slot)
+            if agents.global_slots:                # decomposed world: state is kept in local array order
+                self._order = agents.slot
+            else:
+                self._align_to(agents.slot)
         agents.attach(self)
-        action = DeviceAction(agents.N, dev, agents.slot)
+        action = DeviceAction(agents.N, dev, agents.slot, capacity=agents.capacity)
+        action.global_slots = agents.global_slots
         pg = self._prev_grad
         g = _lib.GradientAgent(
             self._kind, int(bool(self._normalized)), self._scale, self._deposit, self._inertia,

@@ -19,7 +19,8 @@ class ConstAgent(Agent):
 
     def forward(self, obs) -> DeviceAction:
         agents, _ = obs
-        action = DeviceAction(agents.N, agents.device, agents.slot)
+        action = DeviceAction(agents.N, agents.device, agents.slot, capacity=agents.capacity)
+        action.global_slots = agents.global_slots
         u = action.c_struct()
         _lib.check(_lib.lib.die_const_forward(agents.N, *self._data, C.byref(u), stream_ptr(agents.device)),
                    'die_const_forward')
@@ -40,7 +41,8 @@ class BrownianAgent(Agent):
 
     def forward(self, obs) -> DeviceAction:
         agents, _ = obs
-        action = DeviceAction(agents.N, agents.device, agents.slot)
+        action = DeviceAction(agents.N, agents.device, agents.slot, capacity=agents.capacity)
+        action.global_slots = agents.global_slots
         a, u = agents.c_struct(), action.c_struct()
         _lib.check(_lib.lib.die_brownian_forward(C.byref(a), self._scale, self._dep_scale,
                                                  self._seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF,

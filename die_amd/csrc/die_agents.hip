@@ -9,7 +9,7 @@
 #include "die_rng.h"
 
 struct FwdArgs {
-    int W, H;
+    die_geo g;
     int64_t N;
     const void* chem;
     const void* food;
@@ -71,7 +71,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
     constexpr int U = DIE_FWD_UNROLL;
     const T* chem = (const T*)a.chem;
     const T* food = (const T*)a.food;
-    const int W = a.W, H = a.H;
+    const die_geo g = a.g;
+    const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
     const int64_t chunk = (int64_t)DIE_BLOCK * U;
     for (int64_t base = (int64_t)blockIdx.x * chunk; base < a.N; base += (int64_t)gridDim.x * chunk) {
         int64_t n[U];
@@ -100,8 +101,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
 #ifdef DIE_ABL_NOGATHER
             cxm[u] = (float)xm; cxp[u] = (float)xp * 1.5f; cym[u] = (float)ym; cyp[u] = (float)(yp + py);
 #else
-            cxm[u] = die_ld(chem, (int64_t)xm * H + py); cxp[u] = die_ld(chem, (int64_t)xp * H + py);
-            cym[u] = die_ld(chem, (int64_t)px * H + ym); cyp[u] = die_ld(chem, (int64_t)px * H + yp);
+            cxm[u] = die_ld(chem, die_local(g, xm, py)); cxp[u] = die_ld(chem, die_local(g, xp, py));
+            cym[u] = die_ld(chem, die_local(g, px, ym)); cyp[u] = die_ld(chem, die_local(g, px, yp));
 #endif
             wx[u] = (xp - xm) == 2 ? 0.5f : 1.0f;
             wy[u] = (yp - ym) == 2 ? 0.5f : 1.0f;
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
 #ifdef DIE_ABL_NOFOOD
             f_own[u] = (float)(cx + cy);
 #else
-            f_own[u] = die_ld(food, (int64_t)cx * H + cy);
+            f_own[u] = die_ld(food, die_local(g, cx, cy));
 #endif
         }
 #pragma unroll
@@ -243,7 +244,7 @@ extern "C" int die_gradient_forward(const die_medium* m, const die_agents* a, di
                 g->kind);
     DIE_REQUIRE(g->inertia == 0.f || (g->prev_gx && g->prev_gy), "die_gradient_forward: inertia needs prev_gx/prev_gy");
     FwdArgs k;
-    k.W = m->W; k.H = m->H; k.N = a->N;
+    k.g = die_geo_of(m); k.N = a->N;
     k.chem = m->chem; k.food = m->food; k.x = a->x; k.y = a->y; k.slot = a->slot;
     k.heading = g->heading; k.pgx = g->prev_gx; k.pgy = g->prev_gy; k.turn_sign = g->turn_sign;
     k.dx = out->dx; k.dy = out->dy; k.dep = out->deposit;

@@ -65,6 +65,23 @@ __device__ __forceinline__ bool die_claim_occupied(unsigned long long k, int epo
 }
 __device__ __forceinline__ float die_claim_deposit(unsigned long long k) { return __uint_as_float((uint32_t)k); }
 
+// ---- tile geometry (die_medium.gW/gH/ox/oy) ----------------------------------------------------
+struct die_geo {
+    int W, H;        // local plane dims (pitch = H)
+    int gW, gH;      // world size used for coordinate → cell
+    int ox, oy;      // global cell of local element (0, 0)
+};
+static inline die_geo die_geo_of(const die_medium* m) {
+    die_geo g;
+    g.W = m->W; g.H = m->H;
+    g.gW = m->gW > 0 ? m->gW : m->W; g.gH = m->gW > 0 ? m->gH : m->H;
+    g.ox = m->gW > 0 ? m->ox : 0; g.oy = m->gW > 0 ? m->oy : 0;
+    return g;
+}
+__device__ __forceinline__ int64_t die_local(const die_geo& g, int gx, int gy) {
+    return (int64_t)(gx - g.ox) * g.H + (gy - g.oy);
+}
+
 // ---- wave / block reductions -------------------------------------------------------------
 __device__ __forceinline__ double die_wave_sum(double v) {
 #pragma unroll

@@ -18,7 +18,11 @@
 #define DIE_MAX_PARTIALS 8192
 
 struct StepArgs {
-    int W, H, epoch;
+    die_geo g;
+    int epoch;
+    int do_move, do_claim;     // die_agent_move / die_agent_claim_feed run one half each
+    int tile_w, tile_h, tiles_y;
+    int32_t* tile_of;
     int64_t N;
     unsigned long long* owner;
     void* food;
@@ -64,22 +68,28 @@ __device__ __forceinline__ void block_sum_store(double g, long long c, double* p
 template <typename T>
 __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
     const T* food = (const T*)a.food;
+    const die_geo g = a.g;
     double gsum = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const float dx = a.dx[n], dy = a.dy[n];
         uint32_t X = a.x[n], Y = a.y[n];
-        if (a.boundary == DIE_BOUNDARY_WRAP) {            // (xy + dxdy) % 1.
-            X += (uint32_t)die_q32(dx);
-            Y += (uint32_t)die_q32(dy);
-        } else {                                          // clip(0, 1); 1.0 is held as 2^32 − 1
-            int64_t px = (int64_t)X + die_q32(dx), py = (int64_t)Y + die_q32(dy);
-            X = (uint32_t)(px < 0 ? 0 : (px > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : px));
-            Y = (uint32_t)(py < 0 ? 0 : (py > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : py));
+        if (a.do_move) {
+            if (a.boundary == DIE_BOUNDARY_WRAP) {            // (xy + dxdy) % 1.
+                X += (uint32_t)die_q32(dx);
+                Y += (uint32_t)die_q32(dy);
+            } else {                                          // clip(0, 1); 1.0 is held as 2^32 − 1
+                int64_t px = (int64_t)X + die_q32(dx), py = (int64_t)Y + die_q32(dy);
+                X = (uint32_t)(px < 0 ? 0 : (px > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : px));
+                Y = (uint32_t)(py < 0 ? 0 : (py > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : py));
+            }
+            a.x[n] = X;
+            a.y[n] = Y;
         }
-        a.x[n] = X;
-        a.y[n] = Y;
-        const int64_t c = (int64_t)die_cell((int64_t)X, a.W) * a.H + die_cell((int64_t)Y, a.H);
+        const int cx = die_cell((int64_t)X, g.gW), cy = die_cell((int64_t)Y, g.gH);
+        if (a.tile_of) a.tile_of[n] = (cx / a.tile_w) * a.tiles_y + cy / a.tile_h;
+        if (!a.do_claim) continue;
+        const int64_t c = die_local(g, cx, cy);
         const float consumed = a.rate_feed * die_ld(food, c);
         if (a.alive[n]) {
             atomicMax(&a.owner[c], die_claim(a.epoch, a.slot ? (int64_t)a.slot[n] : n, a.dep[n]));
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
             a.stash[n] = consumed;
         }
     }
-    block_sum_store(gsum, 0, a.part_gain, nullptr);
+    if (a.do_claim) block_sum_store(gsum, 0, a.part_gain, nullptr);
 }
 
 template <typename T>
@@ -102,7 +112,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t X = a.x[n], Y = a.y[n];
-        const int64_t c = (int64_t)die_cell((int64_t)X, a.W) * a.H + die_cell((int64_t)Y, a.H);
+        const int64_t c = die_local(a.g, die_cell((int64_t)X, a.g.gW), die_cell((int64_t)Y, a.g.gH));
         bool alive = a.alive[n] != 0;
         if (alive && !a.skip_scatter) {
             if ((uint32_t)(a.owner[c] >> 32) == die_owner_word(a.epoch, a.slot ? (int64_t)a.slot[n] : n)) {       // highest alive slot on the cell
@@ -223,6 +233,7 @@ struct RowsArgs {
     const unsigned long long* claim;   // FUSED only
     void* food;                        // FUSED only
     int W, H, epoch, food_infinite;
+    int halo;                          // tile mode: cells within `halo` of the array border belong to neighbours
     float keep, rate_feed;
     float w[2 * 4 + 1];
 };
@@ -245,7 +256,7 @@ template <> struct Vec4<__half> {
     }
 };
 
-template <typename T, int R, bool FUSED>
+template <typename T, int R, bool FUSED, bool WRAP>
 __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
     static_assert(R >= 1 && R <= 4, "one halo lane of 4 columns per side");
     const T* src = (const T*)a.src;
@@ -259,7 +270,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
     const int nout = min(DIF_WCOLS, H - yb) / 4;            // output lanes are 1..nout (H % 4 == 0)
     const bool need = lane <= nout + 1;                     // + the two halo lanes
     const bool outl = lane >= 1 && lane <= nout;
-    const int col = wrap_idx(yb + 4 * (lane - 1), H);       // 16-byte aligned since H % 4 == 0
+    const int col = WRAP ? wrap_idx(yb + 4 * (lane - 1), H)  // 16-byte aligned since H % 4 == 0
+                         : min(max(yb + 4 * (lane - 1), 0), H - 4);   // tile: clamp, border ring is don't-care
     const int x0 = blockIdx.y * DIF_ROWS;
     const int rows = min(DIF_ROWS, W - x0);
 
@@ -270,7 +282,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
     auto load_row = [&](int i, float v[4]) {
         v[0] = v[1] = v[2] = v[3] = 0.f;
         if (!need) return;
-        const int r = wrap_idx(x0 + i, W);
+        const int r = WRAP ? wrap_idx(x0 + i, W) : min(max(x0 + i, 0), W - 1);
         const int64_t off = (int64_t)r * H + col;
         Vec4<T>::ld(src + off, v);
         if (FUSED) {
@@ -284,12 +296,16 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
                 if (occ[j]) v[j] += die_claim_deposit(c[j]);     // chem[cell] + deposit of the last writer
                 any |= occ[j];
             }
-            // feeding: this wave owns rows [x0, x0+rows) × its output lanes
-            if (any && outl && i >= 0 && i < rows && !a.food_infinite) {
+            // feeding: this wave owns rows [x0, x0+rows) × its output lanes (tile mode: interior cells only)
+            const bool own_row = i >= 0 && i < rows && (WRAP || (r >= a.halo && r < W - a.halo));
+            if (any && outl && own_row && !a.food_infinite) {
                 float f[4];
                 Vec4<T>::ld(food + off, f);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (occ[j]) f[j] = f[j] - a.rate_feed * f[j];
+                for (int j = 0; j < 4; ++j) {
+                    const bool mine = WRAP || (col + j >= a.halo && col + j < H - a.halo);
+                    if (occ[j] && mine) f[j] = f[j] - a.rate_feed * f[j];
+                }
                 Vec4<T>::st(food + off, f);
             }
         }
@@ -336,15 +352,15 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
     }
 }
 
-template <typename T, bool FUSED>
+template <typename T, bool FUSED, bool WRAP = true>
 static int launch_rows(const RowsArgs& a, int R, hipStream_t s) {
     const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
     dim3 grid((strips + 3) / 4, (a.W + DIF_ROWS - 1) / DIF_ROWS);
     switch (R) {
-        case 1: k_diffuse_rows<T, 1, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
-        case 2: k_diffuse_rows<T, 2, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
-        case 3: k_diffuse_rows<T, 3, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
-        case 4: k_diffuse_rows<T, 4, FUSED><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 1: k_diffuse_rows<T, 1, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 2: k_diffuse_rows<T, 2, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 3: k_diffuse_rows<T, 3, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 4: k_diffuse_rows<T, 4, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
         default: return DIE_ERR_UNSUPPORTED;
     }
     return DIE_OK;
@@ -395,7 +411,7 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
         RowsArgs ra;
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
-        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0;
+        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
         ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
         for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
         int rc2 = dtype == DIE_F32 ? launch_rows<float, false>(ra, R, (hipStream_t)stream)
@@ -457,7 +473,8 @@ static int fill_args(StepArgs& k, const die_medium* m, const die_agents* a, cons
     } else {
         k.dx = k.dy = k.dep = nullptr;
     }
-    k.W = m->W; k.H = m->H; k.epoch = m->epoch; k.N = a->N;
+    k.g = die_geo_of(m); k.epoch = m->epoch; k.N = a->N;
+    k.do_move = 1; k.do_claim = 1; k.tile_w = k.tile_h = k.tiles_y = 1; k.tile_of = nullptr;
     k.owner = (unsigned long long*)m->owner; k.food = m->food; k.chem = m->chem;
     k.x = a->x; k.y = a->y; k.slot = a->slot; k.alive = a->alive; k.agent_food = a->agent_food;
     k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
@@ -481,6 +498,62 @@ extern "C" int die_agent_move_claim(const die_medium* m, const die_agents* a, co
     if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_move_claim<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     DIE_CHECK_LAUNCH("die_agent_move_claim");
+    return DIE_OK;
+}
+
+extern "C" int die_agent_move(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                              int32_t tile_w, int32_t tile_h, int32_t tiles_y, int32_t* tile_of, void* stream) {
+    DIE_REQUIRE(m && a && act && d && tile_of, "die_agent_move: null argument");
+    DIE_REQUIRE(tile_w >= 1 && tile_h >= 1 && tiles_y >= 1, "die_agent_move: bad tile shape");
+    DIE_REQUIRE(a->N > 0 && act->N == a->N && a->x && a->y && act->dx && act->dy, "die_agent_move: bad arrays");
+    if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
+        die_set_error("die_agent_move: boundary %d is not representable in Q0.32", d->boundary);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    StepArgs k = {};
+    k.g = die_geo_of(m); k.N = a->N; k.x = a->x; k.y = a->y; k.dx = act->dx; k.dy = act->dy;
+    k.boundary = d->boundary; k.do_move = 1; k.do_claim = 0;
+    k.tile_w = tile_w; k.tile_h = tile_h; k.tiles_y = tiles_y; k.tile_of = tile_of;
+    k_move_claim<float><<<step_grid(a->N), DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    DIE_CHECK_LAUNCH("die_agent_move");
+    return DIE_OK;
+}
+
+extern "C" int die_agent_claim_feed(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                                    void* ws, int64_t ws_bytes, void* stream) {
+    StepArgs k;
+    int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_claim_feed");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(act, "die_agent_claim_feed: null action");
+    k.do_move = 0;
+    k.part_gain = (double*)ws;
+    const int grid = step_grid(a->N);
+    if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    else k_move_claim<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    DIE_CHECK_LAUNCH("die_agent_claim_feed");
+    return DIE_OK;
+}
+
+extern "C" int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma,
+                                      float decay, void* stream) {
+    DIE_REQUIRE(src && dst && src != dst, "die_diffuse_decay_tile: src/dst must be distinct non-null planes");
+    DIE_REQUIRE(dtype == DIE_F32 || dtype == DIE_F16, "die_diffuse_decay_tile: bad dtype %d", dtype);
+    DIE_REQUIRE(sigma > 0.f, "die_diffuse_decay_tile: sigma must be positive");
+    const int R = (int)(4.0 * (double)sigma + 0.5);
+    if (!(R >= 1 && R <= 4 && H % 4 == 0 && H >= 8 && W >= 2 * R + 1)) {
+        die_set_error("die_diffuse_decay_tile: needs H %% 4 == 0, H >= 8, radius 1..4 (W=%d H=%d sigma=%g)", W, H, (double)sigma);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    RowsArgs ra;
+    double wd[2 * DIF_MAXR + 1];
+    gaussian_taps(sigma, wd);
+    ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+    ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
+    for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
+    int rc = dtype == DIE_F32 ? launch_rows<float, false, false>(ra, R, (hipStream_t)stream)
+                              : launch_rows<__half, false, false>(ra, R, (hipStream_t)stream);
+    if (rc != DIE_OK) return rc;
+    DIE_CHECK_LAUNCH("die_diffuse_decay_tile");
     return DIE_OK;
 }
 
@@ -511,6 +584,8 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
     return DIE_OK;
 }
 
+static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream, const char* who);
+
 // winner-independent remainder of k_resolve: dead slots, lifecycle, alive count (fused path only
 // launches it when such slots can exist)
 extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
@@ -520,12 +595,17 @@ extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_
     int rc = die_agent_move_claim(m, a, act, d, ws, ws_bytes, stream);
     if (rc != DIE_OK) return rc;
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    const bool fused = rows_kernel_applies(m->W, m->H, R) && R >= 1 && !getenv("DIE_NO_FUSED_STEP");
+    const bool fused = m->gW <= 0 && rows_kernel_applies(m->W, m->H, R) && R >= 1 && !getenv("DIE_NO_FUSED_STEP");
     if (!fused) {
         rc = die_agent_resolve(m, a, act, d, ws, ws_bytes, stream);
         if (rc != DIE_OK) return rc;
         rc = die_step_reduce(a, d, result, ws, ws_bytes, stream);
         if (rc != DIE_OK) return rc;
+            if (m->gW > 0) {
+            die_set_error("die_env_step: a decomposed tile needs halo exchange and migration between the stages; "
+                          "drive die_agent_move / die_agent_claim_feed / die_agent_resolve / die_diffuse_decay_tile instead");
+            return DIE_ERR_UNSUPPORTED;
+        }
         return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
     }
     // fused path: deposits and feeding ride on the diffusion sweep; the per-agent second pass is only
@@ -551,32 +631,61 @@ extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_
                                                       second_pass ? g : 0, result, second_pass ? -1 : a->N);
         DIE_CHECK_LAUNCH("die_env_step(reduce)");
     }
-    return die_medium_deposit_feed_diffuse(m, d, stream);
+    return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed)");
 }
 
-extern "C" int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, void* stream) {
-    DIE_REQUIRE(m && d, "die_medium_deposit_feed_diffuse: null argument");
-    DIE_REQUIRE(m->owner && m->food && m->chem && m->chem_next && m->chem_next != m->chem,
-                "die_medium_deposit_feed_diffuse: null or aliased plane");
-    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "die_medium_deposit_feed_diffuse: bad dtype %d", m->dtype);
-    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "die_medium_deposit_feed_diffuse: bad epoch %d", m->epoch);
+static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream,
+                                const char* who) {
+    DIE_REQUIRE(m && d, "%s: null argument", who);
+    DIE_REQUIRE(m->owner && m->food && m->chem && m->chem_next && m->chem_next != m->chem, "%s: null or aliased plane", who);
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad dtype %d", who, m->dtype);
+    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "%s: bad epoch %d", who, m->epoch);
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    if (!(rows_kernel_applies(m->W, m->H, R) && R >= 1)) {
-        die_set_error("die_medium_deposit_feed_diffuse: needs H %% 4 == 0 and radius 1..4 (H=%d, sigma=%g)", m->H,
-                      (double)d->diffuse_sigma);
+    if (!(rows_kernel_applies(m->W, m->H, R) && R >= 1 && (!tile || (m->H >= 8 && m->W >= 2 * R + 1 && halo >= R)))) {
+        die_set_error("%s: needs H %% 4 == 0 and radius 1..4 (W=%d H=%d sigma=%g halo=%d)", who, m->W, m->H,
+                      (double)d->diffuse_sigma, halo);
         return DIE_ERR_UNSUPPORTED;
     }
     RowsArgs ra;
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(d->diffuse_sigma, wd);
     ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.food = m->food;
-    ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite;
+    ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo;
     ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
-    int rc = m->dtype == DIE_F32 ? launch_rows<float, true>(ra, R, (hipStream_t)stream)
-                                 : launch_rows<__half, true>(ra, R, (hipStream_t)stream);
+    int rc;
+    if (tile) rc = m->dtype == DIE_F32 ? launch_rows<float, true, false>(ra, R, (hipStream_t)stream)
+                                       : launch_rows<__half, true, false>(ra, R, (hipStream_t)stream);
+    else rc = m->dtype == DIE_F32 ? launch_rows<float, true, true>(ra, R, (hipStream_t)stream)
+                                  : launch_rows<__half, true, true>(ra, R, (hipStream_t)stream);
     if (rc != DIE_OK) return rc;
-    DIE_CHECK_LAUNCH("die_medium_deposit_feed_diffuse");
+    DIE_CHECK_LAUNCH(who);
+    return DIE_OK;
+}
+
+extern "C" int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, void* stream) {
+    DIE_REQUIRE(m && m->gW <= 0, "die_medium_deposit_feed_diffuse: periodic single-tile planes only "
+                                 "(decomposed tiles: die_medium_deposit_feed_diffuse_tile)");
+    return deposit_feed_diffuse(m, d, 0, false, stream, "die_medium_deposit_feed_diffuse");
+}
+
+extern "C" int die_medium_deposit_feed_diffuse_tile(const die_medium* m, const die_dynamics* d, int32_t halo, void* stream) {
+    return deposit_feed_diffuse(m, d, halo, true, stream, "die_medium_deposit_feed_diffuse_tile");
+}
+
+extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                                    void* ws, int64_t ws_bytes, void* stream) {
+    StepArgs k;
+    int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_dead_slots");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(act, "die_agent_dead_slots: null action");
+    k.part_gain = (double*)ws + DIE_MAX_PARTIALS;
+    k.part_alive = (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS);
+    k.skip_scatter = 1;
+    const int grid = step_grid(a->N);
+    if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    else k_resolve<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    DIE_CHECK_LAUNCH("die_agent_dead_slots");
     return DIE_OK;
 }
 

@@ -19,17 +19,23 @@ struct FoodArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(int W, int H, uint64_t* owner, T* food, T* chem, double ratio,
+__global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(die_geo g, uint64_t* owner, T* food, T* chem, double ratio,
                                                            uint64_t seed, FoodArgs fa) {
+    const int W = g.W, H = g.H;
     const int64_t C = (int64_t)W * H;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += stride) {
         // ceil(u·[0 ≤ u ≤ ratio]) with u = random_sample().round(3): occupied iff 0 < u ≤ ratio
-        const int r = die_round3_units(die_draw(seed, 0, (uint64_t)c, DIE_STREAM_INIT_AGENTS).v[0]);
+        // world cell of this element (a decomposed tile's halo wraps around the world)
+        const int lx = (int)(c / H), ly = (int)(c - (int64_t)lx * H);
+        int ix = (lx + g.ox) % g.gW, iy = (ly + g.oy) % g.gH;
+        ix = ix < 0 ? ix + g.gW : ix;
+        iy = iy < 0 ? iy + g.gH : iy;
+        const uint64_t gc = (uint64_t)ix * (uint64_t)g.gH + (uint64_t)iy;
+        const int r = die_round3_units(die_draw(seed, 0, gc, DIE_STREAM_INIT_AGENTS).v[0]);
         const double u = r / 1000.0;
         owner[c] = (r > 0 && u <= ratio) ? 1ull : 0ull;    // provisional flag; k_scatter writes the claim word
-        const int ix = (int)(c / H), iy = (int)(c - (int64_t)ix * H);
-        const double x = (double)ix / W, y = (double)iy / H;
+        const double x = (double)ix / g.gW, y = (double)iy / g.gH;
         double s = 0.0;
         for (int k = 0; k < fa.n_waves; ++k)
             s += fa.amp[k] * sin(6.283185307179586476925 * (fa.fx[k] * x + fa.fy[k] * y) + fa.phase[k]);
@@ -76,10 +82,11 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_scan_blocks(const int32_t* block_
     for (int i = lo; i < hi; ++i) { block_off[i] = run; run += block_sum[i]; }
 }
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_scatter(int W, int H, uint64_t* owner, const int64_t* block_off, int64_t N,
+__global__ __launch_bounds__(DIE_BLOCK) void k_scatter(die_geo g, uint64_t* owner, const int64_t* block_off, int64_t N,
                                                        uint32_t* x, uint32_t* y, uint8_t* alive, float* agent_food,
                                                        uint64_t seed) {
-    const int64_t C = (int64_t)W * H;
+    const int H = g.H, W = g.gW;             // labels are world coordinates: linspace(0, 1, gW)
+    const int64_t C = (int64_t)g.W * g.H;
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     int flags = 0, cnt = 0;
 #pragma unroll
@@ -101,10 +108,11 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_scatter(int W, int H, uint64_t* o
         if (c >= C) break;
         if (flags & (1 << i)) {
             if (k < N) {
-                const int ix = (int)(c / H), iy = (int)(c - (int64_t)ix * H);
+                const int lx = (int)(c / H), ly = (int)(c - (int64_t)lx * H);
+                const int ix = lx + g.ox, iy = ly + g.oy;
                 // x = linspace(0, 1, W)[ix] in Q0.32; the last label 1.0 is held as 2^32 − 1
                 const double qx = W > 1 ? (double)ix / (double)(W - 1) * 4294967296.0 : 0.0;
-                const double qy = H > 1 ? (double)iy / (double)(H - 1) * 4294967296.0 : 0.0;
+                const double qy = g.gH > 1 ? (double)iy / (double)(g.gH - 1) * 4294967296.0 : 0.0;
                 const long long X = __double2ll_rn(qx), Y = __double2ll_rn(qy);
                 x[k] = (uint32_t)(X > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : X);
                 y[k] = (uint32_t)(Y > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : Y);
@@ -169,10 +177,10 @@ extern "C" int die_init_medium(const die_medium* m, double agent_ratio, uint64_t
     for (int i = 0; i < 8; ++i) { fa.fx[i] = food->fx[i]; fa.fy[i] = food->fy[i]; fa.phase[i] = food->phase[i]; fa.amp[i] = food->amp[i]; }
     const int grid = init_grid((int64_t)m->W * m->H);
     if (m->dtype == DIE_F32)
-        k_init_medium<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(m->W, m->H, m->owner, (float*)m->food,
+        k_init_medium<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(die_geo_of(m), m->owner, (float*)m->food,
                                                                            (float*)m->chem, agent_ratio, seed, fa);
     else
-        k_init_medium<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(m->W, m->H, m->owner, (__half*)m->food,
+        k_init_medium<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(die_geo_of(m), m->owner, (__half*)m->food,
                                                                             (__half*)m->chem, agent_ratio, seed, fa);
     DIE_CHECK_LAUNCH("die_init_medium");
     return DIE_OK;
@@ -193,7 +201,7 @@ extern "C" int die_init_agents(const die_medium* m, const die_agents* a, uint64_
     hipStream_t s = (hipStream_t)stream;
     k_count<<<(int)nb, DIE_BLOCK, 0, s>>>(m->owner, C, block_sum);
     k_scan_blocks<<<1, DIE_BLOCK, 0, s>>>(block_sum, (int)nb, block_off, num_alive_dev, a->N);
-    k_scatter<<<(int)nb, DIE_BLOCK, 0, s>>>(m->W, m->H, m->owner, block_off, a->N, a->x, a->y, a->alive, a->agent_food, seed);
+    k_scatter<<<(int)nb, DIE_BLOCK, 0, s>>>(die_geo_of(m), m->owner, block_off, a->N, a->x, a->y, a->alive, a->agent_food, seed);
     k_zero_tail<<<init_grid(a->N), DIE_BLOCK, 0, s>>>(num_alive_dev, a->N, a->x, a->y, a->alive, a->agent_food);
     DIE_CHECK_LAUNCH("die_init_agents");
     return DIE_OK;

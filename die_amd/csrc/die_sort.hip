@@ -12,11 +12,14 @@
 
 #define DIE_SORT_MAX_EXTRA 4
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_sort_keys(int W, int H, int64_t N, const uint32_t* x, const uint32_t* y,
+__global__ __launch_bounds__(DIE_BLOCK) void k_sort_keys(die_geo g, int64_t N, const uint32_t* x, const uint32_t* y,
                                                          int nby, uint32_t* key, uint32_t* val) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
-        const int ix = die_cell((int64_t)x[n], W), iy = die_cell((int64_t)y[n], H);
+        // row / column inside the local planes (a decomposed tile: world cell − tile origin)
+        int ix = die_cell((int64_t)x[n], g.gW) - g.ox, iy = die_cell((int64_t)y[n], g.gH) - g.oy;
+        ix = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
+        iy = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
         key[n] = (uint32_t)((ix >> 3) * nby + (iy >> 6));
         val[n] = (uint32_t)n;
     }
@@ -96,7 +99,7 @@ extern "C" int die_agents_sort(const die_medium* m, const die_agents* in, const 
     hipStream_t s = (hipStream_t)stream;
     int64_t g = (N + DIE_BLOCK - 1) / DIE_BLOCK;
     const int grid = (int)(g < 4096 ? g : 4096);
-    k_sort_keys<<<grid, DIE_BLOCK, 0, s>>>(m->W, m->H, N, in->x, in->y, (m->H + 63) / 64, key_in, val_in);
+    k_sort_keys<<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), N, in->x, in->y, (m->H + 63) / 64, key_in, val_in);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)N, 0, bits, s);
     if (e != hipSuccess) {
         die_set_error("die_agents_sort: radix sort failed: %s", hipGetErrorString(e));

@@ -49,6 +49,7 @@ class DeviceMedium:
         self.chem = torch.zeros((W, H), dtype=dtype, device=device)
         self.chem_next = torch.empty((W, H), dtype=dtype, device=device)
         self.epoch = 1
+        self.world = None        # (gW, gH, ox, oy) when these planes are one tile of a decomposed world
 
     @property
     def shape(self):
@@ -56,7 +57,8 @@ class DeviceMedium:
 
     def c_struct(self) -> _lib.Medium:
         return _lib.Medium(self.W, self.H, _lib.DIE_F32 if self.dtype == torch.float32 else _lib.DIE_F16, self.epoch,
-                           _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next))
+                           _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next),
+                           *(self.world or (0, 0, 0, 0)))
 
     def next_epoch(self):
         """Advance the ownership epoch; zero the plane when the 3-bit tag wraps."""
@@ -129,6 +131,7 @@ class DeviceAgents:
         self.alive = torch.zeros(N, dtype=torch.uint8, device=device)
         self.agent_food = torch.zeros(N, dtype=torch.float32, device=device)
         self.slot: Optional[torch.Tensor] = None
+        self.global_slots = False    # decomposed world: `slot` holds world slot ids, N <= capacity of the arrays
         self._attached = []          # weak references to objects holding per-slot state (Agent objects)
 
     @property
@@ -159,10 +162,16 @@ class DeviceAgents:
             v = self.agent_food
         else:
             raise KeyError(channel)
+        if self.global_slots:
+            return v[:self.N]                       # local agents in array order (see DistEnv.gather_world)
         return unpermute(v, self.slot)
 
     def to_numpy(self) -> np.ndarray:
         return np.stack([self.sel(c).to(torch.float64).cpu().numpy() for c in self.channels])
+
+    @property
+    def capacity(self) -> int:
+        return int(self.x.numel())
 
     def q32_numpy(self):
         """Raw coordinate words as uint32 arrays, slot order."""
@@ -184,11 +193,12 @@ class DeviceAction:
     was computed for (`slot` as in DeviceAgents); `to_numpy` / `sel` give slot order."""
     channels = DataChannels.actions
 
-    def __init__(self, num_slots: int, device, slot: Optional[torch.Tensor] = None):
+    def __init__(self, num_slots: int, device, slot: Optional[torch.Tensor] = None, capacity: Optional[int] = None):
         N = int(num_slots)
         self.N, self.device = N, torch.device(device)
-        self.data = torch.empty((3, N), dtype=torch.float32, device=device)
+        self.data = torch.empty((3, int(capacity or N)), dtype=torch.float32, device=device)
         self.slot = slot
+        self.global_slots = False
 
     @property
     def shape(self):
@@ -198,9 +208,12 @@ class DeviceAction:
         return _lib.Action(self.N, _ptr(self.data[0]), _ptr(self.data[1]), _ptr(self.data[2]))
 
     def sel(self, channel: str) -> torch.Tensor:
-        return unpermute(self.data[self.channels.index(channel)], self.slot)
+        row = self.data[self.channels.index(channel)]
+        return row[:self.N] if self.global_slots else unpermute(row, self.slot)
 
     def to_numpy(self) -> np.ndarray:
+        if self.global_slots:
+            return self.data[:, :self.N].to(torch.float64).cpu().numpy()
         return unpermute(self.data, self.slot).to(torch.float64).cpu().numpy()
 
     def in_order_of(self, slot: Optional[torch.Tensor]) -> 'DeviceAction':

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 3
+#define DIE_ABI_VERSION 4
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -69,6 +69,12 @@ typedef struct die_medium {
     void* food;          /* 'env_food', W*H */
     void* chem;          /* 'chem1', W*H, current */
     void* chem_next;     /* W*H, receives the diffused plane; the caller swaps after die_env_step */
+    /* Domain decomposition.  gW == 0: the planes ARE the periodic W×H world.
+     * gW > 0: the planes are one rank's tile of a gW×gH world, halo included: local element
+     * (i, j) is global cell (ox + i, oy + j); agent coordinates stay global; nothing wraps
+     * inside the tile (the halo is filled by the caller's exchange). */
+    int32_t gW, gH;
+    int32_t ox, oy;
 } die_medium;
 
 /* The (4, N) agent array of core/data_init.py:114-150, structure of arrays. */
@@ -179,6 +185,26 @@ int die_step_reduce(const die_agents* a, const die_dynamics* d, die_step_result*
  * diffused and decayed (:136-145) into m->chem_next.  Replaces die_agent_resolve's per-agent
  * scatter + die_diffuse_decay; DIE_ERR_UNSUPPORTED for other shapes (use those two instead). */
 int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, void* stream);
+/* Same sweep on a halo-padded tile of a decomposed world (no wrap; chem AND claims of the halo
+ * must have been exchanged): deposits are applied everywhere, feeding only to the cells at
+ * least `halo` away from the array border, the outer `radius` ring of chem_next is unspecified. */
+int die_medium_deposit_feed_diffuse_tile(const die_medium* m, const die_dynamics* d, int32_t halo, void* stream);
+/* The part of die_agent_resolve that does not touch the field: dead slots finish their feed,
+ * lifecycle (agents_die), alive count — for callers that let the field sweep do the scatter. */
+int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+/* Decomposed step, first half: positions only (core/env.py:163-172).  tile_of[n] receives the
+ * index tile_x * tiles_y + tile_y of the interior tile (tile_w × tile_h cells each) the agent now
+ * stands on, so the caller can migrate it before die_agent_claim_feed. */
+int die_agent_move(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                   int32_t tile_w, int32_t tile_h, int32_t tiles_y, int32_t* tile_of, void* stream);
+/* Decomposed step, second half: claim + feeding of die_agent_move_claim without the move. */
+int die_agent_claim_feed(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                         void* workspace, int64_t workspace_bytes, void* stream);
+/* gaussian × (1 − decay) on a halo-padded tile: no wrap; exact for cells at least `radius` away
+ * from the array border, the outer ring of dst is unspecified. */
+int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype,
+                           float sigma, float decay, void* stream);
 /* gaussian(sigma, mode='wrap') × (1 − decay): src → dst, W×H planes of `dtype`. */
 int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype,
                       float sigma, float decay, void* stream);

@@ -1,0 +1,108 @@
+"""CPU tests of the decomposition layer (die_amd/dist.py) over gloo, world sizes 2 and 4: tile
+geometry, two-phase periodic halo exchange incl. corners, agent-record routing, hole filling.
+No kernel runs here; the GPU equality test is tests/test_gpu_dist.py."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from die_amd.dist import Comm, TileGeometry, fill_holes, halo_exchange, route_records
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, size, port, fn, args):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        fn(rank, size, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(size, fn, *args):
+    mp.spawn(_worker, args=(size, _free_port(), fn, args), nprocs=size, join=True)
+
+
+def test_tile_geometry():
+    g = TileGeometry((64, 48), (2, 2), 3, 6)
+    assert (g.px, g.py, g.Wi, g.Hi, g.x0, g.y0) == (1, 1, 32, 24, 32, 24)
+    assert (g.W, g.H, g.ox, g.oy) == (44, 36, 26, 18)
+    assert g.neighbour(1, 1) == 0 and g.neighbour(-1, 0) == 1 and g.neighbour(0, -1) == 2
+    assert list(g.tile_of_cell([0, 31, 32, 63], [0, 23, 24, 47])) == [0, 0, 3, 3]
+    with pytest.raises(ValueError):
+        TileGeometry((64, 48), (3, 2), 0, 2)
+    with pytest.raises(ValueError):
+        TileGeometry((64, 48), (2, 2), 0, 40)
+    g1 = TileGeometry((16, 16), (1, 1), 0, 4)
+    assert g1.neighbour(1, 0) == 0 and g1.neighbour(0, -1) == 0
+
+
+def _halo_case(rank, size, world, grid, h):
+    g = TileGeometry(world, grid, rank, h)
+    comm = Comm()
+    gid = np.arange(world[0] * world[1], dtype=np.float32).reshape(world)
+    plane = torch.full((g.W, g.H), -1.0)
+    ri, ci = g.interior()
+    plane[ri, ci] = torch.from_numpy(gid[g.x0:g.x0 + g.Wi, g.y0:g.y0 + g.Hi])
+    halo_exchange(plane, g, comm)
+    ix = (np.arange(g.W) + g.ox) % world[0]
+    iy = (np.arange(g.H) + g.oy) % world[1]
+    want = gid[ix][:, iy]
+    assert np.array_equal(plane.numpy(), want), f'rank {rank}: halo mismatch'
+
+
+@pytest.mark.parametrize('size,world,grid,h', [(2, (12, 16), (1, 2), 3), (2, (16, 12), (2, 1), 4), (4, (16, 24), (2, 2), 5),
+                                                (1, (8, 8), (1, 1), 3), (4, (32, 8), (4, 1), 2)])
+def test_halo_exchange_is_periodic_including_corners(size, world, grid, h):
+    _run(size, _halo_case, world, grid, h)
+
+
+def _route_case(rank, size, n):
+    comm = Comm()
+    rs = np.random.RandomState(100 + rank)
+    dest = torch.from_numpy(rs.randint(0, size, n))
+    payload = torch.from_numpy(np.stack([np.full(n, rank), np.arange(n), dest.numpy()]).astype(np.int32))
+    kept, arrivals = route_records(payload, dest, comm)
+    assert kept.sum().item() == int((dest == rank).sum())
+    a = arrivals.numpy()
+    assert (a[2] == rank).all() and (a[0] != rank).all()
+    # every rank can recompute what the others drew: nothing lost, nothing duplicated
+    want = 0
+    for r in range(size):
+        if r != rank:
+            want += int((np.random.RandomState(100 + r).randint(0, size, n) == rank).sum())
+    assert a.shape[1] == want
+    assert len({(int(s), int(i)) for s, i in zip(a[0], a[1])}) == want
+
+
+@pytest.mark.parametrize('size', [2, 4])
+def test_route_records_delivers_every_record_once(size):
+    _run(size, _route_case, 500)
+
+
+def test_fill_holes_plans():
+    rs = np.random.RandomState(0)
+    for n, n_leave, n_arr in [(100, 10, 10), (100, 10, 25), (100, 30, 5), (50, 50, 0), (50, 0, 7), (40, 15, 0), (1, 1, 0)]:
+        leaving = torch.zeros(n, dtype=torch.bool)
+        leaving[torch.from_numpy(rs.permutation(n)[:n_leave])] = True
+        vals = torch.arange(n + n_arr + 5)                       # capacity beyond n
+        arrivals = torch.arange(1000, 1000 + n_arr)
+        n_new, arr_dst, mv_src, mv_dst = fill_holes(n, leaving, n_arr)
+        assert n_new == n - n_leave + n_arr
+        if mv_src.numel():
+            vals[mv_dst] = vals[mv_src]
+        if n_arr:
+            vals[arr_dst] = arrivals
+        got = sorted(vals[:n_new].tolist())
+        want = sorted(torch.arange(n)[~leaving].tolist() + arrivals.tolist())
+        assert got == want
