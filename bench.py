@@ -47,6 +47,23 @@ def algorithmic_bytes(C, K):
     }
 
 
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v2_pmc_traffic_per_kernel_avg.json')
+PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
+             'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
+
+
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
+    command (profiles/README.md): (FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE under-counts wide coalesced
+    streams by 2x on gfx950 (applied to the diffusion sweep only); None if the file is absent."""
+    try:
+        c = json.load(open(PMC_FILE))[PMC_NAMES[kernel]]
+        fetch = c['FETCH_SIZE'] * (2 if kernel == 'k_diffuse_rows_fused' else 1)
+        return int((fetch + c['WRITE_SIZE']) * 1024)
+    except Exception:
+        return None
+
+
 def time_kernels(env, agent, reps):
     """Average launch duration (µs) of each kernel of the step, HIP events on the launch stream."""
     import torch
@@ -197,7 +214,8 @@ def main():
         ach = B[dom] / (kt[dom] * 1e-6) / 1e9
         line['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom),
+            'traffic_source': 'profiles/r01_v2_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},

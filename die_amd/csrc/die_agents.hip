@@ -227,7 +227,10 @@ static int agent_grid(int64_t N) {
 static int fwd_grid(int64_t N) {
     const int64_t chunk = (int64_t)DIE_BLOCK * DIE_FWD_UNROLL;
     int64_t g = (N + chunk - 1) / chunk;
-    const int64_t cap = 256 * 16;
+#ifndef DIE_FWD_GRID_CAP
+#define DIE_FWD_GRID_CAP (256 * 16)
+#endif
+    const int64_t cap = DIE_FWD_GRID_CAP;
     return (int)(g < cap ? (g > 0 ? g : 1) : cap);
 }
 
