@@ -490,6 +490,70 @@ def test_results_do_not_depend_on_agent_order(die, sort_every):
     assert np.allclose(runs[0][4], runs[1][4], rtol=1e-12, atol=1e-12)
 
 
+def test_f16_field_channels_step_parity(die):
+    """BASELINE configs[4] keeps the field channels in fp16: same kernels, half-precision planes.
+    Index work stays exact; fields agree with the float64 oracle to fp16 resolution."""
+    W, H, N, K = 128, 64, 3000, 2500
+    rs = np.random.RandomState(77)
+    medium, agents = random_state(W, H, N, K, rs)
+    medium[1] = medium[1].astype(np.float16).astype(np.float64)
+    medium[2] = medium[2].astype(np.float16).astype(np.float64)
+    kw = dict(scale=1.53 / (W - 1), sense_offset=5.2 / (W - 1), sense_angle=100)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    ref_env = R.RefEnv(medium, agents)
+    ref_agent = R.RefPhysarumAgent(N, seed=3, **kw)
+    ref_agent._direction_rads = dir0.copy()
+    env = die.Env.from_numpy(medium, agents, field_dtype=torch.float16)
+    assert env.medium.chem.dtype == torch.float16
+    agent = die.PhysarumAgent(max_agents=N, seed=3, **kw)
+    agent.set_state(dir0)
+    action = agent.forward(env._get_current_obs)
+    want_action = ref_agent.forward(ref_env.obs)
+    got_action = action.to_numpy()
+    assert np.mean(~np.isclose(got_action, want_action, rtol=RTOL, atol=4e-7 * kw['scale'])) < 2e-3
+    _, reward, _, _, info = env.step(action)
+    _, want_reward, _, _, want_info = ref_env.step(got_action)
+    m, a = env.medium.to_numpy(), env.agents.to_numpy()
+    # the oracle moved by the float64 value of the fp32 action, the device by its Q0.32 rounding
+    assert np.abs(a[:2] - ref_env.agents[:2]).max() <= 2.0 ** -32 and np.array_equal(a[2], ref_env.agents[2])
+    assert (m[0] != ref_env.medium[0]).mean() <= 1e-3
+    assert info['num_agents'] == want_info['num_agents']
+    # fp16 planes: 11-bit significand → 5e-4 relative, plus half an ulp of the smallest normal range used
+    assert np.allclose(m[1], ref_env.medium[1], rtol=1e-3, atol=1e-4)
+    assert np.allclose(m[2], ref_env.medium[2], rtol=2e-3, atol=2e-4)
+    assert np.allclose(a[3], ref_env.agents[3], rtol=1e-4, atol=1e-5)
+    assert abs(reward - want_reward) <= 1e-4 * np.abs(ref_env.last_gained).sum() + 1e-6
+
+
+def test_brownian_256_config1_free_run(die):
+    """BASELINE configs[0]: BrownianAgent, 256x256, 300 steps (examples/minimal_run.py) — seeded
+    Philox uniforms on both sides, so the whole run is reproducible against the oracle: agents
+    bit-exact is not expected (fp32 action vs float64), cells and fields must stay close."""
+    W = H = 256
+    medium, agents = R.synthetic_init(W, H, 0.05, seed=11)
+    medium[1] = f32(medium[1])
+    agents[:2] = q32(agents[:2])
+    agents[3] = f32(agents[3])
+    N = agents.shape[1]
+    ref_env, ref_agent = R.RefEnv(medium, agents), R.RefBrownianAgent(move_scale=0.01, deposit_scale=0.5, seed=4)
+    env = die.Env.from_numpy(medium, agents)
+    agent = die.BrownianAgent(move_scale=0.01, deposit_scale=0.5, seed=4)
+    obs, robs = env._get_current_obs, ref_env.obs
+    tot = rtot = 0.0
+    for _ in range(300):
+        obs, rew, *_ = env.step(agent.forward(obs))
+        robs, rrew, *_ = ref_env.step(ref_agent.forward(robs))
+        tot, rtot = tot + rew, rtot + rrew
+    a, m = env.agents.to_numpy(), env.medium.to_numpy()
+    K = int(agents[2].sum())
+    same = (R.cell(a[0, :K], W) == R.cell(ref_env.agents[0, :K], W)) & (R.cell(a[1, :K], H) == R.cell(ref_env.agents[1, :K], H))
+    assert same.mean() >= 0.995                     # Brownian decisions have no thresholds: only Q0.32 rounding of dx
+    assert np.abs(m[2] - ref_env.medium[2]).sum() <= 0.02 * np.abs(ref_env.medium[2]).sum()
+    assert np.isclose(m[1].sum(), ref_env.medium[1].sum(), rtol=1e-3)
+    assert np.isclose(tot, rtot, rtol=1e-3, atol=1e-2)
+
+
 # ------------------------------------------------------------------------------------ data_init
 @pytest.mark.parametrize('W,H,ratio', [(16, 12, 0.15), (64, 64, 0.05), (300, 200, 0.15), (1024, 1024, 0.15)])
 def test_init_parity(die, W, H, ratio):
