@@ -197,7 +197,7 @@ class DistEnv:
 
     def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], dynamics=None, *, probe_reach: int,
                  capacity: Optional[int] = None, device=None, group=None, field_dtype=torch.float32,
-                 seed: int = 0, init: bool = True, sort_every: int = 8):
+                 seed: int = 0, init: bool = True, sort_every: int = 8, overlap: bool = True):
         from . import _lib
         from .data_init import DataInitializer
         from .device_array import DeviceAgents, DeviceMedium
@@ -217,10 +217,15 @@ class DistEnv:
         self.medium.world = (g.gW, g.gH, g.ox, g.oy)
         self._seed = int(seed)
         self._sort_every = int(sort_every)
+        self._overlap = bool(overlap)
         self._steps = 0
         self.capacity = int(capacity) if capacity else None
         self.agents = None
         self.last_result = None
+        # second HIP stream: the chem halo of the NEXT sweep is exchanged while forward / move /
+        # migration / claims of the next step run on the compute stream
+        self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
+        self._chem_halo_in_flight = False
         if init:
             self._init_tile()
 
@@ -355,6 +360,18 @@ class DistEnv:
         A.N = n_new
         action.N = n_new
 
+    def _start_chem_halo(self):
+        """chem is final until the next sweep: start its halo exchange on the comm stream now.  The
+        forward pass that runs meanwhile only reads halo cells whose redundantly diffused values equal
+        the incoming ones bit for bit (same kernel, same inputs), so the overlap is race-free in value."""
+        if self._comm_stream is None:
+            halo_exchange([self.medium.chem], self.geo, self.comm)
+        else:
+            self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._comm_stream):
+                halo_exchange([self.medium.chem], self.geo, self.comm)
+        self._chem_halo_in_flight = True
+
     def step(self, action):
         """One decomposed env step.  Returns (obs, result_tensor): result is the LOCAL
         die_step_result; `read_result` all-reduces it."""
@@ -385,7 +402,13 @@ class DistEnv:
                 result.view(torch.int64)[1] = A.N
         # the field sweep applies deposits on load, so it needs chem AND claims of the halo
         M = self.medium
-        halo_exchange([M.chem, M.owner], g, self.comm)
+        if self._chem_halo_in_flight:
+            if self._comm_stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+            self._chem_halo_in_flight = False
+            halo_exchange([M.owner], g, self.comm)
+        else:
+            halo_exchange([M.chem, M.owner], g, self.comm)
         m = M.c_struct()
         lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), g.h, sp),
                   'die_medium_deposit_feed_diffuse_tile')
@@ -393,6 +416,8 @@ class DistEnv:
         self._steps += 1
         if self._sort_every > 0 and self._steps % self._sort_every == 0 and A.N > 1:
             self.sort_agents()
+        if self._overlap:
+            self._start_chem_halo()
         self.last_result = result
         return self._get_current_obs, result
 

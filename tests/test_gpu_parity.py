@@ -356,6 +356,28 @@ def test_fused_step_equals_staged_step(die, W, H, N, K):
     assert np.array_equal(outs[0][1], outs[1][1])
 
 
+def test_alternative_claim_and_staged_paths_give_identical_results(die, monkeypatch):
+    """Switchable code paths of die_env_step — claim by plain store + repair pass (DIE_STORE_CLAIM)
+    and the un-fused stage sequence (DIE_NO_FUSED_STEP) — must reproduce the default path's bits."""
+    W, H, N, K = 96, 64, 6000, 5000
+    rs = np.random.RandomState(31)
+    medium, agents = random_state(W, H, N, K, rs, collide=0.5)      # many shared cells
+    action = quantised_action(N, rs, 3.0 / W)
+    outs = []
+    for var in (None, 'DIE_STORE_CLAIM', 'DIE_NO_FUSED_STEP'):
+        if var:
+            monkeypatch.setenv(var, '1')
+        env = die.Env.from_numpy(medium, agents, sort_every=0)
+        for _ in range(3):
+            env.step(action)
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), env.medium.owner_slots().cpu().numpy()))
+        if var:
+            monkeypatch.delenv(var)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
 def test_step_kat_collisions_and_dead_slots(die):
     """Hand-checkable case (tests/test_oracle_kat.py): last writer wins, feed duplication,
     dead slot on an occupied cell consumes, reward counts every slot."""
