@@ -38,10 +38,14 @@ def parse():
 
 
 def algorithmic_bytes(C, K):
-    """DESIGN.md §5 / SURVEY.md §8(d), fp32 fields: B = 12·C + 104·K per env step, split by kernel."""
+    """DESIGN.md §5 / SURVEY.md §8(d), fp32 fields: B = 12·C + 104·K per env step; per kernel, what an ideal
+    version of that kernel has to move."""
     return {
-        'k_gradient_forward': 48 * K,     # x,y,heading R 12 + heading W 4 + action W 12 + 5 gathers 20
-        'k_move_claim': 44 * K,           # x,y RW 16 + agent_food RW 8 + action R 12 + food gather 4 + claim 4
+        # fused forward + move + claim + feed: x,y R+W 16, heading R+W 8, agent_food R+W 8, action W 12,
+        # 6 gathers (4 chem taps, food at old and new cell) 24, claim 4
+        'k_forward_move_claim': 72 * K,
+        'k_gradient_forward': 48 * K,     # stand-alone forward: x,y,heading R 12 + heading W 4 + action W 12 + 5 gathers 20
+        'k_move_claim': 44 * K,           # stand-alone: x,y RW 16 + agent_food RW 8 + action R 12 + food gather 4 + claim 4
         'k_diffuse_rows_fused': 8 * C + 20 * K,   # chem R + W per cell; per agent chem RMW 8 + food RMW 8 + mark 4
         'step': 12 * C + 104 * K,
     }
@@ -49,6 +53,7 @@ def algorithmic_bytes(C, K):
 
 PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v2_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
+             'k_forward_move_claim': 'void k_forward_move_claim<float, 1>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
 
 
@@ -82,14 +87,18 @@ def time_kernels(env, agent, reps):
 
     env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
     obs = env._get_current_obs
-    action = agent.forward(obs)
-    out['k_gradient_forward'] = timed(lambda: agent.forward(obs))
+    sort_every, env._sort_every = env._sort_every, 0
 
-    def move():
-        env.medium.next_epoch()
-        env._stage('die_agent_move_claim', action)
-    out['k_move_claim'] = timed(move)
+    def whole():
+        env.step(agent.forward(obs))
+    t_step = timed(whole)                 # k_forward_move_claim + k_reduce + k_diffuse_rows<fused>
+    action = agent.forward(obs)
+    action.ensure()
+    env.medium.next_epoch()
+    env._stage('die_agent_move_claim', action)
     out['k_diffuse_rows_fused'] = timed(env._medium_deposit_feed_diffuse)
+    out['k_forward_move_claim'] = t_step - out['k_diffuse_rows_fused']      # includes k_reduce (≈ 5 µs)
+    env._sort_every = sort_every
     return out
 
 

@@ -17,7 +17,7 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class Medium(C.Structure):
@@ -67,6 +67,8 @@ _SIGNATURES = {
     'die_const_forward': (C.c_int, [C.c_int64, C.c_float, C.c_float, C.c_float, _P(Action), C.c_void_p]),
     'die_env_step': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64,
                                C.c_void_p]),
+    'die_forward_env_step': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
+                                       C.c_void_p, C.c_int64, C.c_void_p]),
     'die_agent_move_claim': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                        C.c_void_p]),
     'die_agent_move': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

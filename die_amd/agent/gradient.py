@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..device_array import DeviceAction, _ptr, stream_ptr
+from ..device_array import DeviceAction, PendingAction, _ptr, stream_ptr
 from .base import Agent, save_args
 
 
@@ -47,6 +47,8 @@ class GradientAgent(Agent):
         self._prev_grad: Optional[torch.Tensor] = None
         self._turn_sign: Optional[torch.Tensor] = None            # test hook: per-slot ±1 instead of Philox
         self._order: Optional[torch.Tensor] = None                # slot tensor the state arrays are aligned with
+        self._pending = None                                      # forward() whose kernel has not run yet
+        self.lazy = True                                          # let Env.step fuse forward with the step
 
     @property
     def init_params(self) -> Dict[str, Any]:
@@ -132,8 +134,8 @@ class GradientAgent(Agent):
             else:
                 self._align_to(agents.slot)
         agents.attach(self)
-        action = DeviceAction(agents.N, dev, agents.slot, capacity=agents.capacity)
-        action.global_slots = agents.global_slots
+        if self._pending is not None:               # keep heading updates in call order
+            self._pending.ensure()
         pg = self._prev_grad
         g = _lib.GradientAgent(
             self._kind, int(bool(self._normalized)), self._scale, self._deposit, self._inertia,
@@ -141,11 +143,27 @@ class GradientAgent(Agent):
             self._turn_radians, self._sense_radians, self._rtol, 0, _ptr(self._direction_rads),
             _ptr(pg[0]) if pg is not None else None, _ptr(pg[1]) if pg is not None else None,
             _ptr(self._turn_sign), self._seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF, 0)
-        m, a, u = medium.c_struct(), agents.c_struct(), action.c_struct()
-        _lib.check(_lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(g), C.byref(u), stream_ptr(dev)),
-                   'die_gradient_forward')
         self._calls += 1
+        action = PendingAction(self, agents, medium, g, (self._direction_rads, pg, self._turn_sign))
+        self._pending = action
+        if not self.lazy:
+            action.ensure()
         return action
+
+    def _run_forward(self, action):
+        """Launch the stand-alone forward kernel for a pending action."""
+        if self._pending is action:
+            self._pending = None
+        agents, medium = action.agents, action.medium
+        m, a, u = medium.c_struct(), agents.c_struct(), action.raw_struct()
+        _lib.check(_lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u),
+                                                 stream_ptr(agents.device)), 'die_gradient_forward')
+
+    def _forward_consumed(self, action):
+        """Env.step ran this action's forward inside die_forward_env_step."""
+        if self._pending is action:
+            self._pending = None
+        action.done()
 
     def render(self) -> Sequence[np.ndarray]:
         return [np.ones((1, 1, 3))]

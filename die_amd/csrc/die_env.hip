@@ -12,7 +12,7 @@
 // consumption (co-located agents each get the full amount, :224-225), so all reads of `food`
 // (pass 1) are separated from the single write per occupied cell (pass 2) by a kernel boundary.
 // "Last writer wins" of the fancy-index assignment at :211 is an atomicMax on the slot id.
-#include "die_common.h"
+#include "die_forward.h"
 #include <stdlib.h>
 
 #define DIE_MAX_PARTIALS 8192
@@ -66,58 +66,79 @@ __device__ __forceinline__ void block_sum_store(double g, long long c, double* p
     }
 }
 
+// One slot of _agent_move + claim + _agent_feed (alive slots); returns its `gained` (0 for dead slots).
 template <typename T>
-__global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
+__device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t n, uint32_t X, uint32_t Y, const float dx,
+                                                const float dy, const float dep, const uint32_t sid) {
     const T* food = (const T*)a.food;
     const die_geo g = a.g;
+    if (a.do_move) {
+        if (a.boundary == DIE_BOUNDARY_WRAP) {            // (xy + dxdy) % 1.
+            X += (uint32_t)die_q32(dx);
+            Y += (uint32_t)die_q32(dy);
+        } else {                                          // clip(0, 1); 1.0 is held as 2^32 − 1
+            int64_t px = (int64_t)X + die_q32(dx), py = (int64_t)Y + die_q32(dy);
+            X = (uint32_t)(px < 0 ? 0 : (px > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : px));
+            Y = (uint32_t)(py < 0 ? 0 : (py > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : py));
+        }
+        a.x[n] = X;
+        a.y[n] = Y;
+    }
+    const int cx = die_cell((int64_t)X, g.gW), cy = die_cell((int64_t)Y, g.gH);
+    if (a.tile_of) a.tile_of[n] = (cx / a.tile_w) * a.tiles_y + cy / a.tile_h;
+    if (!a.do_claim) return 0.f;
+    const int64_t c = die_local(g, cx, cy);
+#ifndef DIE_ABL_NOFOODG
+    const float consumed = a.rate_feed * die_ld(food, c);
+#else
+    const float consumed = a.rate_feed * (float)c;
+#endif
+    if (a.alive[n]) {
+        // Claim: one 64-bit atomicMax (≈ 58 µs per 2.5 M agents).  claim_by_store: plain store now
+        // (≈ 21 µs) and k_claim_fix raises the word to the maximum afterwards (≈ 38 µs) — measured, no gain.
+        const unsigned long long key = die_claim(a.epoch, (int64_t)sid, dep);
+#ifndef DIE_ABL_NOCLAIM
+        if (a.claim_by_store) a.owner[c] = key;
+        else atomicMax(&a.owner[c], key);
+#else
+        if (key == 12345ull) a.owner[c] = key;
+#endif
+        const float gained = consumed - action_cost(a, dx, dy, dep);
+#ifndef DIE_ABL_NOAF
+        a.agent_food[n] += gained;
+#endif
+        return gained;
+    }
+    if (a.has_dead) a.stash[n] = consumed;
+    return 0.f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
     double gsum = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
-        const float dx = a.dx[n], dy = a.dy[n];
-        uint32_t X = a.x[n], Y = a.y[n];
-        if (a.do_move) {
-            if (a.boundary == DIE_BOUNDARY_WRAP) {            // (xy + dxdy) % 1.
-                X += (uint32_t)die_q32(dx);
-                Y += (uint32_t)die_q32(dy);
-            } else {                                          // clip(0, 1); 1.0 is held as 2^32 − 1
-                int64_t px = (int64_t)X + die_q32(dx), py = (int64_t)Y + die_q32(dy);
-                X = (uint32_t)(px < 0 ? 0 : (px > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : px));
-                Y = (uint32_t)(py < 0 ? 0 : (py > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : py));
-            }
-            a.x[n] = X;
-            a.y[n] = Y;
-        }
-        const int cx = die_cell((int64_t)X, g.gW), cy = die_cell((int64_t)Y, g.gH);
-        if (a.tile_of) a.tile_of[n] = (cx / a.tile_w) * a.tiles_y + cy / a.tile_h;
-        if (!a.do_claim) continue;
-        const int64_t c = die_local(g, cx, cy);
-#ifndef DIE_ABL_NOFOODG
-        const float consumed = a.rate_feed * die_ld(food, c);
-#else
-        const float consumed = a.rate_feed * (float)c;
-#endif
-        if (a.alive[n]) {
-            // Claim.  A 64-bit atomicMax per agent costs ≈ 80 µs per 2.5 M agents on this chip, a plain
-            // 8-byte store ≈ 24 µs: store now (some claimant of this step survives), and let
-            // k_claim_fix raise the word to the maximum — only agents that lost to a LOWER slot
-            // (≈ half of the ≈ 7 % that share a cell) issue an atomic there.
-            const unsigned long long key = die_claim(a.epoch, a.slot ? (int64_t)a.slot[n] : n, a.dep[n]);
-#ifndef DIE_ABL_NOCLAIM
-            if (a.claim_by_store) a.owner[c] = key;
-            else atomicMax(&a.owner[c], key);
-#else
-            if (key == 12345ull) a.owner[c] = key;
-#endif
-            const float gained = consumed - action_cost(a, dx, dy, a.dep[n]);
-#ifndef DIE_ABL_NOAF
-            a.agent_food[n] += gained;
-#endif
-            gsum += (double)gained;
-        } else if (a.has_dead) {
-            a.stash[n] = consumed;
-        }
+        const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
+        gsum += (double)move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid);
     }
     if (a.do_claim) block_sum_store(gsum, 0, a.part_gain, nullptr);
+}
+
+// Agent.forward fused with the first half of Env.step: the action stays in registers between the two
+// (it is still written out for the caller, but never read back), x / y / slot are loaded once.
+template <typename T, int KIND>
+__global__ __launch_bounds__(DIE_BLOCK) void k_forward_move_claim(FwdArgs f, StepArgs a) {
+    double gsum = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
+        const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
+        const uint32_t X = a.x[n], Y = a.y[n];
+        const FwdOut o = die_forward_agent<T, KIND>(f, X, Y, f.heading[n], sid, n);
+        f.heading[n] = o.heading;
+        if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
+        gsum += (double)move_claim_one<T>(a, n, X, Y, o.dx, o.dy, o.dep, sid);
+    }
+    block_sum_store(gsum, 0, a.part_gain, nullptr);
 }
 
 // Second half of the claim: raise every cell's word to the maximum over its claimants.
@@ -622,53 +643,80 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
 }
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream, const char* who);
+extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                                    void* ws, int64_t ws_bytes, void* stream);
 
-// winner-independent remainder of k_resolve: dead slots, lifecycle, alive count (fused path only
-// launches it when such slots can exist)
+static bool fused_step_applies(const die_medium* m, const die_dynamics* d) {
+    const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
+    return m->gW <= 0 && rows_kernel_applies(m->W, m->H, R) && R >= 1 && !getenv("DIE_NO_FUSED_STEP");
+}
+
+// everything of die_env_step after the claims are in place (fused path)
+static int env_step_tail(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                         die_step_result* result, void* ws, int64_t ws_bytes, void* stream) {
+    // deposits and feeding ride on the diffusion sweep; the per-agent second pass is only needed for
+    // dead slots / lifecycle (it then skips the winner's scatter)
+    const bool second_pass = d->has_dead_slots || d->agents_die;
+    if (second_pass) {
+        int rc = die_agent_dead_slots(m, a, act, d, ws, ws_bytes, stream);
+        if (rc != DIE_OK) return rc;
+    }
+    const int g = step_grid(a->N);
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
+                                                  second_pass ? g : 0,
+                                                  (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
+                                                  second_pass ? g : 0, result, second_pass ? -1 : a->N);
+    DIE_CHECK_LAUNCH("die_env_step(reduce)");
+    return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed)");
+}
+
 extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                             die_step_result* result, void* ws, int64_t ws_bytes, void* stream) {
     DIE_REQUIRE(m && a && act && d && result, "die_env_step: null argument");
     DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_env_step: chem_next must be a second plane");
     int rc = die_agent_move_claim(m, a, act, d, ws, ws_bytes, stream);
     if (rc != DIE_OK) return rc;
-    const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    const bool fused = m->gW <= 0 && rows_kernel_applies(m->W, m->H, R) && R >= 1 && !getenv("DIE_NO_FUSED_STEP");
-    if (!fused) {
-        rc = die_agent_resolve(m, a, act, d, ws, ws_bytes, stream);
-        if (rc != DIE_OK) return rc;
-        rc = die_step_reduce(a, d, result, ws, ws_bytes, stream);
-        if (rc != DIE_OK) return rc;
-            if (m->gW > 0) {
-            die_set_error("die_env_step: a decomposed tile needs halo exchange and migration between the stages; "
-                          "drive die_agent_move / die_agent_claim_feed / die_agent_resolve / die_diffuse_decay_tile instead");
-            return DIE_ERR_UNSUPPORTED;
-        }
-        return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
+    if (fused_step_applies(m, d)) return env_step_tail(m, a, act, d, result, ws, ws_bytes, stream);
+    rc = die_agent_resolve(m, a, act, d, ws, ws_bytes, stream);
+    if (rc != DIE_OK) return rc;
+    rc = die_step_reduce(a, d, result, ws, ws_bytes, stream);
+    if (rc != DIE_OK) return rc;
+    if (m->gW > 0) {
+        die_set_error("die_env_step: a decomposed tile needs halo exchange and migration between the stages; "
+                      "drive die_agent_move / die_agent_claim_feed / die_medium_deposit_feed_diffuse_tile instead");
+        return DIE_ERR_UNSUPPORTED;
     }
-    // fused path: deposits and feeding ride on the diffusion sweep; the per-agent second pass is only
-    // needed for dead slots / lifecycle (it then skips the winner's scatter)
-    const bool second_pass = d->has_dead_slots || d->agents_die;
-    if (second_pass) {
-        StepArgs k;
-        rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_env_step");
-        if (rc != DIE_OK) return rc;
-        k.part_gain = (double*)ws + DIE_MAX_PARTIALS;
-        k.part_alive = (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS);
-        k.skip_scatter = 1;
-        const int grid = step_grid(a->N);
-        if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
-        else k_resolve<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
-        DIE_CHECK_LAUNCH("die_env_step(dead slots)");
+    return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
+}
+
+extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                    const die_dynamics* d, die_step_result* result, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+    DIE_REQUIRE(m && a && g && act && d && result, "die_forward_env_step: null argument");
+    DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_forward_env_step: chem_next must be a second plane");
+    if (!fused_step_applies(m, d)) {
+        die_set_error("die_forward_env_step: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+        return DIE_ERR_UNSUPPORTED;
     }
-    {
-        const int g = step_grid(a->N);
-        k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
-                                                      second_pass ? g : 0,
-                                                      (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
-                                                      second_pass ? g : 0, result, second_pass ? -1 : a->N);
-        DIE_CHECK_LAUNCH("die_env_step(reduce)");
+    FwdArgs f;
+    int rc = die_fill_fwd_args(f, m, a, g, act, "die_forward_env_step");
+    if (rc != DIE_OK) return rc;
+    StepArgs k;
+    rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_forward_env_step");
+    if (rc != DIE_OK) return rc;
+    k.part_gain = (double*)ws;
+    const int grid = step_grid(a->N);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->dtype == DIE_F32) {
+        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim<float, DIE_AGENT_PHYSARUM><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+        else k_forward_move_claim<float, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+    } else {
+        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim<__half, DIE_AGENT_PHYSARUM><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+        else k_forward_move_claim<__half, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
     }
-    return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed)");
+    if (k.claim_by_store) k_claim_fix<<<grid, DIE_BLOCK, 0, s>>>(k);
+    DIE_CHECK_LAUNCH("die_forward_env_step");
+    return env_step_tail(m, a, act, d, result, ws, ws_bytes, stream);
 }
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream,

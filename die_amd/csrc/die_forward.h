@@ -1,0 +1,163 @@
+// GradientAgent / PhysarumAgent forward() for ONE agent slot (core/agent/gradient.py:96-124,
+// 168-219), shared by k_gradient_forward (die_agents.hip) and the fused k_forward_move_claim
+// (die_env.hip).
+#pragma once
+#include "die_common.h"
+#include "die_rng.h"
+
+struct FwdArgs {
+    die_geo g;
+    int64_t N;
+    const void* chem;
+    const void* food;
+    const uint32_t* x;
+    const uint32_t* y;
+    const uint32_t* slot;
+    float* heading;
+    float* pgx;
+    float* pgy;
+    const int8_t* turn_sign;
+    float* dx;
+    float* dy;
+    float* dep;
+    float scale, deposit, inertia, sense_offset, noise_scale, grad_clip, turn_rad, sense_rad, rtol;
+    int normalized;
+    uint64_t seed;
+    uint32_t step;
+};
+
+#define DIE_PI_F 3.14159265358979323846f
+#define DIE_2PI_F 6.28318530717958647692f
+
+// sin/cos for |x| ≤ ~2π (headings live in (−π, π]): Cody–Waite reduction by π/2 and the
+// cephes single-precision minimax polynomials; ≤ 1.5 ulp, branch-free, ~30 VALU — the
+// library sincosf carries a large-argument path this kernel can never take.
+__device__ __forceinline__ void die_sincos(float x, float* s, float* c) {
+    const float k = rintf(x * 0.636619772367581343f);        // x / (π/2)
+    const int q = (int)k;
+    float r = fmaf(k, -1.5703125f, x);                        // π/2 split in three parts
+    r = fmaf(k, -4.837512969970703125e-4f, r);
+    r = fmaf(k, -7.549789948768648e-8f, r);
+    const float z = r * r;
+    float ps = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    ps = fmaf(ps * z, r, r);
+    float pc = fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+    pc = fmaf(pc * z, z, fmaf(-0.5f, z, 1.0f));
+    const float ss = (q & 1) ? pc : ps;
+    const float cc = (q & 1) ? ps : pc;
+    *s = (q & 2) ? -ss : ss;
+    *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+// core/utils.py:178-180 for |r| < 3π: into (-π, π]
+__device__ __forceinline__ float renorm_rad(float r) {
+    if (r > DIE_PI_F) r -= DIE_2PI_F;
+    if (r <= -DIE_PI_F) r += DIE_2PI_F;
+    return r;
+}
+
+struct FwdOut {
+    float dx, dy, dep, heading;
+};
+
+// Reads the 4 chem taps around the probe cell and the food under the agent, decides the turn,
+// applies momentum, updates _prev_grad in place (when kept) and returns heading' and the action.
+template <typename T, int KIND>
+__device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint32_t X, const uint32_t Y, const float d,
+                                                   const uint32_t sid, const int64_t n) {
+    const T* chem = (const T*)a.chem;
+    const T* food = (const T*)a.food;
+    const die_geo g = a.g;
+    const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
+    float sd, cd;
+    die_sincos(d, &sd, &cd);
+    // probe cell: agents + sense_offset·(cos d, sin d), nearest label, clamped (gradient.py:73-76,105)
+    const int px = die_cell((int64_t)X + die_q32(a.sense_offset * cd), W);
+    const int py = die_cell((int64_t)Y + die_q32(a.sense_offset * sd), H);
+    // np.gradient at the probe cell: central inside, one-sided at the four edges (gradient.py:57)
+    const int xm = px > 0 ? px - 1 : 0, xp = px < W - 1 ? px + 1 : W - 1;
+    const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;
+#ifdef DIE_ABL_NOGATHER
+    const float cxm = (float)xm, cxp = (float)xp * 1.5f, cym = (float)ym, cyp = (float)(yp + py);
+#else
+    const float cxm = die_ld(chem, die_local(g, xm, py)), cxp = die_ld(chem, die_local(g, xp, py));
+    const float cym = die_ld(chem, die_local(g, px, ym)), cyp = die_ld(chem, die_local(g, px, yp));
+#endif
+    // food under the agent (gradient.py:114-116)
+    const int cx = die_cell((int64_t)X, W), cy = die_cell((int64_t)Y, H);
+#ifdef DIE_ABL_NOFOOD
+    const float f_own = (float)(cx + cy);
+#else
+    const float f_own = die_ld(food, die_local(g, cx, cy));
+#endif
+    const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
+    const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
+    const float norm = sqrtf(gx * gx + gy * gy);
+    float ux = gx, uy = gy;
+    if (a.normalized) {                       // g / |g| with 0/0 → 0 (gradient.py:60-63)
+        ux = norm > 0.f ? gx / norm : 0.f;
+        uy = norm > 0.f ? gy / norm : 0.f;
+    }
+    if (a.grad_clip >= 0.f && !(norm >= a.grad_clip)) ux = uy = 0.f;   // gradient.py:64-66
+
+    float d_new = d;
+    float dep_mask = 1.0f;
+    bool heading_from_vector = true;
+    if (KIND == DIE_AGENT_PHYSARUM) {
+        // _discrete_turn / _choose_turn (gradient.py:168-208)
+        const float dr = sqrtf(ux * ux + uy * uy);
+        const float drads = atan2f(uy, ux);
+        const float delta = renorm_rad(d - drads);
+        const float atol = a.turn_rad * a.rtol;
+        const bool und_grad = fabsf(drads) <= 1e-8f + 1e-5f * fabsf(drads);
+        const bool und_turn = fabsf(delta) <= atol + 1e-2f * fabsf(delta);
+        const bool unseen = fabsf(delta) > a.sense_rad;
+        const bool und = und_grad || und_turn || unseen;
+        float sgn;
+        if (und) {
+            if (a.turn_sign) sgn = (float)a.turn_sign[sid];
+            else sgn = (die_draw(a.seed, a.step, (uint64_t)sid, DIE_STREAM_TURN).v[0] & 1u) ? 1.f : -1.f;
+        } else {
+            sgn = delta > atol ? -1.f : 1.f;  // right (clockwise) / left
+        }
+        const float d2 = renorm_rad(d + sgn * a.turn_rad);
+        float s2, c2;
+        die_sincos(d2, &s2, &c2);
+        const float r = a.normalized ? 1.f : dr;
+        ux = r * c2;
+        uy = r * s2;
+        dep_mask = (und_grad || und_turn) ? 0.1f : 1.0f;   // clip(mask, .1, 1) (gradient.py:210-214)
+        d_new = d2;
+        heading_from_vector = !a.normalized;               // |g| may be 0 there: angle(0) = 0
+    }
+    // _process_momentum (gradient.py:82-91)
+    if (a.inertia != 0.f || a.noise_scale != 0.f) {
+        float nx = 0.f, ny = 0.f;
+        if (a.noise_scale != 0.f) {
+            const die_u32x4 r = die_draw(a.seed, a.step, (uint64_t)sid, DIE_STREAM_NOISE);
+            const float u1 = ((float)r.v[0] + 1.0f) * 2.3283064365386963e-10f;
+            const float u2 = (float)r.v[1] * 2.3283064365386963e-10f;
+            const float rad = 0.4f * sqrtf(-2.0f * logf(u1));
+            float sn, cn;
+            sincosf(DIE_2PI_F * u2, &sn, &cn);
+            nx = rad * cn;
+            ny = rad * sn;
+        }
+        const float ox = a.pgx ? a.pgx[n] : 0.f, oy = a.pgy ? a.pgy[n] : 0.f;
+        ux = (1.f - a.inertia) * ux + a.inertia * ox + a.noise_scale * nx;
+        uy = (1.f - a.inertia) * uy + a.inertia * oy + a.noise_scale * ny;
+        heading_from_vector = true;
+    }
+    if (a.pgx) { a.pgx[n] = ux; a.pgy[n] = uy; }
+    if (heading_from_vector) d_new = atan2f(uy, ux);          // get_radians (gradient.py:110)
+    FwdOut o;
+    o.heading = d_new;
+    o.dx = ux * a.scale;
+    o.dy = uy * a.scale;
+    o.dep = a.deposit * f_own * dep_mask;
+    return o;
+}
+
+// host side: validate and fill FwdArgs (shared by die_gradient_forward and die_forward_env_step)
+int die_fill_fwd_args(FwdArgs& k, const die_medium* m, const die_agents* a, const die_gradient_agent* g,
+                      const die_action* out, const char* who);

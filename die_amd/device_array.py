@@ -233,3 +233,40 @@ class DeviceAction:
         a = DeviceAction(action.shape[1], device, None)
         a.data.copy_(torch.from_numpy(np.ascontiguousarray(action, dtype=np.float32)))
         return a.in_order_of(slot)
+
+
+class PendingAction(DeviceAction):
+    """The action of a GradientAgent/PhysarumAgent.forward() call whose kernel has not run yet.
+
+    `Env.step` recognises it and runs forward fused with the first half of the step
+    (die_forward_env_step); any other use — `to_numpy()`, `sel()`, handing it to another Env, a second
+    `forward()` on the same agent — first runs the stand-alone forward kernel.  Either way the arrays
+    hold the same values afterwards."""
+
+    def __init__(self, agent, agents, medium, g_struct, keepalive):
+        N = agents.N
+        self.N, self.device = N, agents.device
+        self._data = torch.empty((3, agents.capacity), dtype=torch.float32, device=agents.device)
+        self.slot = agents.slot
+        self.global_slots = agents.global_slots
+        self.agent, self.agents, self.medium = agent, agents, medium
+        self.g_struct, self._keepalive = g_struct, keepalive
+        self.pending = True
+
+    @property
+    def data(self):
+        self.ensure()
+        return self._data
+
+    def raw_struct(self) -> _lib.Action:
+        """Pointers of the (possibly still unfilled) arrays, without forcing the forward kernel."""
+        d = self._data
+        return _lib.Action(self.N, _ptr(d[0]), _ptr(d[1]), _ptr(d[2]))
+
+    def ensure(self):
+        if self.pending:
+            self.pending = False
+            self.agent._run_forward(self)
+
+    def done(self):
+        self.pending = False

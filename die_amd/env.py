@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from .data_init import DataInitializer
-from .device_array import DeviceAction, DeviceAgents, DeviceMedium, _ptr, stream_ptr
+from .device_array import DeviceAction, DeviceAgents, DeviceMedium, PendingAction, _ptr, stream_ptr
 
 try:                                    # the reference subclasses gym.Env but defines no spaces
     import gymnasium as _gym
@@ -116,6 +116,7 @@ class Env(_EnvBase):
         self._steps = 0
         self._shadow = None
         self._sort_ws = None
+        self._fuse_forward = True
 
     @classmethod
     def from_numpy(cls, medium: np.ndarray, agents: np.ndarray, dynamics: Optional[Dynamics] = None, **kw) -> 'Env':
@@ -175,13 +176,30 @@ class Env(_EnvBase):
 
     def step(self, action):
         """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
-        act = self._as_action(action)
-        self.medium.next_epoch()
         result = torch.empty(2, dtype=torch.float64, device=self.device)
-        m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), act.c_struct(), self._c_dynamics()
-        _lib.check(_lib.lib.die_env_step(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(result),
-                                         _ptr(self._workspace), self._workspace.numel(), stream_ptr(self.device)),
-                   'die_env_step')
+        fused = False
+        if isinstance(action, PendingAction) and action.pending and action.agents is self.agents \
+                and action.medium is self.medium and action.slot is self.agents.slot and self._fuse_forward:
+            # `env.step(agent.forward(obs))`: forward runs fused with the move / claim pass
+            self.medium.next_epoch()
+            m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), action.raw_struct(), self._c_dynamics()
+            rc = _lib.lib.die_forward_env_step(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u), C.byref(d),
+                                               _ptr(result), _ptr(self._workspace), self._workspace.numel(),
+                                               stream_ptr(self.device))
+            if rc == -3:                            # DIE_ERR_UNSUPPORTED for this shape: two calls instead
+                self._fuse_forward = False
+                self.medium.epoch -= 1
+            else:
+                _lib.check(rc, 'die_forward_env_step')
+                action.agent._forward_consumed(action)
+                fused = True
+        if not fused:
+            act = self._as_action(action)
+            self.medium.next_epoch()
+            m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), act.c_struct(), self._c_dynamics()
+            _lib.check(_lib.lib.die_env_step(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(result),
+                                             _ptr(self._workspace), self._workspace.numel(), stream_ptr(self.device)),
+                       'die_env_step')
         self.medium.swap_chem()
         if self.dynamics.op_food_flow is not _identity_food_flow:
             self._host_food_flow()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 4
+#define DIE_ABI_VERSION 5
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -170,6 +170,16 @@ int die_const_forward(int64_t N, float dx, float dy, float deposit, die_action* 
  * plane is in m->chem_next.  `result` is a device pointer. */
 int die_env_step(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                  die_step_result* result, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Agent.forward + Env.step in one call for the common loop `env.step(agent.forward(obs))`
+ * (examples/minimal_run.py:24-25): GradientAgent/PhysarumAgent.forward is fused with the move /
+ * claim / feeding pass, so the action is written to `act` for the caller but never read back and
+ * the agent coordinates are loaded once.  Same results as die_gradient_forward followed by
+ * die_env_step.  DIE_ERR_UNSUPPORTED when the fused field sweep does not apply (decomposed tile,
+ * H % 4 != 0, gaussian radius > 4): call the two separately then. */
+int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                         const die_dynamics* d, die_step_result* result, void* workspace, int64_t workspace_bytes,
+                         void* stream);
 
 /* The stages of die_env_step, individually (tests and custom update cycles such as
  * examples/simple_agents.py:16-30 `_manual_step`). */

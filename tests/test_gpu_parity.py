@@ -378,6 +378,35 @@ def test_alternative_claim_and_staged_paths_give_identical_results(die, monkeypa
             assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('kind', ['physarum', 'gradient'])
+def test_fused_forward_step_equals_separate_calls(die, kind):
+    """`env.step(agent.forward(obs))` runs forward inside die_forward_env_step; with `agent.lazy = False`
+    it is die_gradient_forward + die_env_step.  Same bits, including the action handed back."""
+    W, H, N, K = 128, 96, 6000, 5000
+    rs = np.random.RandomState(17)
+    medium, agents = random_state(W, H, N, K, rs, collide=0.2)
+    outs = []
+    for lazy in (True, False):
+        env = die.Env.from_numpy(medium, agents, sort_every=3)
+        if kind == 'physarum':
+            ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        else:
+            ag = die.GradientAgent(max_agents=N, seed=5, scale=0.01, sense_offset=0.03, inertia=0.9, noise_scale=0.025)
+        ag.lazy = lazy
+        obs = env._get_current_obs
+        acts = []
+        for i in range(7):
+            act = ag.forward(obs)
+            if i == 2:
+                ag.forward(obs)                      # a second forward before the step: evaluated in call order
+                act = ag.forward(obs)
+            obs, *_ = env.step(act)
+            acts.append(act.to_numpy())              # still readable after the fused step
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.stack(acts)))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)
+
+
 def test_step_kat_collisions_and_dead_slots(die):
     """Hand-checkable case (tests/test_oracle_kat.py): last writer wins, feed duplication,
     dead slot on an occupied cell consumes, reward counts every slot."""
