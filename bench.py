@@ -51,7 +51,7 @@ def algorithmic_bytes(C, K):
     }
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v2_pmc_traffic_per_kernel_avg.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v3_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
@@ -76,28 +76,44 @@ def time_kernels(env, agent, reps):
     obs = env._get_current_obs
     out = {}
 
-    def timed(fn):
+    def timed(fn, prep=None):
+        """Average device time of what `fn` enqueues.  A ~100 µs spin kernel is queued first, so that the start
+        event, the launch and the stop event are all in the queue before the GPU reaches them: the host's
+        enqueue latency stays out of the measurement (it agrees with rocprofv3's kernel durations)."""
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
         for a, b in ev:
+            args = prep() if prep else ()
+            torch.cuda._sleep(250000)
             a.record()
-            fn()
+            fn(*args)
             b.record()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in ev) / reps * 1e3
 
     env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
     obs = env._get_current_obs
     sort_every, env._sort_every = env._sort_every, 0
 
-    def whole():
-        env.step(agent.forward(obs))
-    t_step = timed(whole)                 # k_forward_move_claim + k_reduce + k_diffuse_rows<fused>
-    action = agent.forward(obs)
-    action.ensure()
-    env.medium.next_epoch()
-    env._stage('die_agent_move_claim', action)
+    import ctypes as C
+    from die_amd.device_array import _ptr, stream_ptr
+
+    calls = [0]
+
+    def front_prep():                     # host work of one fused forward + move/claim launch
+        calls[0] += 1
+        if sort_every > 0 and calls[0] % sort_every == 0:
+            env.sort_agents()             # same re-sort cadence as the timed loop
+        act = agent.forward(obs)          # pending: its kernel runs inside die_forward_move_claim
+        env.medium.next_epoch()
+        return (act, env.medium.c_struct(), env.agents.c_struct(), act.raw_struct(), env._c_dynamics())
+
+    def front(act, m, a, u, d):           # k_forward_move_claim alone, through the C ABI
+        _lib.check(_lib.lib.die_forward_move_claim(C.byref(m), C.byref(a), C.byref(act.g_struct), C.byref(u), C.byref(d),
+                                                   _ptr(env._workspace), env._workspace.numel(), stream_ptr(env.device)),
+                   'die_forward_move_claim')
+        agent._forward_consumed(act)
+    out['k_forward_move_claim'] = timed(front, front_prep)
     out['k_diffuse_rows_fused'] = timed(env._medium_deposit_feed_diffuse)
-    out['k_forward_move_claim'] = t_step - out['k_diffuse_rows_fused']      # includes k_reduce (≈ 5 µs)
     env._sort_every = sort_every
     return out
 
@@ -224,7 +240,7 @@ def main():
         line['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/r01_v2_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
+            'traffic_source': 'profiles/r01_v3_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},

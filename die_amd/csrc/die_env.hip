@@ -689,20 +689,14 @@ extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_
     return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
 }
 
-extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
-                                    const die_dynamics* d, die_step_result* result, void* ws, int64_t ws_bytes,
-                                    void* stream) {
-    DIE_REQUIRE(m && a && g && act && d && result, "die_forward_env_step: null argument");
-    DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_forward_env_step: chem_next must be a second plane");
-    if (!fused_step_applies(m, d)) {
-        die_set_error("die_forward_env_step: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
-        return DIE_ERR_UNSUPPORTED;
-    }
+extern "C" int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                      const die_dynamics* d, void* ws, int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(m && a && g && act && d, "die_forward_move_claim: null argument");
     FwdArgs f;
-    int rc = die_fill_fwd_args(f, m, a, g, act, "die_forward_env_step");
+    int rc = die_fill_fwd_args(f, m, a, g, act, "die_forward_move_claim");
     if (rc != DIE_OK) return rc;
     StepArgs k;
-    rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_forward_env_step");
+    rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_forward_move_claim");
     if (rc != DIE_OK) return rc;
     k.part_gain = (double*)ws;
     const int grid = step_grid(a->N);
@@ -715,7 +709,21 @@ extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, di
         else k_forward_move_claim<__half, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
     }
     if (k.claim_by_store) k_claim_fix<<<grid, DIE_BLOCK, 0, s>>>(k);
-    DIE_CHECK_LAUNCH("die_forward_env_step");
+    DIE_CHECK_LAUNCH("die_forward_move_claim");
+    return DIE_OK;
+}
+
+extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                    const die_dynamics* d, die_step_result* result, void* ws, int64_t ws_bytes,
+                                    void* stream) {
+    DIE_REQUIRE(m && a && g && act && d && result, "die_forward_env_step: null argument");
+    DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_forward_env_step: chem_next must be a second plane");
+    if (!fused_step_applies(m, d)) {
+        die_set_error("die_forward_env_step: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+        return DIE_ERR_UNSUPPORTED;
+    }
+    int rc = die_forward_move_claim(m, a, g, act, d, ws, ws_bytes, stream);
+    if (rc != DIE_OK) return rc;
     return env_step_tail(m, a, act, d, result, ws, ws_bytes, stream);
 }
 

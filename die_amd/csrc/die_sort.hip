@@ -11,6 +11,12 @@
 #include <hipcub/hipcub.hpp>
 
 #define DIE_SORT_MAX_EXTRA 4
+#ifndef DIE_SORT_XSHIFT
+#define DIE_SORT_XSHIFT 4      // bucket = 2^XSHIFT rows × 2^YSHIFT columns (16×32: best of the shapes tried)
+#endif
+#ifndef DIE_SORT_YSHIFT
+#define DIE_SORT_YSHIFT 5
+#endif
 
 __global__ __launch_bounds__(DIE_BLOCK) void k_sort_keys(die_geo g, int64_t N, const uint32_t* x, const uint32_t* y,
                                                          int nby, uint32_t* key, uint32_t* val) {
@@ -20,7 +26,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_sort_keys(die_geo g, int64_t N, c
         int ix = die_cell((int64_t)x[n], g.gW) - g.ox, iy = die_cell((int64_t)y[n], g.gH) - g.oy;
         ix = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
         iy = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
-        key[n] = (uint32_t)((ix >> 3) * nby + (iy >> 6));
+        key[n] = (uint32_t)((ix >> DIE_SORT_XSHIFT) * nby + (iy >> DIE_SORT_YSHIFT));
         val[n] = (uint32_t)n;
     }
 }
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_permute(PermArgs a) {
 }
 
 static int key_bits(int W, int H) {
-    const int64_t nb = (int64_t)((W + 7) / 8) * ((H + 63) / 64);
+    const int64_t nb = (int64_t)((W >> DIE_SORT_XSHIFT) + 1) * ((H >> DIE_SORT_YSHIFT) + 1);
     int b = 1;
     while (((int64_t)1 << b) < nb) ++b;
     return b;
@@ -99,7 +105,7 @@ extern "C" int die_agents_sort(const die_medium* m, const die_agents* in, const 
     hipStream_t s = (hipStream_t)stream;
     int64_t g = (N + DIE_BLOCK - 1) / DIE_BLOCK;
     const int grid = (int)(g < 4096 ? g : 4096);
-    k_sort_keys<<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), N, in->x, in->y, (m->H + 63) / 64, key_in, val_in);
+    k_sort_keys<<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), N, in->x, in->y, (m->H >> DIE_SORT_YSHIFT) + 1, key_in, val_in);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)N, 0, bits, s);
     if (e != hipSuccess) {
         die_set_error("die_agents_sort: radix sort failed: %s", hipGetErrorString(e));

@@ -181,6 +181,10 @@ int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_
                          const die_dynamics* d, die_step_result* result, void* workspace, int64_t workspace_bytes,
                          void* stream);
 
+/* First kernel of die_forward_env_step alone (forward + move + claim + feeding of alive slots). */
+int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                           const die_dynamics* d, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The stages of die_env_step, individually (tests and custom update cycles such as
  * examples/simple_agents.py:16-30 `_manual_step`). */
 int die_agent_move_claim(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,

@@ -5,7 +5,7 @@ if len(sys.argv) > 1 and sys.argv[1] == 'child':
     sys.path.insert(0, ROOT)
     import torch, die_amd, bench
     W = H = 4096
-    env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=0.15), seed=1234, max_agents='alive', sync=False, sort_every=8)
+    env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=0.15), seed=1234, max_agents='alive', sync=False, sort_every=int(os.environ.get('ABL_SORT', '8')))
     K = env.agents.N
     agent = die_amd.PhysarumAgent(max_agents=K, seed=1234, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
     obs = env._get_current_obs

@@ -507,7 +507,7 @@ def test_agent_sort_is_a_bucket_ordered_permutation(die):
     assert np.array_equal(env.agents.to_numpy(), before)
     x = (env.agents.x.cpu().numpy().view(np.uint32).astype(np.float64)) / 2 ** 32
     y = (env.agents.y.cpu().numpy().view(np.uint32).astype(np.float64)) / 2 ** 32
-    key = (R.cell(x, W) >> 3) * ((H + 63) // 64) + (R.cell(y, H) >> 6)
+    key = (R.cell(x, W) >> 4) * ((H >> 5) + 1) + (R.cell(y, H) >> 5)
     assert (np.diff(key) >= 0).all()
     env.sort_agents()                                   # sorting a sorted array keeps it a permutation
     assert np.array_equal(env.agents.to_numpy(), before)
