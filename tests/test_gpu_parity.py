@@ -685,3 +685,29 @@ def test_full_size_properties_4096(die):
     assert (own[ix, iy] >= np.arange(K)).all()                 # the owner of my cell is me or a higher slot
     o = own[own >= 0]
     assert (ix[o] * H + iy[o] == np.nonzero(own.ravel() >= 0)[0]).all()
+
+
+def test_largest_baseline_grid_16384_f16_invariants(die):
+    """BASELINE configs[4] grid: 16384² with fp16 field channels (268 M cells, ≈ 40 M agents) — maximum-size
+    smoke test of the index arithmetic (int64 offsets, 29-bit slot field of the claim word) with the same
+    size-independent invariants as at 4096²."""
+    W = H = 16384
+    env = die.Env((W, H), die.Dynamics(init_agent_ratio=0.15), seed=99, max_agents='alive', field_dtype=torch.float16,
+                  sort_every=2)
+    K = env.agents.N
+    assert abs(K / (W * H) - 0.15) < 0.001 and K < 2 ** 29
+    agent = die.PhysarumAgent(max_agents=K, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), seed=3)
+    obs = env._get_current_obs
+    for step in range(3):
+        af0 = env.agents.agent_food.double().sum().item()
+        obs, reward, term, _, info = env.step(agent.forward(obs))
+        assert info['num_agents'] == K and not term
+        af1 = env.agents.agent_food.double().sum().item()
+        assert abs((af1 - af0) - reward) <= 1e-5 * abs(af0)
+        n_occ = int(env.medium.occupied().sum().item())
+        assert 0.85 * K < n_occ <= K
+    own = env.medium.owner_slots()
+    assert int(own.max().item()) < K and int((own >= 0).sum().item()) == n_occ
+    slots = own[own >= 0]
+    assert slots.unique().numel() == slots.numel()              # every owner owns exactly one cell
+    assert torch.isfinite(env.medium.chem.float()).all() and float(env.medium.chem.float().max()) > 0
