@@ -138,7 +138,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_forward_move_claim(FwdArgs f, Ste
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
         gsum += (double)move_claim_one<T>(a, n, X, Y, o.dx, o.dy, o.dep, sid);
     }
-    block_sum_store(gsum, 0, a.part_gain, nullptr);
+    if (a.do_claim) block_sum_store(gsum, 0, a.part_gain, nullptr);
 }
 
 // Second half of the claim: raise every cell's word to the maximum over its claimants.
@@ -576,6 +576,35 @@ extern "C" int die_agent_move(const die_medium* m, const die_agents* a, const di
     return DIE_OK;
 }
 
+extern "C" int die_forward_move(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                const die_dynamics* d, int32_t tile_w, int32_t tile_h, int32_t tiles_y, int32_t* tile_of,
+                                void* stream) {
+    DIE_REQUIRE(m && a && g && act && d && tile_of, "die_forward_move: null argument");
+    DIE_REQUIRE(tile_w >= 1 && tile_h >= 1 && tiles_y >= 1, "die_forward_move: bad tile shape");
+    if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
+        die_set_error("die_forward_move: boundary %d is not representable in Q0.32", d->boundary);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    FwdArgs f;
+    int rc = die_fill_fwd_args(f, m, a, g, act, "die_forward_move");
+    if (rc != DIE_OK) return rc;
+    StepArgs k = {};
+    k.g = die_geo_of(m); k.N = a->N; k.x = a->x; k.y = a->y; k.slot = a->slot;
+    k.boundary = d->boundary; k.do_move = 1; k.do_claim = 0;
+    k.tile_w = tile_w; k.tile_h = tile_h; k.tiles_y = tiles_y; k.tile_of = tile_of;
+    const int grid = step_grid(a->N);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->dtype == DIE_F32) {
+        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim<float, DIE_AGENT_PHYSARUM><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+        else k_forward_move_claim<float, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+    } else {
+        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim<__half, DIE_AGENT_PHYSARUM><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+        else k_forward_move_claim<__half, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+    }
+    DIE_CHECK_LAUNCH("die_forward_move");
+    return DIE_OK;
+}
+
 extern "C" int die_agent_claim_feed(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                                     void* ws, int64_t ws_bytes, void* stream) {
     StepArgs k;
@@ -627,6 +656,19 @@ extern "C" int die_agent_resolve(const die_medium* m, const die_agents* a, const
     if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_resolve<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     DIE_CHECK_LAUNCH("die_agent_resolve");
+    return DIE_OK;
+}
+
+extern "C" int die_step_reduce_ex(const die_agents* a, die_step_result* result, void* ws, int64_t ws_bytes,
+                                  int32_t with_second_pass, int64_t alive_const, void* stream) {
+    DIE_REQUIRE(a && result && ws, "die_step_reduce_ex: null argument");
+    DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_step_reduce_ex: workspace too small");
+    const int g = step_grid(a->N);
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
+                                                  with_second_pass ? g : 0,
+                                                  (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
+                                                  with_second_pass ? g : 0, result, with_second_pass ? -1 : alive_const);
+    DIE_CHECK_LAUNCH("die_step_reduce_ex");
     return DIE_OK;
 }
 

@@ -377,15 +377,23 @@ class DistEnv:
         die_step_result; `read_result` all-reduces it."""
         from .device_array import _ptr, stream_ptr
         lib, A, g = self._lib, self.agents, self.geo
-        action.N = A.N
+        from .device_array import PendingAction
         sp = stream_ptr(self.device)
         d = self._c_dynamics()
-        m, a, u = self.medium.c_struct(), self._struct(A), action.c_struct()
-        lib.check(lib.lib.die_agent_move(C.byref(m), C.byref(a), C.byref(u), C.byref(d), g.Wi, g.Hi, g.Py,
-                                         _ptr(self._tile_of), sp), 'die_agent_move')
+        m, a = self.medium.c_struct(), self._struct(A)
+        if isinstance(action, PendingAction) and action.pending and action.agents is A and action.medium is self.medium:
+            u = action.raw_struct()                     # forward runs fused with the move half
+            lib.check(lib.lib.die_forward_move(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u), C.byref(d),
+                                               g.Wi, g.Hi, g.Py, _ptr(self._tile_of), sp), 'die_forward_move')
+            action.agent._forward_consumed(action)
+        else:
+            action.N = A.N
+            u = action.c_struct()
+            lib.check(lib.lib.die_agent_move(C.byref(m), C.byref(a), C.byref(u), C.byref(d), g.Wi, g.Hi, g.Py,
+                                             _ptr(self._tile_of), sp), 'die_agent_move')
         self._migrate(action)
         self.medium.next_epoch()
-        result = torch.zeros(2, dtype=torch.float64, device=self.device)
+        result = torch.empty(2, dtype=torch.float64, device=self.device)
         if A.N > 0:
             m, a, u = self.medium.c_struct(), self._struct(A), action.c_struct()
             ws, wsn = _ptr(self._workspace), self._workspace.numel()
@@ -395,11 +403,10 @@ class DistEnv:
             if second:                      # dead slots / lifecycle: needs the claims, not the field
                 lib.check(lib.lib.die_agent_dead_slots(C.byref(m), C.byref(a), C.byref(u), C.byref(d), ws, wsn, sp),
                           'die_agent_dead_slots')
-            else:
-                self._zero_second_partials()
-            lib.check(lib.lib.die_step_reduce(C.byref(a), C.byref(d), _ptr(result), ws, wsn, sp), 'die_step_reduce')
-            if not second:
-                result.view(torch.int64)[1] = A.N
+            lib.check(lib.lib.die_step_reduce_ex(C.byref(a), _ptr(result), ws, wsn, int(second), A.N, sp),
+                      'die_step_reduce_ex')
+        else:
+            result.zero_()
         # the field sweep applies deposits on load, so it needs chem AND claims of the halo
         M = self.medium
         if self._chem_halo_in_flight:

@@ -212,6 +212,13 @@ int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_act
  * stands on, so the caller can migrate it before die_agent_claim_feed. */
 int die_agent_move(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                    int32_t tile_w, int32_t tile_h, int32_t tiles_y, int32_t* tile_of, void* stream);
+/* die_gradient_forward fused with die_agent_move (decomposed worlds; the action is written to `act`). */
+int die_forward_move(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                     const die_dynamics* d, int32_t tile_w, int32_t tile_h, int32_t tiles_y, int32_t* tile_of, void* stream);
+/* die_step_reduce when the caller knows whether the dead-slot pass ran: without it only the
+ * move/claim partials are summed and num_alive = alive_const. */
+int die_step_reduce_ex(const die_agents* a, die_step_result* result, void* workspace, int64_t workspace_bytes,
+                       int32_t with_second_pass, int64_t alive_const, void* stream);
 /* Decomposed step, second half: claim + feeding of die_agent_move_claim without the move. */
 int die_agent_claim_feed(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                          void* workspace, int64_t workspace_bytes, void* stream);
