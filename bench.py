@@ -30,7 +30,7 @@ def parse():
     p.add_argument('--ratio', type=float, default=0.15)
     p.add_argument('--seed', type=int, default=1234)
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-steps', type=int, default=3)
+    p.add_argument('--cpu-steps', type=int, default=6)
     p.add_argument('--kernel-reps', type=int, default=20)
     p.add_argument('--sort-every', type=int, default=8)
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')

@@ -711,3 +711,48 @@ def test_largest_baseline_grid_16384_f16_invariants(die):
     slots = own[own >= 0]
     assert slots.unique().numel() == slots.numel()              # every owner owns exactly one cell
     assert torch.isfinite(env.medium.chem.float()).all() and float(env.medium.chem.float().max()) > 0
+
+
+def test_custom_food_flow_and_render(die):
+    """Dynamics.op_food_flow as an arbitrary Python operator (core/env.py:147-150; the 'dyn-pred'
+    dynamics of examples/simple_agents.py:95-100 use WaveSequence.get_flow_operator) runs through a
+    host round trip; Env.render() returns the three frames of core/render.py:84-89."""
+    W, H, N, K = 48, 36, 400, 300
+    rs = np.random.RandomState(2)
+    medium, agents = random_state(W, H, N, K, rs)
+    wave = R.wave_field(W, H, 0.25)
+
+    def flow(food):
+        return 0.05 * np.abs(wave) + (1 - 0.5) * food            # scale·wave(t) + (1 − decay)·current
+
+    dyn = die.Dynamics(op_food_flow=flow)
+    rdyn = R.RefDynamics(op_food_flow=flow, rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)))
+    env, ref = die.Env.from_numpy(medium, agents, dyn), R.RefEnv(medium, agents, rdyn)
+    for _ in range(3):
+        action = quantised_action(N, rs, 2.0 / W)
+        env.step(action)
+        ref.step(action)
+    m = env.medium.to_numpy()
+    assert np.allclose(m[1], ref.medium[1], rtol=RTOL, atol=1e-7)
+    assert np.allclose(m[2], ref.medium[2], rtol=RTOL, atol=1e-7)
+    assert np.array_equal(m[0], ref.medium[0])
+    frames = env.render()
+    assert [f.shape for f in frames] == [(W, H, 3), (W, H, 4), (H, -(-N // H), 4)]
+    assert np.array_equal(frames[0][..., 0], m[0]) and np.allclose(frames[0][..., 2], m[2])
+    assert frames[2][..., 3].sum() == K
+
+
+def test_minimal_run_example(die):
+    """The port of the reference's examples/minimal_run.py runs end to end (both agents)."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'minimal_run.py')
+    spec = importlib.util.spec_from_file_location('minimal_run', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, env = mod.run_minimal(die.BrownianAgent(move_scale=0.01, seed=1), agent_ratio=0.05, field_size=(64, 64), iters=20,
+                                 seed=1)
+    assert np.isfinite(total) and env._num_alive_agents > 50
+    total, env = mod.run_minimal(die.PhysarumAgent(max_agents=64 * 64, scale=0.006, turn_angle=30, sense_offset=0.04, seed=1),
+                                 agent_ratio=0.15, field_size=(64, 64), iters=20, seed=1)
+    assert np.isfinite(total) and float(env.medium.chem.max()) > 0
