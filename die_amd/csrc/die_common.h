@@ -8,7 +8,9 @@
 #include "../../include/die_hip.h"
 
 #define DIE_WAVE 64
+#ifndef DIE_BLOCK
 #define DIE_BLOCK 256
+#endif
 
 void die_set_error(const char* fmt, ...);
 

@@ -282,6 +282,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
 #define DIF_ROWS 16     // rows per wave: 16 → ≈17 waves per CU at 4096² (32: 87 µs, 16: 75 µs, 8: 86 µs for the fused sweep)
 #endif
 #define DIF_WCOLS 248          // output columns per wave
+#ifndef DIF_BLOCK
+#define DIF_BLOCK 128          // waves are independent (no LDS, no barrier): small workgroups balance better
+#endif
 
 struct RowsArgs {
     const void* src;
@@ -313,14 +316,14 @@ template <> struct Vec4<__half> {
 };
 
 template <typename T, int R, bool FUSED, bool WRAP>
-__global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
+__global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     static_assert(R >= 1 && R <= 4, "one halo lane of 4 columns per side");
     const T* src = (const T*)a.src;
     T* dst = (T*)a.dst;
     T* food = (T*)a.food;
     const int W = a.W, H = a.H;
     const int lane = threadIdx.x & (DIE_WAVE - 1);
-    const int strip = blockIdx.x * (DIE_BLOCK / DIE_WAVE) + (threadIdx.x >> 6);
+    const int strip = blockIdx.x * (DIF_BLOCK / DIE_WAVE) + (threadIdx.x >> 6);
     const int yb = strip * DIF_WCOLS;                       // first output column of this wave
     if (yb >= H) return;                                    // whole wave idle (nothing below synchronises)
     const int nout = min(DIF_WCOLS, H - yb) / 4;            // output lanes are 1..nout (H % 4 == 0)
@@ -411,12 +414,13 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse_rows(RowsArgs a) {
 template <typename T, bool FUSED, bool WRAP = true>
 static int launch_rows(const RowsArgs& a, int R, hipStream_t s) {
     const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
-    dim3 grid((strips + 3) / 4, (a.W + DIF_ROWS - 1) / DIF_ROWS);
+    constexpr int WPB = DIF_BLOCK / DIE_WAVE;
+    dim3 grid((strips + WPB - 1) / WPB, (a.W + DIF_ROWS - 1) / DIF_ROWS);
     switch (R) {
-        case 1: k_diffuse_rows<T, 1, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
-        case 2: k_diffuse_rows<T, 2, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
-        case 3: k_diffuse_rows<T, 3, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
-        case 4: k_diffuse_rows<T, 4, FUSED, WRAP><<<grid, DIE_BLOCK, 0, s>>>(a); break;
+        case 1: k_diffuse_rows<T, 1, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
+        case 2: k_diffuse_rows<T, 2, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
+        case 3: k_diffuse_rows<T, 3, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
+        case 4: k_diffuse_rows<T, 4, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
         default: return DIE_ERR_UNSUPPORTED;
     }
     return DIE_OK;
