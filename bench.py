@@ -33,6 +33,7 @@ def parse():
     p.add_argument('--cpu-steps', type=int, default=6)
     p.add_argument('--kernel-reps', type=int, default=20)
     p.add_argument('--sort-every', type=int, default=8)
+    p.add_argument('--fields', choices=['f32', 'f16'], default='f32', help='dtype of the field channels (configs[4] uses f16)')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
@@ -181,7 +182,8 @@ def main():
         agent = die_amd.PhysarumAgent(max_agents=env.capacity, seed=args.seed + rank, **agent_kw)
     else:
         env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
-                          max_agents='alive', device=device, sync=False, sort_every=args.sort_every)
+                          max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
+                          field_dtype=torch.float16 if args.fields == 'f16' else torch.float32)
         K = env.agents.N
         agent = die_amd.PhysarumAgent(max_agents=K, seed=args.seed + rank, **agent_kw)
 
@@ -216,8 +218,8 @@ def main():
     line = {
         'metric': 'env steps/sec on 4096^2 Physarum grid', 'value': round(steps_per_s, 2), 'unit': 'env steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'PhysarumAgent {W}x{H} fp32 fields, agent ratio {args.ratio} (BASELINE configs[2]); '
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.fields, 'data': 'synthetic',
+        'config': {'workload': f'PhysarumAgent {W}x{H} {args.fields} fields, agent ratio {args.ratio} (BASELINE configs[2]); '
                                'step = PhysarumAgent.forward + Env.step with the action handed over in HBM',
                    'grid': [W, H], 'alive_agents': K, 'agent_slots': K, 'steps_per_rank': args.steps,
                    'parallelism': mode,
