@@ -69,6 +69,8 @@ _SIGNATURES = {
                                C.c_void_p]),
     'die_forward_env_step': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_env_step_finish': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64,
+                                      C.c_void_p]),
     'die_forward_move_claim': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                          C.c_int64, C.c_void_p]),
     'die_agent_move_claim': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,

@@ -742,6 +742,10 @@ extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_
 extern "C" int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
                                       const die_dynamics* d, void* ws, int64_t ws_bytes, void* stream) {
     DIE_REQUIRE(m && a && g && act && d, "die_forward_move_claim: null argument");
+    if (!fused_step_applies(m, d)) {       // it is the first half of the fused step: refuse before touching anything
+        die_set_error("die_forward_move_claim: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+        return DIE_ERR_UNSUPPORTED;
+    }
     FwdArgs f;
     int rc = die_fill_fwd_args(f, m, a, g, act, "die_forward_move_claim");
     if (rc != DIE_OK) return rc;
@@ -761,6 +765,16 @@ extern "C" int die_forward_move_claim(const die_medium* m, const die_agents* a, 
     if (k.claim_by_store) k_claim_fix<<<grid, DIE_BLOCK, 0, s>>>(k);
     DIE_CHECK_LAUNCH("die_forward_move_claim");
     return DIE_OK;
+}
+
+extern "C" int die_env_step_finish(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                                   die_step_result* result, void* ws, int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(m && a && act && d && result && ws, "die_env_step_finish: null argument");
+    if (!fused_step_applies(m, d)) {
+        die_set_error("die_env_step_finish: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+        return DIE_ERR_UNSUPPORTED;
+    }
+    return env_step_tail(m, a, act, d, result, ws, ws_bytes, stream);
 }
 
 extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,

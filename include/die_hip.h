@@ -185,6 +185,12 @@ int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_
 int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
                            const die_dynamics* d, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Everything of die_forward_env_step / die_env_step after the claims are in place (dead-slot pass if
+ * needed, reduction, fused field sweep) — lets a caller put work that only touches the agent arrays
+ * (die_agents_sort) on another stream, next to the sweep. */
+int die_env_step_finish(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
+                        die_step_result* result, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The stages of die_env_step, individually (tests and custom update cycles such as
  * examples/simple_agents.py:16-30 `_manual_step`). */
 int die_agent_move_claim(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
