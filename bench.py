@@ -145,11 +145,14 @@ def main():
     if dist_on:
         import datetime
         import torch.distributed as dist
+        backend = os.environ.get('DIE_DIST_BACKEND', 'nccl')      # 'gloo': rehearsal with several ranks on one GPU
+        if torch.cuda.device_count() == 1:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device(f'cuda:{local_rank}'),
-                                timeout=datetime.timedelta(seconds=300))
+        kw = dict(device_id=torch.device(f'cuda:{local_rank}')) if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
     elif args.gpus > 1:
         sys.exit('launch N>1 with torch.distributed.run (one rank per GPU)')
     device = torch.device(f'cuda:{local_rank}')
@@ -172,7 +175,8 @@ def main():
             agent_kw.update(scale=1.53 / (gW - 1), sense_offset=10.2 / (gW - 1))
             denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
                            device=device, seed=args.seed, sort_every=args.sort_every)
-            mode = f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, halo {denv.geo.h}, RCCL p2p'
+            mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, halo {denv.geo.h}, '
+                    f'{"RCCL" if backend == "nccl" else backend} point-to-point')
         except Exception as e:           # keep the scaling run alive: independent replicas, and say so
             denv = None
             mode = f'{world} independent grid replicas (decomposition unavailable: {type(e).__name__}: {e})'

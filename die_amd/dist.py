@@ -149,21 +149,26 @@ def halo_exchange(planes, geo: TileGeometry, comm: Comm):
 
 def route_records(records: torch.Tensor, dest: torch.Tensor, comm: Comm) -> Tuple[torch.Tensor, torch.Tensor]:
     """Deliver the columns of `records` (F, n) to the ranks in `dest` (n,).  Returns
-    (kept_mask, arrivals) where arrivals is (F, m) gathered from all other ranks in rank order."""
+    (kept_mask, arrivals) where arrivals is (F, m) gathered from all other ranks in rank order.
+    One host synchronisation (the count matrix); the outgoing records are grouped by one stable sort."""
     size, me = comm.size, comm.rank
     leaving = dest != me
-    counts = torch.bincount(dest[leaving].to(torch.int64), minlength=size)
+    d = dest[leaving].to(torch.int64)
+    counts = torch.bincount(d, minlength=size)
     matrix = comm.all_gather_counts(counts)                     # host: matrix[src, dst]
     incoming = matrix[:, me].tolist()
     outgoing = matrix[me].tolist()
     sends, recvs, parts = [], [], []
+    if sum(outgoing):
+        order = torch.sort(d, stable=True).indices
+        grouped = records[:, leaving][:, order]
+        start = 0
+        for peer in range(size):
+            if outgoing[peer]:
+                sends.append((peer, grouped[:, start:start + outgoing[peer]].contiguous()))
+                start += outgoing[peer]
     for peer in range(size):
-        if peer == me:
-            continue
-        if outgoing[peer]:
-            idx = torch.nonzero(dest == peer, as_tuple=False).squeeze(1)
-            sends.append((peer, records[:, idx].contiguous()))
-        if incoming[peer]:
+        if peer != me and incoming[peer]:
             buf = torch.empty((records.shape[0], incoming[peer]), dtype=records.dtype, device=records.device)
             recvs.append((peer, buf))
             parts.append(buf)
