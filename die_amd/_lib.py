@@ -17,7 +17,7 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class Medium(C.Structure):
@@ -49,6 +49,11 @@ class GradientAgent(C.Structure):
                 ('turn_tolerance', C.c_float), ('reserved', C.c_int32), ('heading', C.c_void_p),
                 ('prev_gx', C.c_void_p), ('prev_gy', C.c_void_p), ('turn_sign', C.c_void_p),
                 ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32)]
+
+
+class Rect(C.Structure):
+    _fields_ = [('plane', C.c_void_p), ('pitch', C.c_int32), ('r0', C.c_int32), ('r1', C.c_int32), ('c0', C.c_int32),
+                ('c1', C.c_int32), ('elem_bytes', C.c_int32), ('buf_offset', C.c_int64)]
 
 
 class FoodSpec(C.Structure):
@@ -96,6 +101,10 @@ _SIGNATURES = {
     'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),
     'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
+    'die_rects_pack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
+    'die_rects_unpack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
+    'die_records_gather': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'die_records_scatter': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
                                   C.c_int64, C.c_void_p]),

@@ -7,8 +7,8 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdie_hip.so')
-SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip']
-HEADERS = ['die_common.h', 'die_rng.h', os.path.join('..', '..', 'include', 'die_hip.h')]
+SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip', 'die_pack.hip']
+HEADERS = ['die_common.h', 'die_rng.h', 'die_forward.h', os.path.join('..', '..', 'include', 'die_hip.h')]
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
 

@@ -1,0 +1,108 @@
+// Pack / unpack helpers of the decomposed step (die_amd/dist.py): rectangular blocks of the padded
+// planes ⇄ contiguous message buffers (halo exchange), and agent records ⇄ per-agent arrays
+// (migration).  One launch moves every block / every array of a message instead of one tiny copy each.
+#include "die_common.h"
+
+#define DIE_PACK_MAX 16
+
+struct RectArgs {
+    int n;
+    char* plane[DIE_PACK_MAX];
+    int pitch[DIE_PACK_MAX], r0[DIE_PACK_MAX], c0[DIE_PACK_MAX], cols[DIE_PACK_MAX], esz[DIE_PACK_MAX];
+    int64_t first[DIE_PACK_MAX + 1];   // prefix sums of element counts
+    int64_t boff[DIE_PACK_MAX];        // byte offset of each block inside the buffer
+    char* buf;
+};
+
+template <bool PACK>
+__global__ __launch_bounds__(DIE_BLOCK) void k_rects(RectArgs a) {
+    const int64_t total = a.first[a.n];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        int k = 0;
+        while (i >= a.first[k + 1]) ++k;
+        const int64_t e = i - a.first[k];
+        const int r = (int)(e / a.cols[k]), c = (int)(e - (int64_t)r * a.cols[k]);
+        char* p = a.plane[k] + ((int64_t)(a.r0[k] + r) * a.pitch[k] + a.c0[k] + c) * a.esz[k];
+        char* b = a.buf + a.boff[k] + e * a.esz[k];
+        if (a.esz[k] == 8) { if (PACK) *(uint64_t*)b = *(const uint64_t*)p; else *(uint64_t*)p = *(const uint64_t*)b; }
+        else if (a.esz[k] == 4) { if (PACK) *(uint32_t*)b = *(const uint32_t*)p; else *(uint32_t*)p = *(const uint32_t*)b; }
+        else { if (PACK) *(uint16_t*)b = *(const uint16_t*)p; else *(uint16_t*)p = *(const uint16_t*)b; }
+    }
+}
+
+static int rects(const die_rect* r, int32_t n, void* buf, bool pack, void* stream, const char* who) {
+    DIE_REQUIRE(r && buf && n >= 1 && n <= DIE_PACK_MAX, "%s: 1..%d blocks", who, DIE_PACK_MAX);
+    RectArgs a;
+    a.n = n; a.buf = (char*)buf; a.first[0] = 0;
+    for (int k = 0; k < n; ++k) {
+        DIE_REQUIRE(r[k].plane && r[k].r1 > r[k].r0 && r[k].c1 > r[k].c0 && r[k].r0 >= 0 && r[k].c0 >= 0 && r[k].c1 <= r[k].pitch,
+                    "%s: bad block %d", who, k);
+        DIE_REQUIRE(r[k].elem_bytes == 2 || r[k].elem_bytes == 4 || r[k].elem_bytes == 8, "%s: element size %d", who, r[k].elem_bytes);
+        DIE_REQUIRE(r[k].buf_offset % r[k].elem_bytes == 0, "%s: misaligned block %d", who, k);
+        a.plane[k] = (char*)r[k].plane; a.pitch[k] = r[k].pitch; a.r0[k] = r[k].r0; a.c0[k] = r[k].c0;
+        a.cols[k] = r[k].c1 - r[k].c0; a.esz[k] = r[k].elem_bytes; a.boff[k] = r[k].buf_offset;
+        a.first[k + 1] = a.first[k] + (int64_t)(r[k].r1 - r[k].r0) * a.cols[k];
+    }
+    for (int k = n; k < DIE_PACK_MAX; ++k) { a.plane[k] = nullptr; a.pitch[k] = a.r0[k] = a.c0[k] = a.cols[k] = a.esz[k] = 0; a.boff[k] = 0; a.first[k + 1] = a.first[n]; }
+    int64_t g = (a.first[n] + DIE_BLOCK - 1) / DIE_BLOCK;
+    const int grid = (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
+    if (pack) k_rects<true><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    else k_rects<false><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    DIE_CHECK_LAUNCH(who);
+    return DIE_OK;
+}
+
+extern "C" int die_rects_pack(const die_rect* r, int32_t n, void* buf, void* stream) { return rects(r, n, buf, true, stream, "die_rects_pack"); }
+extern "C" int die_rects_unpack(const die_rect* r, int32_t n, const void* buf, void* stream) { return rects(r, n, (void*)buf, false, stream, "die_rects_unpack"); }
+
+struct RecArgs {
+    int n;
+    char* arr[DIE_PACK_MAX];
+    int esz[DIE_PACK_MAX];
+    const int64_t* idx;
+    int64_t count;
+    int32_t* rec;       // (n, count) 4-byte words, row-major
+};
+
+template <bool GATHER>
+__global__ __launch_bounds__(DIE_BLOCK) void k_records(RecArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.count; j += stride) {
+        const int64_t s = a.idx[j];
+        for (int k = 0; k < a.n; ++k) {
+            int32_t* r = a.rec + (int64_t)k * a.count + j;
+            if (a.esz[k] == 4) { if (GATHER) *r = ((const int32_t*)a.arr[k])[s]; else ((int32_t*)a.arr[k])[s] = *r; }
+            else { if (GATHER) *r = (int32_t)((const uint8_t*)a.arr[k])[s]; else ((uint8_t*)a.arr[k])[s] = (uint8_t)*r; }
+        }
+    }
+}
+
+static int records(void* const* arrays, const int32_t* esz, int32_t n, const int64_t* idx, int64_t count, int32_t* rec, bool gather,
+                   void* stream, const char* who) {
+    DIE_REQUIRE(arrays && esz && n >= 1 && n <= DIE_PACK_MAX, "%s: 1..%d arrays", who, DIE_PACK_MAX);
+    if (count == 0) return DIE_OK;
+    DIE_REQUIRE(idx && rec && count > 0, "%s: null index / record buffer", who);
+    RecArgs a;
+    a.n = n; a.idx = idx; a.count = count; a.rec = rec;
+    for (int k = 0; k < DIE_PACK_MAX; ++k) {
+        a.arr[k] = k < n ? (char*)arrays[k] : nullptr;
+        a.esz[k] = k < n ? esz[k] : 0;
+        DIE_REQUIRE(k >= n || (arrays[k] && (esz[k] == 4 || esz[k] == 1)), "%s: array %d must be 4- or 1-byte", who, k);
+    }
+    int64_t g = (count + DIE_BLOCK - 1) / DIE_BLOCK;
+    const int grid = (int)(g < 2048 ? g : 2048);
+    if (gather) k_records<true><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    else k_records<false><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    DIE_CHECK_LAUNCH(who);
+    return DIE_OK;
+}
+
+extern "C" int die_records_gather(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int64_t* idx, int64_t count,
+                                  int32_t* records_out, void* stream) {
+    return records(arrays, elem_bytes, n, idx, count, records_out, true, stream, "die_records_gather");
+}
+extern "C" int die_records_scatter(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int64_t* idx, int64_t count,
+                                   const int32_t* records_in, void* stream) {
+    return records(arrays, elem_bytes, n, idx, count, (int32_t*)records_in, false, stream, "die_records_scatter");
+}

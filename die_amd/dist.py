@@ -128,23 +128,61 @@ class Comm:
         return c
 
 
+_HALO_BUFFERS: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def _slice_rect(_lib, plane: torch.Tensor, view, offset: int):
+    rs, cs = view
+    return _lib.Rect(plane.data_ptr(), plane.shape[1], rs.start, rs.stop, cs.start, cs.stop, plane.element_size(), offset)
+
+
 def halo_exchange(planes, geo: TileGeometry, comm: Comm):
     """Fill the halo ring of one or several padded (W, H) planes from the periodic neighbours; all
-    planes travel in the same two batches (phase 0: columns, phase 1: full-width rows)."""
+    planes travel together in two batches (phase 0: columns, phase 1: full-width rows).  On a GPU the
+    strips of all planes are packed into ONE message per neighbour by die_rects_pack / _unpack."""
     if isinstance(planes, torch.Tensor):
         planes = [planes]
     plan = geo.halo_plan()
+    on_gpu = all(p.is_cuda for p in planes)
+    if on_gpu:
+        from . import _lib
+        from .device_array import stream_ptr
     for phase in (0, 1):
-        sends, recvs = [], []
-        for plane in planes:
-            for ph, to, sview, frm, rview in plan:
-                if ph != phase:
-                    continue
-                sends.append((to, plane[sview]))
-                recvs.append((frm, plane[rview]))
-        # a pair of ranks that are each other's neighbour on both sides exchanges two messages per plane:
-        # "send to the −side, send to the +side" pairs with "recv from the +side, recv from the −side"
+        entries = [e for e in plan if e[0] == phase]          # [to −side, to +side]
+        if not on_gpu:
+            sends, recvs = [], []
+            for plane in planes:
+                for ph, to, sview, frm, rview in entries:
+                    sends.append((to, plane[sview]))
+                    recvs.append((frm, plane[rview]))
+            comm.exchange(sends, recvs)
+            continue
+        # message layout: for each direction, the strips of every plane back to back (8-byte aligned)
+        srects, rrects, offs, off = [], [], [], 0
+        for ph, to, sview, frm, rview in entries:
+            offs.append(off)
+            for plane in planes:
+                rows = sview[0].stop - sview[0].start
+                cols = sview[1].stop - sview[1].start
+                srects.append(_slice_rect(_lib, plane, sview, off))
+                rrects.append(_slice_rect(_lib, plane, rview, off))
+                off += (rows * cols * plane.element_size() + 7) & ~7
+        offs.append(off)
+        key = (planes[0].device, phase, off)
+        if key not in _HALO_BUFFERS:
+            _HALO_BUFFERS[key] = (torch.empty(off, dtype=torch.uint8, device=planes[0].device),
+                                  torch.empty(off, dtype=torch.uint8, device=planes[0].device))
+        sbuf, rbuf = _HALO_BUFFERS[key]
+        sp = stream_ptr(planes[0].device)
+        sarr = (_lib.Rect * len(srects))(*srects)
+        _lib.check(_lib.lib.die_rects_pack(sarr, len(srects), C.c_void_p(sbuf.data_ptr()), sp), 'die_rects_pack')
+        # "send to the −side, send to the +side" pairs with "recv from the +side, recv from the −side": the
+        # message a rank sends to its −side neighbour is what that neighbour receives from its +side
+        sends = [(entries[0][1], sbuf[offs[0]:offs[1]]), (entries[1][1], sbuf[offs[1]:offs[2]])]
+        recvs = [(entries[0][3], rbuf[offs[0]:offs[1]]), (entries[1][3], rbuf[offs[1]:offs[2]])]
         comm.exchange(sends, recvs)
+        rarr = (_lib.Rect * len(rrects))(*rrects)
+        _lib.check(_lib.lib.die_rects_unpack(rarr, len(rrects), C.c_void_p(rbuf.data_ptr()), sp), 'die_rects_unpack')
 
 
 def route_records(records: torch.Tensor, dest: torch.Tensor, comm: Comm) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -338,30 +376,47 @@ class DistEnv:
             ts += obj._die_state_tensors(A)
         return ts
 
+    def _record_arrays(self, tensors):
+        arrs = tensors + [self.agents.alive]
+        ptrs = (C.c_void_p * len(arrs))(*[t.data_ptr() for t in arrs])
+        esz = (C.c_int32 * len(arrs))(*[t.element_size() for t in arrs])
+        return arrs, ptrs, esz
+
     def _migrate(self, action):
-        A, g, comm = self.agents, self.geo, self.comm
+        """Send agents whose cell left the tile to the owning rank and take in the arrivals: one
+        gather launch for the leavers' records, one scatter launch for the arrivals (and one pair for the
+        tail entries that move into remaining holes)."""
+        from .device_array import stream_ptr
+        A, comm, lib = self.agents, self.comm, self._lib
+        if comm.size == 1:
+            return
         n = A.N
         dest = self._tile_of[:n]
         tensors = self._per_agent_tensors(action)
-        if comm.size == 1:
-            return
+        arrs, ptrs, esz = self._record_arrays(tensors)
+        sp = stream_ptr(self.device)
         lv_idx = torch.nonzero(dest != comm.rank, as_tuple=False).squeeze(1)
-        rec = torch.stack([t[:n][lv_idx].view(torch.int32) for t in tensors] +
-                          [A.alive[:n][lv_idx].to(torch.int32)])              # (F, L) 4-byte records
+        L = int(lv_idx.numel())
+        rec = torch.empty((len(arrs), L), dtype=torch.int32, device=self.device)
+        lib.check(lib.lib.die_records_gather(ptrs, esz, len(arrs), C.c_void_p(lv_idx.data_ptr()), L,
+                                             C.c_void_p(rec.data_ptr()), sp), 'die_records_gather')
         _, arrivals = route_records(rec, dest[lv_idx], comm)
         n_arr = int(arrivals.shape[1])
         mask = torch.zeros(max(n, 1), dtype=torch.bool, device=self.device)
         mask[lv_idx] = True
         n_new, arr_dst, mv_src, mv_dst = fill_holes(n, mask, n_arr)
         if n_new > self.capacity:
-            raise RuntimeError(f'rank {me}: {n_new} agents exceed the local capacity {self.capacity}')
-        views = tensors + [A.alive]
-        for k, t in enumerate(views):
-            if mv_src.numel():
-                t[mv_dst] = t[mv_src]
-            if n_arr:
-                col = arrivals[k]
-                t[arr_dst] = col.to(torch.uint8) if t.dtype == torch.uint8 else col.view(t.dtype)
+            raise RuntimeError(f'rank {comm.rank}: {n_new} agents exceed the local capacity {self.capacity}')
+        if mv_src.numel():
+            tmp = torch.empty((len(arrs), int(mv_src.numel())), dtype=torch.int32, device=self.device)
+            lib.check(lib.lib.die_records_gather(ptrs, esz, len(arrs), C.c_void_p(mv_src.data_ptr()), mv_src.numel(),
+                                                 C.c_void_p(tmp.data_ptr()), sp), 'die_records_gather')
+            lib.check(lib.lib.die_records_scatter(ptrs, esz, len(arrs), C.c_void_p(mv_dst.data_ptr()), mv_dst.numel(),
+                                                  C.c_void_p(tmp.data_ptr()), sp), 'die_records_scatter')
+        if n_arr:
+            arrivals = arrivals.contiguous()
+            lib.check(lib.lib.die_records_scatter(ptrs, esz, len(arrs), C.c_void_p(arr_dst.data_ptr()), n_arr,
+                                                  C.c_void_p(arrivals.data_ptr()), sp), 'die_records_scatter')
         A.N = n_new
         action.N = n_new
 

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 5
+#define DIE_ABI_VERSION 6
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -265,6 +265,24 @@ int64_t die_sort_workspace_bytes(int32_t W, int32_t H, int64_t N);
 int die_agents_sort(const die_medium* m, const die_agents* in, const die_agents* out, int32_t n_extra,
                     const float* const* extra_in, float* const* extra_out, void* workspace,
                     int64_t workspace_bytes, void* stream);
+
+/* ---- message packing for decomposed worlds (die_amd/dist.py; no reference counterpart) ----------
+ * A block [r0, r1) x [c0, c1) of a row-major plane (pitch in elements, 2/4/8-byte elements) copied
+ * to / from byte offset buf_offset of one contiguous message buffer; up to 16 blocks per launch. */
+typedef struct die_rect {
+    void* plane;
+    int32_t pitch, r0, r1, c0, c1, elem_bytes;
+    int64_t buf_offset;
+} die_rect;
+int die_rects_pack(const die_rect* rects, int32_t n, void* buf, void* stream);
+int die_rects_unpack(const die_rect* rects, int32_t n, const void* buf, void* stream);
+/* Agent records: word (k, j) of the (n, count) int32 matrix is element idx[j] of array k (4-byte
+ * arrays bit-copied, 1-byte arrays widened): migration packs leavers and writes arrivals with one
+ * launch each. */
+int die_records_gather(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int64_t* idx, int64_t count,
+                       int32_t* records_out, void* stream);
+int die_records_scatter(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int64_t* idx, int64_t count,
+                        const int32_t* records_in, void* stream);
 
 #ifdef __cplusplus
 }
