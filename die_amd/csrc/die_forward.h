@@ -56,6 +56,15 @@ __device__ __forceinline__ float renorm_rad(float r) {
     return r;
 }
 
+// np.angle(x + 1j*y) as numpy evaluates it (core/utils.py:158-169): 1j*y is (0·y − 0) + (0 + y)j and the
+// sum with x adds the real parts, so y = −0 becomes +0 and x = −0 survives only next to a negative y:
+// angle(−0, −0) = +π, every other pair of zeros gives 0.  Only exact zeros are affected.
+__device__ __forceinline__ float die_np_angle(float x, float y) {
+    const float re = x + (0.f * y - 0.f);
+    const float im = 0.f + (0.f + y);
+    return atan2f(im, re);
+}
+
 struct FwdOut {
     float dx, dy, dep, heading;
 };
@@ -98,7 +107,10 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
         ux = norm > 0.f ? gx / norm : 0.f;
         uy = norm > 0.f ? gy / norm : 0.f;
     }
-    if (a.grad_clip >= 0.f && !(norm >= a.grad_clip)) ux = uy = 0.f;   // gradient.py:64-66
+    // grad *= (norm >= grad_clip) (gradient.py:64-66): a masked component becomes a SIGNED zero, and
+    // np.angle(∓0 ∓0j) below is 0, −0, π or −π by quadrant — a sub-threshold gradient with gx < 0 is
+    // therefore NOT "undetermined" in the reference.  Keep the signs.
+    if (a.grad_clip >= 0.f && !(norm >= a.grad_clip)) { ux = copysignf(0.f, ux); uy = copysignf(0.f, uy); }
 
     float d_new = d;
     float dep_mask = 1.0f;
@@ -106,7 +118,7 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
     if (KIND == DIE_AGENT_PHYSARUM) {
         // _discrete_turn / _choose_turn (gradient.py:168-208)
         const float dr = sqrtf(ux * ux + uy * uy);
-        const float drads = atan2f(uy, ux);
+        const float drads = die_np_angle(ux, uy);
         const float delta = renorm_rad(d - drads);
         const float atol = a.turn_rad * a.rtol;
         const bool und_grad = fabsf(drads) <= 1e-8f + 1e-5f * fabsf(drads);
@@ -124,8 +136,8 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
         float s2, c2;
         die_sincos(d2, &s2, &c2);
         const float r = a.normalized ? 1.f : dr;
-        ux = r * c2;
-        uy = r * s2;
+        ux = r * c2 - 0.f * s2;                            // polar2xy: (r + 0j)·(cos + i·sin), zero signs included
+        uy = r * s2 + 0.f * c2;
         dep_mask = (und_grad || und_turn) ? 0.1f : 1.0f;   // clip(mask, .1, 1) (gradient.py:210-214)
         d_new = d2;
         heading_from_vector = !a.normalized;               // |g| may be 0 there: angle(0) = 0
@@ -148,8 +160,12 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
         uy = (1.f - a.inertia) * uy + a.inertia * oy + a.noise_scale * ny;
         heading_from_vector = true;
     }
+    else {                                                 // (1−0)·g + 0·prev + 0·noise: the sum ends with "+ (+0)", which turns −0 into +0
+        ux += 0.f;
+        uy += 0.f;
+    }
     if (a.pgx) { a.pgx[n] = ux; a.pgy[n] = uy; }
-    if (heading_from_vector) d_new = atan2f(uy, ux);          // get_radians (gradient.py:110)
+    if (heading_from_vector) d_new = die_np_angle(ux, uy);    // get_radians (gradient.py:110)
     FwdOut o;
     o.heading = d_new;
     o.dx = ux * a.scale;

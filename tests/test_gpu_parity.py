@@ -168,6 +168,47 @@ def test_physarum_forward_parity(die, W, H, N, cfg):
     assert bad.sum() <= max(3, 1e-4 * N), f'{bad.sum()} of {N} slots differ'
 
 
+@pytest.mark.parametrize('normalized', [True, False])
+@pytest.mark.parametrize('kind', ['physarum', 'gradient'])
+def test_sub_threshold_gradients_keep_their_sign(die, kind, normalized):
+    """`grad *= (norm >= grad_clip)` (core/agent/gradient.py:64-66) leaves SIGNED zeros, and
+    np.angle(∓0 ∓0j) is 0 / −0 / π / −π by quadrant: in the reference a faint gradient with gx < 0 is
+    not "undetermined" (found by scratch/fuzz_forward.py).  Field: tiny smooth chem (|grad| ≪ clip)
+    next to a live region and exactly flat patches."""
+    W, H, N = 64, 48, 6000
+    rs = np.random.RandomState(12)
+    medium, agents = random_state(W, H, N, N, rs)
+    medium[2][:, : H // 2] *= 1e-6                       # sub-threshold but non-zero gradients, all quadrants
+    medium[2] = f32(medium[2])
+    kw = dict(scale=0.01, sense_offset=0.03, normalized_grad=normalized, grad_clip=1e-5)
+    if kind == 'physarum':
+        kw.update(sense_angle=100)                     # 90° on the 30° lattice is an exact tie against drads = ±π
+        ref, dev = R.RefPhysarumAgent(N, seed=1, **kw), die.PhysarumAgent(max_agents=N, seed=1, **kw)
+    else:
+        kw.update(inertia=0.0, noise_scale=0.0)
+        ref, dev = R.RefGradientAgent(N, seed=1, **kw), die.GradientAgent(max_agents=N, seed=1, **kw)
+    dir0 = f32(ref._direction_rads)
+    ref._direction_rads = dir0.copy()
+    want = ref.forward((agents, medium))
+    env = die.Env.from_numpy(medium, agents)
+    dev.set_state(dir0)
+    got = dev.forward(env._get_current_obs).to_numpy()
+    bad = ~(np.isclose(got, want, rtol=RTOL, atol=1e-6 * kw['scale'] + 1e-9).all(axis=0))
+    ddir = np.abs(R.renormalize_radians(dev.direction_rads_numpy() - ref._direction_rads))
+    bad |= np.minimum(ddir, 2 * np.pi - ddir) > 1e-5
+    assert bad.mean() <= 1e-3, f'{bad.sum()} of {N} slots differ'
+    # the quirk itself is present in the sample: masked gradients that are not "undetermined"
+    if kind == 'physarum':
+        g = np.stack(np.gradient(medium[2]))
+        off = np.stack(R.polar2xy(kw['sense_offset'], dir0))
+        gg = g[:, R.cell(agents[0] + off[0], W), R.cell(agents[1] + off[1], H)]
+        faint = np.hypot(gg[0], gg[1]) < 1e-5
+        both_neg = faint & (gg[0] < 0) & (gg[1] < 0)        # angle(−0 −0j) = π: a "real" direction
+        mixed = faint & (gg[0] < 0) & (gg[1] > 0)            # angle(−0 +0j) = 0: undetermined
+        assert both_neg.sum() > 50 and mixed.sum() > 50
+        assert ref._deposit_mask[both_neg].mean() > 0.7 and ref._deposit_mask[mixed].mean() == 0
+
+
 def test_physarum_forward_with_reference_made_vectors(die, golden_dir):
     """The turn logic on device vs outputs of the reference's own _discrete_turn
     (tests/golden/ref_helpers.npz, case 0 = default parameters): build a chem field whose
