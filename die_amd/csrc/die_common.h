@@ -80,8 +80,14 @@ static inline die_geo die_geo_of(const die_medium* m) {
     g.ox = m->gW > 0 ? m->ox : 0; g.oy = m->gW > 0 ? m->oy : 0;
     return g;
 }
+// world cell → element of the local planes.  Clamped: in a decomposed world a slot can for one call sit
+// outside the tile that holds it (e.g. zeroed by the lifecycle, about to migrate); it must never turn
+// into an out-of-bounds access.  For periodic single-tile planes the clamps are no-ops.
 __device__ __forceinline__ int64_t die_local(const die_geo& g, int gx, int gy) {
-    return (int64_t)(gx - g.ox) * g.H + (gy - g.oy);
+    int lx = gx - g.ox, ly = gy - g.oy;
+    lx = lx < 0 ? 0 : (lx >= g.W ? g.W - 1 : lx);
+    ly = ly < 0 ? 0 : (ly >= g.H ? g.H - 1 : ly);
+    return (int64_t)lx * g.H + ly;
 }
 
 // ---- wave / block reductions -------------------------------------------------------------

@@ -442,6 +442,11 @@ class DistEnv:
         d = self._c_dynamics()
         m, a = self.medium.c_struct(), self._struct(A)
         if isinstance(action, PendingAction) and action.pending and action.agents is A and action.medium is self.medium:
+            # the halo must cover the probe: sense_offset is in units of the world, i.e. up to this many cells
+            reach = int(np.ceil(abs(float(action.g_struct.sense_offset)) * (max(g.gW, g.gH) - 1))) + 1 + self.R
+            if reach > g.h:
+                raise ValueError(f'probe reach {reach} cells exceeds the halo {g.h}: build DistEnv with probe_reach >= '
+                                 f'{reach - 1 - self.R}')
             u = action.raw_struct()                     # forward runs fused with the move half
             lib.check(lib.lib.die_forward_move(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u), C.byref(d),
                                                g.Wi, g.Hi, g.Py, _ptr(self._tile_of), sp), 'die_forward_move')
@@ -467,6 +472,15 @@ class DistEnv:
                       'die_step_reduce_ex')
         else:
             result.zero_()
+        if self.dynamics.agents_die and self.comm.size > 1:
+            # the lifecycle zeroes every channel of a starved slot: it now stands on world cell (0, 0), which
+            # belongs to rank 0 — send it there before the next forward() senses from that position
+            n = A.N
+            self._tile_of[:n] = self.comm.rank
+            if n:
+                gone = (A.x[:n] == 0) & (A.y[:n] == 0)
+                self._tile_of[:n][gone] = 0
+            self._migrate(action)
         # the field sweep applies deposits on load, so it needs chem AND claims of the halo
         M = self.medium
         if self._chem_halo_in_flight:

@@ -1,0 +1,93 @@
+"""Randomised decomposed-vs-single-device equality (ranks share the GPU, gloo)."""
+import os, sys, socket, tempfile; sys.path.insert(0, '.')
+import numpy as np, torch
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0)); return s.getsockname()[1]
+
+def make_case(seed):
+    rs = np.random.RandomState(seed)
+    grid = [(1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (1, 3), (3, 1)][rs.randint(7)]
+    Wi = int(rs.choice([48, 64, 80])); Hi = int(rs.choice([44, 64, 96]))
+    W, H = Wi * grid[0], Hi * grid[1]
+    N = int(rs.choice([500, 3000])); K = int(N * rs.choice([0.6, 1.0]))
+    agent = rs.choice(['physarum', 'brownian', 'gradient'])
+    boundary = rs.choice(['wrap', 'limit'])
+    die = bool(rs.rand() < 0.3)
+    return dict(grid=grid, W=W, H=H, N=N, K=K, agent=str(agent), boundary=str(boundary), agents_die=die, steps=8,
+                sort_every=int(rs.choice([0, 2])), seed=seed)
+
+def build(case, die_amd):
+    from tests.test_gpu_parity import random_state, f32
+    rs = np.random.RandomState(case['seed'] + 1000)
+    medium, agents = random_state(case['W'], case['H'], case['N'], case['K'], rs, collide=0.2)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, case['N']) / turn) * turn)
+    prev = f32(rs.normal(0, .4, (2, case['N'])))
+    dyn = die_amd.Dynamics(boundary=die_amd.BoundaryCondition(case['boundary']), agents_die=case['agents_die'])
+    return medium, agents, dir0, prev, dyn
+
+def make_agent(case, die_amd, n_slots):
+    W = case['W']
+    if case['agent'] == 'physarum':
+        return die_amd.PhysarumAgent(max_agents=n_slots, seed=9, scale=1.53 / (W - 1), sense_offset=6.2 / (W - 1), sense_angle=100)
+    if case['agent'] == 'gradient':
+        return die_amd.GradientAgent(max_agents=n_slots, seed=9, scale=0.01, sense_offset=0.03, inertia=0.9, noise_scale=0.025)
+    return die_amd.BrownianAgent(move_scale=0.3, deposit_scale=0.5, seed=9)      # jumps across several tiles
+
+def worker(rank, size, port, case, out):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        import die_amd
+        from die_amd.dist import DistEnv
+        medium, agents, dir0, prev, dyn = build(case, die_amd)
+        env = DistEnv.from_global_numpy(medium, agents, case['grid'], dyn, probe_reach=int(np.ceil(max(6.2 / (case['W'] - 1), 0.03) * (max(case['W'], case['H']) - 1))), device='cuda:0', sort_every=case['sort_every'],
+                                        capacity=case['N'] + 64)
+        ag = make_agent(case, die_amd, env.capacity)
+        if case['agent'] != 'brownian':
+            sl = env.local_slots()
+            d = torch.zeros(env.capacity, dtype=torch.float32, device='cuda:0'); d[:env.agents.N] = torch.from_numpy(dir0.astype(np.float32)).cuda()[sl]
+            p = None
+            if case['agent'] == 'gradient':
+                p = torch.zeros((2, env.capacity), dtype=torch.float32, device='cuda:0'); p[:, :env.agents.N] = torch.from_numpy(prev.astype(np.float32)).cuda()[:, sl]
+            ag.set_state_local(env.agents, d, p)
+        obs = env._get_current_obs
+        for _ in range(case['steps']):
+            obs, res = env.step(ag.forward(obs))
+        world = env.gather_world()
+        if rank == 0:
+            np.savez(out, medium=world[0], agents=world[1])
+    finally:
+        dist.destroy_process_group()
+
+if __name__ == '__main__':
+    import torch.multiprocessing as mp
+    import die_amd
+    fails = 0
+    for seed in range(int(os.environ.get('FUZZ_FIRST', '0')), int(os.environ.get('FUZZ_FIRST', '0')) + int(os.environ.get('FUZZ_CASES', '8'))):
+        case = make_case(seed)
+        out = os.path.join(tempfile.gettempdir(), f'fd_{seed}.npz')
+        size = case['grid'][0] * case['grid'][1]
+        try:
+            mp.spawn(worker, args=(size, free_port(), case, out), nprocs=size, join=True)
+            got = np.load(out)
+            medium, agents, dir0, prev, dyn = build(case, die_amd)
+            env = die_amd.Env.from_numpy(medium, agents, dyn, sort_every=0)
+            ag = make_agent(case, die_amd, case['N'])
+            if case['agent'] != 'brownian':
+                ag.set_state(dir0, prev if case['agent'] == 'gradient' else None)
+            obs = env._get_current_obs
+            for _ in range(case['steps']):
+                obs, *_ = env.step(ag.forward(obs))
+            m, a = env.medium.to_numpy(), env.agents.to_numpy()
+            if case['boundary'] == 'limit':
+                assert np.abs(got['agents'][:2] - a[:2]).max() == 0
+            assert np.array_equal(got['agents'], a), 'agents'
+            assert np.array_equal(got['medium'], m), 'medium'
+            print('ok  ', case, flush=True)
+        except Exception as e:
+            fails += 1; print('FAIL', case, type(e).__name__, str(e)[:300], flush=True)
+    print(f'fuzz dist: {fails} failures', flush=True)

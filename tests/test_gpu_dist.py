@@ -84,3 +84,76 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     r = np.array(rewards)
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
     assert np.allclose(got['rewards'][:, 0], r[:, 0], rtol=1e-12, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# regression cases found by scratch/fuzz_dist.py: starved slots (agents_die) jump to world cell (0, 0) and must
+# be re-homed before the next forward(); Brownian agents jump across several tiles (general routing); 'limit'.
+def _case_state(case):
+    import die_amd
+    from tests.test_gpu_parity import f32, random_state
+    rs = np.random.RandomState(case['seed'])
+    medium, agents = random_state(case['W'], case['H'], case['N'], case['K'], rs, collide=0.2)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, case['N']) / turn) * turn)
+    dyn = die_amd.Dynamics(boundary=die_amd.BoundaryCondition(case['boundary']), agents_die=case['agents_die'])
+    return medium, agents, dir0, dyn
+
+
+def _case_agent(case, n_slots):
+    import die_amd
+    if case['agent'] == 'physarum':
+        return die_amd.PhysarumAgent(max_agents=n_slots, seed=9, scale=1.53 / (case['W'] - 1), sense_offset=6.2 / (case['W'] - 1),
+                                     sense_angle=100)
+    return die_amd.BrownianAgent(move_scale=0.3, deposit_scale=0.5, seed=9)
+
+
+def _case_worker(rank, size, port, case, out_path):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        from die_amd.dist import DistEnv
+        medium, agents, dir0, dyn = _case_state(case)
+        reach = int(np.ceil(6.2 / (case['W'] - 1) * (max(case['W'], case['H']) - 1)))
+        env = DistEnv.from_global_numpy(medium, agents, case['grid'], dyn, probe_reach=reach, device='cuda:0',
+                                        sort_every=case['sort_every'], capacity=case['N'] + 64)
+        ag = _case_agent(case, env.capacity)
+        if case['agent'] == 'physarum':
+            local = torch.zeros(env.capacity, dtype=torch.float32, device='cuda:0')
+            local[:env.agents.N] = torch.from_numpy(dir0.astype(np.float32)).cuda()[env.local_slots()]
+            ag.set_state_local(env.agents, local)
+        obs = env._get_current_obs
+        for _ in range(case['steps']):
+            obs, res = env.step(ag.forward(obs))
+        world = env.gather_world()
+        if rank == 0:
+            np.savez(out_path, medium=world[0], agents=world[1])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', [
+    dict(grid=(1, 2), W=48, H=88, N=500, K=300, agent='physarum', boundary='wrap', agents_die=True, steps=8, sort_every=0, seed=100),
+    dict(grid=(1, 3), W=32, H=96, N=3000, K=3000, agent='brownian', boundary='limit', agents_die=True, steps=6, sort_every=2, seed=1),
+], ids=['starved-slots-rehomed', 'brownian-jumps-limit'])
+def test_decomposed_regressions(tmp_path, case):
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    import die_amd
+    out = str(tmp_path / 'case.npz')
+    size = case['grid'][0] * case['grid'][1]
+    mp.spawn(_case_worker, args=(size, _free_port(), case, out), nprocs=size, join=True)
+    got = np.load(out)
+    medium, agents, dir0, dyn = _case_state(case)
+    env = die_amd.Env.from_numpy(medium, agents, dyn, sort_every=0)
+    ag = _case_agent(case, case['N'])
+    if case['agent'] == 'physarum':
+        ag.set_state(dir0)
+    obs = env._get_current_obs
+    for _ in range(case['steps']):
+        obs, *_ = env.step(ag.forward(obs))
+    assert np.array_equal(got['agents'], env.agents.to_numpy())
+    assert np.array_equal(got['medium'], env.medium.to_numpy())
