@@ -9,7 +9,10 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdie_hip.so')
 SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip', 'die_pack.hip']
 HEADERS = ['die_common.h', 'die_rng.h', 'die_forward.h', os.path.join('..', '..', 'include', 'die_hip.h')]
-FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+# -ffp-contract=on: fuse a*b+c only inside one source expression.  hipcc's default (fast) fuses across
+# statements, so the same inlined device function could round differently in two kernels (the fused and the
+# stand-alone forward must give identical bits: scratch/fuzz_paths.py).
+FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-ffp-contract=on', '-Wall', '-Wno-unused-function']
 
 
 def _hipcc():
