@@ -11,7 +11,7 @@ SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip', 'die
 HEADERS = ['die_common.h', 'die_rng.h', 'die_forward.h', os.path.join('..', '..', 'include', 'die_hip.h')]
 # -ffp-contract=on: fuse a*b+c only inside one source expression.  hipcc's default (fast) fuses across
 # statements, so the same inlined device function could round differently in two kernels (the fused and the
-# stand-alone forward must give identical bits: scratch/fuzz_paths.py).
+# stand-alone forward must give identical bits: tests/fuzz_cases.py fuzz_paths).
 FLAGS = ['-O3', '--offload-arch=gfx950', '-fPIC', '-std=c++17', '-ffp-contract=on', '-Wall', '-Wno-unused-function']
 
 

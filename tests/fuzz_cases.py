@@ -1,0 +1,158 @@
+"""Randomised parity sweeps (GPU vs oracle, and device paths vs each other).  `python -m tests.fuzz_cases
+step|forward|paths|init [cases] [seed]` runs a long sweep; tests/test_gpu_fuzz.py runs short ones."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+import die_amd
+from oracle import cpu_ref as R
+from tests.test_gpu_parity import f32, quantised_action, random_state, ref_dyn
+
+
+def fuzz_step(n_cases=100, seed=0, verbose=True):
+    rs = np.random.RandomState(seed)
+    fails = 0
+    skipped = 0
+    for case in range(n_cases):
+        W = int(rs.choice([2, 3, 4, 5, 7, 8, 12, 16, 31, 32, 33, 64, 100, 128, 250, 256]))
+        H = int(rs.choice([2, 3, 4, 8, 12, 16, 20, 36, 60, 64, 128, 244, 248, 252, 256, 260, 500, 512]))
+        N = int(rs.choice([1, 2, 5, 64, 257, 1000, 4096, 20000]))
+        K = int(rs.randint(0, N + 1))
+        sigma = float(rs.choice([0.3, 0.5, 0.8, 1.0, 1.2]))
+        dyn = die_amd.Dynamics(boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])), food_infinite=bool(rs.rand() < 0.2),
+                               agents_die=bool(rs.rand() < 0.2), op_action_cost=die_amd.zero_cost if rs.rand() < 0.2 else die_amd.linear_action_cost,
+                               diffuse_sigma=sigma, rate_feed=float(rs.choice([0.1, 0.5])), rate_decay_chem=float(rs.choice([0.0, 0.1, 0.3])))
+        sort_every = int(rs.choice([0, 1]))
+        try:
+            medium, agents = random_state(W, H, N, K, rs, collide=float(rs.choice([0.0, 0.3, 0.9])))
+            action = quantised_action(N, rs, float(rs.choice([0.5 / max(W, H), 3.0 / max(W, H), 0.4])))
+            rd = ref_dyn(dyn)
+            for f in ('rate_feed', 'rate_decay_chem', 'diffuse_sigma'):
+                setattr(rd, f, float(np.float32(getattr(rd, f))))
+            ref = R.RefEnv(medium, agents, rd)
+            env = die_amd.Env.from_numpy(medium, agents, dyn, sort_every=sort_every)
+            for step in range(2):
+                _, want_r, want_t, _, want_i = ref.step(action)
+                _, r, t, _, i = env.step(action)
+            ga, gm = env.agents.to_numpy(), env.medium.to_numpy()
+            tol_xy = 2.0 ** -32 if dyn.boundary.value == 'limit' else 0.0
+            assert np.abs(ga[:2] - ref.agents[:2]).max() <= tol_xy, 'xy'
+            assert np.array_equal(ga[2], ref.agents[2]), 'alive'
+            assert np.array_equal(gm[0], ref.medium[0]), 'agents channel'
+            assert i['num_agents'] == want_i['num_agents'] and t == want_t, 'info'
+            assert np.allclose(ga[3], ref.agents[3], rtol=1e-5, atol=2e-7), 'agent_food'
+            assert np.allclose(gm[1], ref.medium[1], rtol=1e-5, atol=1e-8), 'food'
+            assert np.allclose(gm[2], ref.medium[2], rtol=2e-5, atol=2e-7), 'chem'
+            assert abs(r - want_r) <= 1e-5 * np.abs(ref.last_gained).sum() + 1e-9, 'reward'
+        except NotImplementedError as e:
+            skipped += 1
+            continue
+        except Exception as e:
+            fails += 1
+            print(f'CASE {case} FAILED W={W} H={H} N={N} K={K} sigma={sigma} dyn={dyn} sort={sort_every}: {type(e).__name__} {e}', flush=True)
+            if fails > 10:
+                break
+    return fails
+
+
+def fuzz_forward(n_cases=100, seed=0, verbose=True):
+    rs = np.random.RandomState(seed)
+    fails = 0
+    worst = 0.0
+    for case in range(n_cases):
+        W = int(rs.choice([2, 5, 16, 33, 64, 200])); H = int(rs.choice([2, 7, 12, 64, 130, 256]))
+        N = int(rs.choice([1, 50, 3000, 20000]))
+        medium, agents = random_state(W, H, N, int(0.7 * N), rs)
+        phys = rs.rand() < 0.6
+        kw = dict(scale=float(rs.choice([0.001, 0.01, 0.05])), deposit=float(rs.choice([1.0, 4.0, 4.5])),
+                  sense_offset=float(rs.choice([0.0, 0.01, 0.04, 0.3])), normalized_grad=bool(rs.rand() < 0.8),
+                  grad_clip=None if rs.rand() < 0.2 else float(rs.choice([1e-5, 1e-3])))
+        if phys:
+            kw.update(turn_angle=int(rs.choice([20, 30, 35, 45])), sense_angle=int(rs.choice([60, 100, 120])), turn_tolerance=float(rs.choice([0.05, 0.1, 0.2])),
+                      inertia=float(rs.choice([0.0, 0.0, 0.5])), noise_scale=float(rs.choice([0.0, 0.0, 0.02])))
+            ref = R.RefPhysarumAgent(N, seed=case, **kw); dev = die_amd.PhysarumAgent(max_agents=N, seed=case, **kw)
+        else:
+            kw.update(inertia=float(rs.choice([0.0, 0.9])), noise_scale=float(rs.choice([0.0, 0.025])))
+            ref = R.RefGradientAgent(N, seed=case, **kw); dev = die_amd.GradientAgent(max_agents=N, seed=case, **kw)
+        prev = f32(rs.normal(0, .4, (2, N)))
+        ref._prev_grad = prev.copy()
+        dir0 = f32(ref._direction_rads); ref._direction_rads = dir0.copy()
+        want = ref.forward((agents, medium))
+        env = die_amd.Env.from_numpy(medium, agents)
+        dev.set_state(dir0, prev if kw['inertia'] else None)
+        got = dev.forward(env._get_current_obs).to_numpy()
+        atol = 1e-6 * kw['scale'] + 1e-9
+        bad = ~(np.isclose(got[0], want[0], rtol=1e-5, atol=atol) & np.isclose(got[1], want[1], rtol=1e-5, atol=atol) & np.isclose(got[2], want[2], rtol=1e-5, atol=1e-8))
+        frac = bad.mean(); worst = max(worst, frac if N >= 3000 else 0)
+        if bad.sum() > max(3, 3e-3 * N):
+            fails += 1
+            print(f'CASE {case} W={W} H={H} N={N} phys={phys} kw={kw}: {bad.sum()} bad of {N}', flush=True)
+    return fails
+
+
+def fuzz_paths(n_cases=100, seed=0, verbose=True):
+    rs = np.random.RandomState(seed)
+    fails = 0
+    for case in range(n_cases):
+        W = int(rs.choice([4, 16, 33, 64, 128])); H = int(rs.choice([4, 8, 12, 64, 244, 252, 256]))
+        N = int(rs.choice([5, 300, 4000])); K = int(rs.randint(0, N + 1))
+        medium, agents = random_state(W, H, N, K, rs, collide=float(rs.choice([0.0, 0.5])))
+        dyn = dict(boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])), agents_die=bool(rs.rand() < 0.3), food_infinite=bool(rs.rand() < 0.2),
+                   diffuse_sigma=float(rs.choice([0.5, 0.8])))
+        phys = rs.rand() < 0.7
+        turn = np.radians(30); dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn); prev = f32(rs.normal(0, .4, (2, N)))
+        outs = []
+        for variant in ('default', 'DIE_NO_FUSED_STEP', 'DIE_STORE_CLAIM', 'eager', 'sorted'):
+            if variant.startswith('DIE_'): os.environ[variant] = '1'
+            env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=1 if variant == 'sorted' else 0)
+            if phys: ag = die_amd.PhysarumAgent(max_agents=N, seed=3, scale=2.0 / max(W, H), sense_offset=0.05)
+            else: ag = die_amd.GradientAgent(max_agents=N, seed=3, scale=0.01, sense_offset=0.03, inertia=0.8, noise_scale=0.02)
+            ag.set_state(dir0, None if phys else prev)
+            ag.lazy = variant != 'eager'
+            obs = env._get_current_obs
+            for _ in range(4):
+                obs, *_ = env.step(ag.forward(obs))
+            outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy()))
+            if variant.startswith('DIE_'): del os.environ[variant]
+        for v, o in zip(('staged', 'store-claim', 'eager', 'sorted'), outs[1:]):
+            for a, b in zip(outs[0], o):
+                if not np.array_equal(a, b):
+                    fails += 1; print(f'CASE {case} variant {v} differs: W={W} H={H} N={N} K={K} phys={phys} dyn={dyn}', flush=True); break
+    return fails
+
+
+def fuzz_init(n_cases=100, seed=0, verbose=True):
+    rs = np.random.RandomState(seed)
+    fails = 0
+    for case in range(n_cases):
+        W = int(rs.choice([2, 3, 17, 64, 100, 255, 256, 513])); H = int(rs.choice([2, 5, 12, 64, 127, 128, 300, 1024]))
+        ratio = float(rs.choice([0.0, 0.001, 0.05, 0.15, 0.5, 1.0])); seed = int(rs.randint(0, 2 ** 31)) * int(rs.choice([1, 2 ** 20 + 7]))
+        try:
+            want_m, want_a = R.synthetic_init(W, H, ratio, seed)
+            K = int(want_m[0].sum())
+            if K == 0:
+                continue
+            env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=ratio), seed=seed)
+            m, a = env.medium.to_numpy(), env.agents.to_numpy()
+            assert np.array_equal(m[0], want_m[0]), 'seeding'
+            assert env._num_seeded == K
+            assert np.abs(a[:2] - want_a[:2]).max() <= 2.0 ** -32, 'xy'
+            assert np.array_equal(a[2], want_a[2]) and np.allclose(a[3], want_a[3], rtol=1e-6), 'alive/food'
+            d = np.abs(m[1] - want_m[1]); assert (d > 1e-6).mean() <= 1e-4 and d.max() <= 1.001e-3, 'food field'
+            ag = die_amd.PhysarumAgent(max_agents=W * H, seed=seed); ag._alloc_state('cuda:0')
+            ref = R.RefPhysarumAgent(W * H, seed=seed)
+            assert np.mean(np.abs(ag.direction_rads_numpy() - ref._direction_rads) > 1e-6) <= 2e-4, 'heading'
+        except Exception as e:
+            fails += 1; print(f'CASE {case} W={W} H={H} ratio={ratio} seed={seed}: {type(e).__name__} {e}', flush=True)
+    return fails
+
+
+
+if __name__ == '__main__':
+    which = sys.argv[1] if len(sys.argv) > 1 else 'step'
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init}[which](n, seed)
+    print(f'{which}: {n} cases, {f} failures')

@@ -173,7 +173,7 @@ def test_physarum_forward_parity(die, W, H, N, cfg):
 def test_sub_threshold_gradients_keep_their_sign(die, kind, normalized):
     """`grad *= (norm >= grad_clip)` (core/agent/gradient.py:64-66) leaves SIGNED zeros, and
     np.angle(∓0 ∓0j) is 0 / −0 / π / −π by quadrant: in the reference a faint gradient with gx < 0 is
-    not "undetermined" (found by scratch/fuzz_forward.py).  Field: tiny smooth chem (|grad| ≪ clip)
+    not "undetermined" (found by tests/fuzz_cases.py fuzz_forward).  Field: tiny smooth chem (|grad| ≪ clip)
     next to a live region and exactly flat patches."""
     W, H, N = 64, 48, 6000
     rs = np.random.RandomState(12)
