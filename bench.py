@@ -34,6 +34,7 @@ def parse():
     p.add_argument('--kernel-reps', type=int, default=20)
     p.add_argument('--sort-every', type=int, default=8)
     p.add_argument('--fields', choices=['f32', 'f16'], default='f32', help='dtype of the field channels (configs[4] uses f16)')
+    p.add_argument('--migrate-every', type=int, default=8, help='decomposed runs: hand strays over every M steps (1 = every step)')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
@@ -172,10 +173,13 @@ def main():
             from die_amd.dist import DistEnv
             gW, gH = W * grid[0], H * grid[1]
             # same cell-unit parameters as the single-GPU workload (10.2-cell probe, 1.53-cell step)
-            agent_kw.update(scale=1.53 / (gW - 1), sense_offset=10.2 / (gW - 1))
+            # (a non-square world is anisotropic in cells, offsets being fractions of the unit square: size them on the longer axis)
+            agent_kw.update(scale=1.53 / (max(gW, gH) - 1), sense_offset=10.2 / (max(gW, gH) - 1))
             denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
-                           device=device, seed=args.seed, sort_every=args.sort_every)
-            mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, halo {denv.geo.h}, '
+                           device=device, seed=args.seed, sort_every=args.sort_every,
+                           migrate_every=args.migrate_every, max_step_cells=1.6)
+            mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, halo {denv.geo.h}, strays handed over every '
+                    f'{denv.migrate_every} steps, '
                     f'{"RCCL" if backend == "nccl" else backend} point-to-point')
         except Exception as e:           # keep the scaling run alive: independent replicas, and say so
             denv = None

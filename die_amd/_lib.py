@@ -17,7 +17,7 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class Medium(C.Structure):
@@ -74,6 +74,8 @@ _SIGNATURES = {
                                C.c_void_p]),
     'die_forward_env_step': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_forward_move_claim_tile': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
+                                              C.c_int64, C.c_void_p]),
     'die_env_step_finish': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64,
                                       C.c_void_p]),
     'die_forward_move_claim': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
@@ -103,6 +105,7 @@ _SIGNATURES = {
     'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
     'die_rects_pack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_rects_unpack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
+    'die_rects_unpack_max': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_records_gather': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_records_scatter': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),

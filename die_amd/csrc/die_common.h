@@ -80,11 +80,14 @@ static inline die_geo die_geo_of(const die_medium* m) {
     g.ox = m->gW > 0 ? m->ox : 0; g.oy = m->gW > 0 ? m->oy : 0;
     return g;
 }
-// world cell → element of the local planes.  Clamped: in a decomposed world a slot can for one call sit
-// outside the tile that holds it (e.g. zeroed by the lifecycle, about to migrate); it must never turn
-// into an out-of-bounds access.  For periodic single-tile planes the clamps are no-ops.
+// world cell → element of the local planes.  In a decomposed world the halo holds periodic images, so a
+// cell on the far side of the world's seam maps into the halo (gx − ox modulo gW); then clamped: a slot can
+// for one call sit outside the tile that holds it (zeroed by the lifecycle, about to migrate) and must never
+// turn into an out-of-bounds access.  For periodic single-tile planes all of this is a no-op.
 __device__ __forceinline__ int64_t die_local(const die_geo& g, int gx, int gy) {
     int lx = gx - g.ox, ly = gy - g.oy;
+    lx = lx >= g.W ? lx - g.gW : (lx < 0 ? lx + g.gW : lx);      // beyond the planes: try the periodic image
+    ly = ly >= g.H ? ly - g.gH : (ly < 0 ? ly + g.gH : ly);
     lx = lx < 0 ? 0 : (lx >= g.W ? g.W - 1 : lx);
     ly = ly < 0 ? 0 : (ly >= g.H ? g.H - 1 : ly);
     return (int64_t)lx * g.H + ly;

@@ -739,18 +739,18 @@ extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_
     return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
 }
 
-extern "C" int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
-                                      const die_dynamics* d, void* ws, int64_t ws_bytes, void* stream) {
-    DIE_REQUIRE(m && a && g && act && d, "die_forward_move_claim: null argument");
-    if (!fused_step_applies(m, d)) {       // it is the first half of the fused step: refuse before touching anything
-        die_set_error("die_forward_move_claim: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+static int forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                              const die_dynamics* d, void* ws, int64_t ws_bytes, void* stream, bool tile_ok, const char* who) {
+    DIE_REQUIRE(m && a && g && act && d, "%s: null argument", who);
+    if (!tile_ok && !fused_step_applies(m, d)) {   // first half of the fused step: refuse before touching anything
+        die_set_error("%s: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4", who);
         return DIE_ERR_UNSUPPORTED;
     }
     FwdArgs f;
-    int rc = die_fill_fwd_args(f, m, a, g, act, "die_forward_move_claim");
+    int rc = die_fill_fwd_args(f, m, a, g, act, who);
     if (rc != DIE_OK) return rc;
     StepArgs k;
-    rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_forward_move_claim");
+    rc = fill_args(k, m, a, act, d, ws, ws_bytes, who);
     if (rc != DIE_OK) return rc;
     k.part_gain = (double*)ws;
     const int grid = step_grid(a->N);
@@ -763,8 +763,19 @@ extern "C" int die_forward_move_claim(const die_medium* m, const die_agents* a, 
         else k_forward_move_claim<__half, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
     }
     if (k.claim_by_store) k_claim_fix<<<grid, DIE_BLOCK, 0, s>>>(k);
-    DIE_CHECK_LAUNCH("die_forward_move_claim");
+    DIE_CHECK_LAUNCH(who);
     return DIE_OK;
+}
+
+extern "C" int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                      const die_dynamics* d, void* ws, int64_t ws_bytes, void* stream) {
+    return forward_move_claim(m, a, g, act, d, ws, ws_bytes, stream, false, "die_forward_move_claim");
+}
+
+extern "C" int die_forward_move_claim_tile(const die_medium* m, const die_agents* a, die_gradient_agent* g,
+                                           const die_action* act, const die_dynamics* d, void* ws, int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(m && m->gW > 0, "die_forward_move_claim_tile: the planes must be a tile of a decomposed world");
+    return forward_move_claim(m, a, g, act, d, ws, ws_bytes, stream, true, "die_forward_move_claim_tile");
 }
 
 extern "C" int die_env_step_finish(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
@@ -798,7 +809,7 @@ static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int 
     DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad dtype %d", who, m->dtype);
     DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "%s: bad epoch %d", who, m->epoch);
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    if (!(rows_kernel_applies(m->W, m->H, R) && R >= 1 && (!tile || (m->H >= 8 && m->W >= 2 * R + 1 && halo >= R)))) {
+    if (!(rows_kernel_applies(m->W, m->H, R) && R >= 1 && (!tile || (m->H >= 8 && m->W >= 2 * R + 1 && halo >= 0)))) {
         die_set_error("%s: needs H %% 4 == 0 and radius 1..4 (W=%d H=%d sigma=%g halo=%d)", who, m->W, m->H,
                       (double)d->diffuse_sigma, halo);
         return DIE_ERR_UNSUPPORTED;

@@ -14,7 +14,8 @@ struct RectArgs {
     char* buf;
 };
 
-template <bool PACK>
+// MODE 0: plane → buffer, 1: buffer → plane, 2: plane = max(plane, buffer) on unsigned 64-bit words (claim merge)
+template <int MODE>
 __global__ __launch_bounds__(DIE_BLOCK) void k_rects(RectArgs a) {
     const int64_t total = a.first[a.n];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -25,13 +26,16 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_rects(RectArgs a) {
         const int r = (int)(e / a.cols[k]), c = (int)(e - (int64_t)r * a.cols[k]);
         char* p = a.plane[k] + ((int64_t)(a.r0[k] + r) * a.pitch[k] + a.c0[k] + c) * a.esz[k];
         char* b = a.buf + a.boff[k] + e * a.esz[k];
-        if (a.esz[k] == 8) { if (PACK) *(uint64_t*)b = *(const uint64_t*)p; else *(uint64_t*)p = *(const uint64_t*)b; }
-        else if (a.esz[k] == 4) { if (PACK) *(uint32_t*)b = *(const uint32_t*)p; else *(uint32_t*)p = *(const uint32_t*)b; }
-        else { if (PACK) *(uint16_t*)b = *(const uint16_t*)p; else *(uint16_t*)p = *(const uint16_t*)b; }
+        if (MODE == 2) {
+            // blocks of one message may overlap (a corner band lies inside two edge bands): atomic
+            atomicMax((unsigned long long*)p, *(const unsigned long long*)b);
+        } else if (a.esz[k] == 8) { if (MODE == 0) *(uint64_t*)b = *(const uint64_t*)p; else *(uint64_t*)p = *(const uint64_t*)b; }
+        else if (a.esz[k] == 4) { if (MODE == 0) *(uint32_t*)b = *(const uint32_t*)p; else *(uint32_t*)p = *(const uint32_t*)b; }
+        else { if (MODE == 0) *(uint16_t*)b = *(const uint16_t*)p; else *(uint16_t*)p = *(const uint16_t*)b; }
     }
 }
 
-static int rects(const die_rect* r, int32_t n, void* buf, bool pack, void* stream, const char* who) {
+static int rects(const die_rect* r, int32_t n, void* buf, int mode, void* stream, const char* who) {
     DIE_REQUIRE(r && buf && n >= 1 && n <= DIE_PACK_MAX, "%s: 1..%d blocks", who, DIE_PACK_MAX);
     RectArgs a;
     a.n = n; a.buf = (char*)buf; a.first[0] = 0;
@@ -47,14 +51,18 @@ static int rects(const die_rect* r, int32_t n, void* buf, bool pack, void* strea
     for (int k = n; k < DIE_PACK_MAX; ++k) { a.plane[k] = nullptr; a.pitch[k] = a.r0[k] = a.c0[k] = a.cols[k] = a.esz[k] = 0; a.boff[k] = 0; a.first[k + 1] = a.first[n]; }
     int64_t g = (a.first[n] + DIE_BLOCK - 1) / DIE_BLOCK;
     const int grid = (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
-    if (pack) k_rects<true><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
-    else k_rects<false><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    if (mode == 2)
+        for (int k = 0; k < n; ++k) DIE_REQUIRE(a.esz[k] == 8, "%s: max-merge is for 8-byte claim words", who);
+    if (mode == 0) k_rects<0><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    else if (mode == 1) k_rects<1><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
+    else k_rects<2><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
     DIE_CHECK_LAUNCH(who);
     return DIE_OK;
 }
 
-extern "C" int die_rects_pack(const die_rect* r, int32_t n, void* buf, void* stream) { return rects(r, n, buf, true, stream, "die_rects_pack"); }
-extern "C" int die_rects_unpack(const die_rect* r, int32_t n, const void* buf, void* stream) { return rects(r, n, (void*)buf, false, stream, "die_rects_unpack"); }
+extern "C" int die_rects_pack(const die_rect* r, int32_t n, void* buf, void* stream) { return rects(r, n, buf, 0, stream, "die_rects_pack"); }
+extern "C" int die_rects_unpack(const die_rect* r, int32_t n, const void* buf, void* stream) { return rects(r, n, (void*)buf, 1, stream, "die_rects_unpack"); }
+extern "C" int die_rects_unpack_max(const die_rect* r, int32_t n, const void* buf, void* stream) { return rects(r, n, (void*)buf, 2, stream, "die_rects_unpack_max"); }
 
 struct RecArgs {
     int n;

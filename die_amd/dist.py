@@ -59,6 +59,44 @@ class TileGeometry:
     def interior(self) -> Tuple[slice, slice]:
         return slice(self.h, self.h + self.Wi), slice(self.h, self.h + self.Hi)
 
+    DIRS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]     # sorted: negation reverses it
+
+    def _band(self, dx, dy):
+        """Interior cells adjacent to side (dx, dy) — what the neighbour on that side needs as its halo."""
+        h, Wi, Hi = self.h, self.Wi, self.Hi
+        rows = {-1: slice(h, 2 * h), 0: slice(h, h + Wi), 1: slice(Wi, Wi + h)}[dx]
+        cols = {-1: slice(h, 2 * h), 0: slice(h, h + Hi), 1: slice(Hi, Hi + h)}[dy]
+        return rows, cols
+
+    def _halo(self, dx, dy):
+        """Halo cells on side (dx, dy) (edge strips exclude the corners, which are their own blocks)."""
+        h, Wi, Hi, W, H = self.h, self.Wi, self.Hi, self.W, self.H
+        rows = {-1: slice(0, h), 0: slice(h, h + Wi), 1: slice(h + Wi, W)}[dx]
+        cols = {-1: slice(0, h), 0: slice(h, h + Hi), 1: slice(h + Hi, H)}[dy]
+        return rows, cols
+
+    def plan8(self):
+        """One-phase exchange with all 8 neighbours: [(peer, send_view)] in DIRS order and [(peer, recv_view)] in
+        reversed DIRS order.  The message sent towards s is the one the peer receives for its side −s, and
+        reversing the receive order makes the k-th send to a peer meet the k-th receive posted for it, also when
+        one rank is the neighbour on several sides (2-rank axes, self-neighbours)."""
+        sends = [(self.neighbour(dx, dy), self._band(dx, dy)) for dx, dy in self.DIRS]
+        recvs = [(self.neighbour(dx, dy), self._halo(dx, dy)) for dx, dy in reversed(self.DIRS)]
+        return sends, recvs
+
+    def reverse_plan8(self):
+        """Claim merge in one phase: every halo block goes to the rank that owns those cells and is max-merged
+        into the matching interior band there."""
+        sends = [(self.neighbour(dx, dy), self._halo(dx, dy)) for dx, dy in self.DIRS]
+        merges = [(self.neighbour(dx, dy), self._band(dx, dy)) for dx, dy in reversed(self.DIRS)]
+        return sends, merges
+
+    def reverse_plan(self):
+        """Claim merge (guard-band mode): the forward plan with roles swapped — each halo strip travels to the
+        rank that owns those cells and is max-merged into its interior band; rows first, then columns, so a
+        corner's claims arrive in two hops.  [(phase, send_to, send_view, recv_from, merge_view)]."""
+        return [(ph, frm, rview, to, sview) for ph, to, sview, frm, rview in self.halo_plan()]
+
     def halo_plan(self):
         """[(phase, send_to, send_view, recv_from, recv_view)] as index tuples into a padded plane.
         Phase 0 moves columns between y-neighbours (interior rows only), phase 1 moves full-width
@@ -136,53 +174,92 @@ def _slice_rect(_lib, plane: torch.Tensor, view, offset: int):
     return _lib.Rect(plane.data_ptr(), plane.shape[1], rs.start, rs.stop, cs.start, cs.stop, plane.element_size(), offset)
 
 
-def halo_exchange(planes, geo: TileGeometry, comm: Comm):
-    """Fill the halo ring of one or several padded (W, H) planes from the periodic neighbours; all
-    planes travel together in two batches (phase 0: columns, phase 1: full-width rows).  On a GPU the
-    strips of all planes are packed into ONE message per neighbour by die_rects_pack / _unpack."""
+def _exchange_blocks(planes, sends, recvs, comm: Comm, merge_max: bool, tag: str, cache: Optional[dict] = None):
+    """Move blocks of padded planes between ranks: `sends` / `recvs` are [(peer, view)] lists (views = (row slice,
+    column slice)), every plane travels in the same message.  GPU: one pack launch, one message per
+    neighbour, one unpack (or max-merge) launch.  CPU (tests): plain slicing."""
+    on_gpu = all(p.is_cuda for p in planes)
+    if not on_gpu:
+        msg_s = [(peer, torch.cat([p[v].reshape(-1).view(torch.uint8) for p in planes])) for peer, v in sends]
+        msg_r = [(peer, torch.empty(sum(p[v].numel() * p.element_size() for p in planes), dtype=torch.uint8)) for peer, v in recvs]
+        comm.exchange(msg_s, msg_r)
+        for (peer, v), (_, buf) in zip(recvs, msg_r):
+            off = 0
+            for p in planes:
+                n = p[v].numel() * p.element_size()
+                blk = buf[off:off + n].view(p.dtype).reshape(p[v].shape)
+                if merge_max:
+                    cur = p[v].contiguous().numpy().view(np.uint64)
+                    blk = torch.from_numpy(np.maximum(cur, blk.numpy().view(np.uint64)).view(np.int64))
+                p[v] = blk
+                off += n
+        return
+    from . import _lib
+    from .device_array import stream_ptr
+    dev = planes[0].device
+    key = (tag, merge_max, comm.rank, tuple(p.data_ptr() for p in planes))
+    cache = _EXCHANGE_PLANS if cache is None else cache
+    plan = cache.get(key)
+    if plan is None:
+        def layout(items):
+            rects, offs, off = [], [], 0
+            for peer, v in items:
+                offs.append(off)
+                for p in planes:
+                    rects.append(_slice_rect(_lib, p, v, off))
+                    off += ((v[0].stop - v[0].start) * (v[1].stop - v[1].start) * p.element_size() + 7) & ~7
+            offs.append(off)
+            chunks = [rects[i:i + 16] for i in range(0, len(rects), 16)]
+            return [((_lib.Rect * len(c))(*c), len(c)) for c in chunks], offs
+        schunks, soffs = layout(sends)
+        rchunks, roffs = layout(recvs)
+        sbuf = torch.empty(soffs[-1], dtype=torch.uint8, device=dev)
+        rbuf = torch.empty(roffs[-1], dtype=torch.uint8, device=dev)
+        smsg = [(peer, sbuf[soffs[k]:soffs[k + 1]]) for k, (peer, v) in enumerate(sends)]
+        rmsg = [(peer, rbuf[roffs[k]:roffs[k + 1]]) for k, (peer, v) in enumerate(recvs)]
+        ops = None
+        if not comm.stage_cpu:                      # RCCL: the P2P ops over the persistent buffers are built once
+            selfs = [t for p_, t in smsg if p_ == comm.rank]
+            selfr = [t for p_, t in rmsg if p_ == comm.rank]
+            ops = ([dist.P2POp(dist.isend, t, p_, comm.group) for p_, t in smsg if p_ != comm.rank] +
+                   [dist.P2POp(dist.irecv, t, p_, comm.group) for p_, t in rmsg if p_ != comm.rank], list(zip(selfr, selfs)))
+        plan = (schunks, rchunks, sbuf, rbuf, smsg, rmsg, ops, planes)     # `planes` keeps the pointers alive
+        cache[key] = plan
+    schunks, rchunks, sbuf, rbuf, smsg, rmsg, ops, _ = plan
+    sp = stream_ptr(dev)
+    for arr, n in schunks:
+        _lib.check(_lib.lib.die_rects_pack(arr, n, C.c_void_p(sbuf.data_ptr()), sp), 'die_rects_pack')
+    if ops is None:
+        comm.exchange(smsg, rmsg)
+    else:
+        p2p, self_pairs = ops
+        for r, t in self_pairs:
+            r.copy_(t)
+        if p2p:
+            for req in dist.batch_isend_irecv(p2p):
+                req.wait()
+    fn = _lib.lib.die_rects_unpack_max if merge_max else _lib.lib.die_rects_unpack
+    for arr, n in rchunks:
+        _lib.check(fn(arr, n, C.c_void_p(rbuf.data_ptr()), sp), 'die_rects_unpack')
+
+
+_EXCHANGE_PLANS: Dict[tuple, tuple] = {}
+
+
+def halo_exchange(planes, geo: TileGeometry, comm: Comm, cache: Optional[dict] = None):
+    """Fill the halo ring of one or several padded (W, H) planes from the 8 periodic neighbours (edges and
+    corners in ONE phase; all planes share the messages)."""
     if isinstance(planes, torch.Tensor):
         planes = [planes]
-    plan = geo.halo_plan()
-    on_gpu = all(p.is_cuda for p in planes)
-    if on_gpu:
-        from . import _lib
-        from .device_array import stream_ptr
-    for phase in (0, 1):
-        entries = [e for e in plan if e[0] == phase]          # [to −side, to +side]
-        if not on_gpu:
-            sends, recvs = [], []
-            for plane in planes:
-                for ph, to, sview, frm, rview in entries:
-                    sends.append((to, plane[sview]))
-                    recvs.append((frm, plane[rview]))
-            comm.exchange(sends, recvs)
-            continue
-        # message layout: for each direction, the strips of every plane back to back (8-byte aligned)
-        srects, rrects, offs, off = [], [], [], 0
-        for ph, to, sview, frm, rview in entries:
-            offs.append(off)
-            for plane in planes:
-                rows = sview[0].stop - sview[0].start
-                cols = sview[1].stop - sview[1].start
-                srects.append(_slice_rect(_lib, plane, sview, off))
-                rrects.append(_slice_rect(_lib, plane, rview, off))
-                off += (rows * cols * plane.element_size() + 7) & ~7
-        offs.append(off)
-        key = (planes[0].device, phase, off)
-        if key not in _HALO_BUFFERS:
-            _HALO_BUFFERS[key] = (torch.empty(off, dtype=torch.uint8, device=planes[0].device),
-                                  torch.empty(off, dtype=torch.uint8, device=planes[0].device))
-        sbuf, rbuf = _HALO_BUFFERS[key]
-        sp = stream_ptr(planes[0].device)
-        sarr = (_lib.Rect * len(srects))(*srects)
-        _lib.check(_lib.lib.die_rects_pack(sarr, len(srects), C.c_void_p(sbuf.data_ptr()), sp), 'die_rects_pack')
-        # "send to the −side, send to the +side" pairs with "recv from the +side, recv from the −side": the
-        # message a rank sends to its −side neighbour is what that neighbour receives from its +side
-        sends = [(entries[0][1], sbuf[offs[0]:offs[1]]), (entries[1][1], sbuf[offs[1]:offs[2]])]
-        recvs = [(entries[0][3], rbuf[offs[0]:offs[1]]), (entries[1][3], rbuf[offs[1]:offs[2]])]
-        comm.exchange(sends, recvs)
-        rarr = (_lib.Rect * len(rrects))(*rrects)
-        _lib.check(_lib.lib.die_rects_unpack(rarr, len(rrects), C.c_void_p(rbuf.data_ptr()), sp), 'die_rects_unpack')
+    sends, recvs = geo.plan8()
+    _exchange_blocks(planes, sends, recvs, comm, False, 'halo%d' % len(planes), cache)
+
+
+def halo_merge_max(plane: torch.Tensor, geo: TileGeometry, comm: Comm, cache: Optional[dict] = None):
+    """Send the claim words of the halo ring to the ranks that own those cells; each rank raises its
+    interior bands to the maximum of what it holds and what arrives (unsigned 64-bit compare)."""
+    sends, merges = geo.reverse_plan8()
+    _exchange_blocks([plane], sends, merges, comm, True, 'merge', cache)
 
 
 def route_records(records: torch.Tensor, dest: torch.Tensor, comm: Comm) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -240,7 +317,8 @@ class DistEnv:
 
     def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], dynamics=None, *, probe_reach: int,
                  capacity: Optional[int] = None, device=None, group=None, field_dtype=torch.float32,
-                 seed: int = 0, init: bool = True, sort_every: int = 8, overlap: bool = True):
+                 seed: int = 0, init: bool = True, sort_every: int = 8, overlap: bool = True,
+                 migrate_every: int = 1, max_step_cells: float = 2.0):
         from . import _lib
         from .data_init import DataInitializer
         from .device_array import DeviceAgents, DeviceMedium
@@ -249,7 +327,11 @@ class DistEnv:
         self.dynamics = dynamics or Dynamics()
         self.comm = Comm(group)
         R = int(4.0 * float(self.dynamics.diffuse_sigma) + 0.5)
-        halo = int(probe_reach) + 1 + R
+        # guard band: agents may stay on a rank for `migrate_every` steps after leaving its interior (their
+        # claims are merged across ranks every step instead); a lifecycle that teleports slots needs M = 1
+        self.migrate_every = 1 if self.dynamics.agents_die else max(1, int(migrate_every))
+        self.band = 0 if self.migrate_every == 1 else int(np.ceil(self.migrate_every * float(max_step_cells))) + 1
+        halo = self.band + int(probe_reach) + 1 + R
         while (world[1] // grid[1] + 2 * halo) % 4:                    # die_diffuse_decay_tile needs H % 4 == 0
             halo += 1
         self.geo = TileGeometry(world, grid, self.comm.rank, halo)
@@ -269,6 +351,7 @@ class DistEnv:
         # migration / claims of the next step run on the compute stream
         self._comm_stream = torch.cuda.Stream(self.device) if self.device.type == 'cuda' else None
         self._chem_halo_in_flight = False
+        self._plans = {}             # cached exchange plans (message buffers, rect lists, P2P ops)
         if init:
             self._init_tile()
 
@@ -425,16 +508,122 @@ class DistEnv:
         forward pass that runs meanwhile only reads halo cells whose redundantly diffused values equal
         the incoming ones bit for bit (same kernel, same inputs), so the overlap is race-free in value."""
         if self._comm_stream is None:
-            halo_exchange([self.medium.chem], self.geo, self.comm)
+            halo_exchange([self.medium.chem], self.geo, self.comm, self._plans)
         else:
             self._comm_stream.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._comm_stream):
-                halo_exchange([self.medium.chem], self.geo, self.comm)
+                halo_exchange([self.medium.chem], self.geo, self.comm, self._plans)
         self._chem_halo_in_flight = True
 
     def step(self, action):
         """One decomposed env step.  Returns (obs, result_tensor): result is the LOCAL
         die_step_result; `read_result` all-reduces it."""
+        if self.migrate_every > 1:
+            return self._step_guard_band(action)
+        return self._step_migrate_each(action)
+
+    # ------------------------------------------------------------------ guard-band mode
+    def _step_guard_band(self, action):
+        """Agents stay where they are for `migrate_every` steps; what crosses ranks every step is fields only:
+            die_forward_move_claim_tile     the single-GPU front kernel; a stray agent claims a HALO cell
+            halo_merge_max(claims)          halo claims travel to the owners, max-merged into their interior
+            halo_exchange(chem, claims)     authoritative interior bands → everybody's halo
+            die_medium_deposit_feed_diffuse_tile(halo=0)   deposits, feeding (halo included: its food stays
+                                            consistent with the owner's) and diffusion over the padded tile
+        No host synchronisation in the loop; every `migrate_every` steps the strays are handed over."""
+        from .device_array import PendingAction, _ptr, stream_ptr
+        lib, A, g, M = self._lib, self.agents, self.geo, self.medium
+        sp = stream_ptr(self.device)
+        d = self._c_dynamics()
+        M.next_epoch()
+        result = torch.empty(2, dtype=torch.float64, device=self.device)
+        ws, wsn = _ptr(self._workspace), self._workspace.numel()
+        second = not self._all_alive
+        if A.N > 0:
+            m, a = M.c_struct(), self._struct(A)
+            if isinstance(action, PendingAction) and action.pending and action.agents is A and action.medium is M:
+                self._check_reach(action)
+                u = action.raw_struct()
+                lib.check(lib.lib.die_forward_move_claim_tile(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u),
+                                                              C.byref(d), ws, wsn, sp), 'die_forward_move_claim_tile')
+                action.agent._forward_consumed(action)
+            else:
+                action.N = A.N
+                u = action.c_struct()
+                lib.check(lib.lib.die_agent_move_claim(C.byref(m), C.byref(a), C.byref(u), C.byref(d), ws, wsn, sp),
+                          'die_agent_move_claim')
+        halo_merge_max(M.owner, g, self.comm, self._plans)
+        if self._chem_halo_in_flight:
+            if self._comm_stream is not None:
+                torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
+            self._chem_halo_in_flight = False
+            halo_exchange([M.owner], g, self.comm, self._plans)
+        else:
+            halo_exchange([M.chem, M.owner], g, self.comm, self._plans)
+        if A.N > 0:
+            m, a, u = M.c_struct(), self._struct(A), action.c_struct()
+            if second:
+                lib.check(lib.lib.die_agent_dead_slots(C.byref(m), C.byref(a), C.byref(u), C.byref(d), ws, wsn, sp),
+                          'die_agent_dead_slots')
+            lib.check(lib.lib.die_step_reduce_ex(C.byref(a), _ptr(result), ws, wsn, int(second), A.N, sp), 'die_step_reduce_ex')
+        else:
+            result.zero_()
+        m = M.c_struct()
+        lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), 0, sp),
+                  'die_medium_deposit_feed_diffuse_tile')
+        M.swap_chem()
+        self._steps += 1
+        if self._steps % self.migrate_every == 0:
+            self._hand_over_strays(action)
+        if self._sort_every > 0 and self._steps % self._sort_every == 0 and A.N > 1:
+            self.sort_agents()
+        if self._overlap:
+            self._start_chem_halo()
+        self.last_result = result
+        return self._get_current_obs, result
+
+    def _hand_over_strays(self, action):
+        """Migration round of the guard-band mode: agents standing outside the interior move to the owner."""
+        from .device_array import _ptr, stream_ptr
+        lib, A, g = self._lib, self.agents, self.geo
+        n = A.N
+        if n:
+            zero = torch.zeros((3, max(n, 1)), dtype=torch.float32, device=self.device)
+            u = lib.Action(n, _ptr(zero[0]), _ptr(zero[1]), _ptr(zero[2]))
+            m, a, d = self.medium.c_struct(), self._struct(A), self._c_dynamics()
+            lib.check(lib.lib.die_agent_move(C.byref(m), C.byref(a), C.byref(u), C.byref(d), g.Wi, g.Hi, g.Py,
+                                             _ptr(self._tile_of), stream_ptr(self.device)), 'die_agent_move')
+            # every stray must still be inside the guard band, or its claims went to a clamped (wrong) cell
+            lv = torch.nonzero(self._tile_of[:n] != self.comm.rank, as_tuple=False).squeeze(1)
+            if lv.numel():
+                far = self._stray_distance(lv)
+                if far > self.band:
+                    raise RuntimeError(f'rank {self.comm.rank}: an agent strayed {far} cells outside its tile, the guard band '
+                                       f'is {self.band}: lower migrate_every or raise max_step_cells')
+        self._migrate(action)
+        halo_exchange([self.medium.food], self.geo, self.comm, self._plans)          # belt and braces: re-seat the food halo
+
+    def _stray_distance(self, idx: torch.Tensor) -> int:
+        g, A = self.geo, self.agents
+        def cells(q, n_world):
+            return (((q[idx].to(torch.int64) & 0xFFFFFFFF) * (n_world - 1) + (1 << 31)) >> 32)
+        def outside(c, lo, size, world):
+            l = (c - lo) % world                                       # offset from the interior's origin, periodic
+            d = torch.minimum(l - (size - 1), world - l)               # … to the far edge going on, or back round the seam
+            return torch.where(l < size, torch.zeros_like(l), d)
+        dx = outside(cells(A.x, g.gW), g.x0, g.Wi, g.gW)
+        dy = outside(cells(A.y, g.gH), g.y0, g.Hi, g.gH)
+        return int(torch.maximum(dx, dy).max().item())
+
+    def _check_reach(self, action):
+        g = self.geo
+        reach = int(np.ceil(abs(float(action.g_struct.sense_offset)) * (max(g.gW, g.gH) - 1))) + 1 + self.R + self.band
+        if reach > g.h:
+            raise ValueError(f'probe reach + guard band = {reach} cells exceeds the halo {g.h}: build DistEnv with a larger '
+                             f'probe_reach')
+
+    # ------------------------------------------------------------------ migrate-every-step mode
+    def _step_migrate_each(self, action):
         from .device_array import _ptr, stream_ptr
         lib, A, g = self._lib, self.agents, self.geo
         from .device_array import PendingAction
@@ -442,11 +631,7 @@ class DistEnv:
         d = self._c_dynamics()
         m, a = self.medium.c_struct(), self._struct(A)
         if isinstance(action, PendingAction) and action.pending and action.agents is A and action.medium is self.medium:
-            # the halo must cover the probe: sense_offset is in units of the world, i.e. up to this many cells
-            reach = int(np.ceil(abs(float(action.g_struct.sense_offset)) * (max(g.gW, g.gH) - 1))) + 1 + self.R
-            if reach > g.h:
-                raise ValueError(f'probe reach {reach} cells exceeds the halo {g.h}: build DistEnv with probe_reach >= '
-                                 f'{reach - 1 - self.R}')
+            self._check_reach(action)
             u = action.raw_struct()                     # forward runs fused with the move half
             lib.check(lib.lib.die_forward_move(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u), C.byref(d),
                                                g.Wi, g.Hi, g.Py, _ptr(self._tile_of), sp), 'die_forward_move')
@@ -487,9 +672,9 @@ class DistEnv:
             if self._comm_stream is not None:
                 torch.cuda.current_stream(self.device).wait_stream(self._comm_stream)
             self._chem_halo_in_flight = False
-            halo_exchange([M.owner], g, self.comm)
+            halo_exchange([M.owner], g, self.comm, self._plans)
         else:
-            halo_exchange([M.chem, M.owner], g, self.comm)
+            halo_exchange([M.chem, M.owner], g, self.comm, self._plans)
         m = M.c_struct()
         lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), g.h, sp),
                   'die_medium_deposit_feed_diffuse_tile')

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 6
+#define DIE_ABI_VERSION 7
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -191,6 +191,11 @@ int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradien
 int die_env_step_finish(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                         die_step_result* result, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* The same kernel on a tile of a decomposed world (claims may land in the halo; the caller merges them
+ * across ranks and runs die_medium_deposit_feed_diffuse_tile). */
+int die_forward_move_claim_tile(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                const die_dynamics* d, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* The stages of die_env_step, individually (tests and custom update cycles such as
  * examples/simple_agents.py:16-30 `_manual_step`). */
 int die_agent_move_claim(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
@@ -276,6 +281,9 @@ typedef struct die_rect {
 } die_rect;
 int die_rects_pack(const die_rect* rects, int32_t n, void* buf, void* stream);
 int die_rects_unpack(const die_rect* rects, int32_t n, const void* buf, void* stream);
+/* buffer → plane with plane = max(plane, buffer) on unsigned 64-bit words: merges the claims a
+ * neighbour's stray agents made on this rank's cells (guard-band decomposition). */
+int die_rects_unpack_max(const die_rect* rects, int32_t n, const void* buf, void* stream);
 /* Agent records: word (k, j) of the (n, count) int32 matrix is element idx[j] of array k (4-byte
  * arrays bit-copied, 1-byte arrays widened): migration packs leavers and writes arrivals with one
  * launch each. */

@@ -15,7 +15,8 @@ def make_case(seed):
     agent = rs.choice(['physarum', 'brownian', 'gradient'])
     boundary = rs.choice(['wrap', 'limit'])
     die = bool(rs.rand() < 0.3)
-    return dict(grid=grid, W=W, H=H, N=N, K=K, agent=str(agent), boundary=str(boundary), agents_die=die, steps=8,
+    me = 1 if agent == 'brownian' else int(rs.choice([1, 3, 6]))
+    return dict(grid=grid, W=W, H=H, N=N, K=K, agent=str(agent), boundary=str(boundary), agents_die=die, steps=8, migrate_every=me,
                 sort_every=int(rs.choice([0, 2])), seed=seed)
 
 def build(case, die_amd):
@@ -45,7 +46,8 @@ def worker(rank, size, port, case, out):
         from die_amd.dist import DistEnv
         medium, agents, dir0, prev, dyn = build(case, die_amd)
         env = DistEnv.from_global_numpy(medium, agents, case['grid'], dyn, probe_reach=int(np.ceil(max(6.2 / (case['W'] - 1), 0.03) * (max(case['W'], case['H']) - 1))), device='cuda:0', sort_every=case['sort_every'],
-                                        capacity=case['N'] + 64)
+                                        capacity=case['N'] + 64, migrate_every=case['migrate_every'],
+                                        max_step_cells=max(1.53 / (case['W'] - 1), 0.01 * 1.5) * (max(case['W'], case['H']) - 1) + 0.5)
         ag = make_agent(case, die_amd, env.capacity)
         if case['agent'] != 'brownian':
             sl = env.local_slots()

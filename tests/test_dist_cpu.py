@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from die_amd.dist import Comm, TileGeometry, fill_holes, halo_exchange, route_records
+from die_amd.dist import Comm, TileGeometry, fill_holes, halo_exchange, halo_merge_max, route_records
 
 
 def _free_port():
@@ -65,6 +65,49 @@ def _halo_case(rank, size, world, grid, h):
                                                 (1, (8, 8), (1, 1), 3), (4, (32, 8), (4, 1), 2)])
 def test_halo_exchange_is_periodic_including_corners(size, world, grid, h):
     _run(size, _halo_case, world, grid, h)
+
+
+def _value(q, gx, gy):
+    """Deterministic pseudo-random claim word of rank q for world cell (gx, gy)."""
+    x = (np.uint64(q + 1) * np.uint64(0x9E3779B97F4A7C15)) ^ (gx.astype(np.uint64) * np.uint64(0xC2B2AE3D27D4EB4F)) \
+        ^ (gy.astype(np.uint64) * np.uint64(0x165667B19E3779F9))
+    return (x ^ (x >> np.uint64(29))) * np.uint64(0xBF58476D1CE4E5B9)
+
+
+def _merge_case(rank, size, world, grid, h):
+    comm = Comm()
+    geos = [TileGeometry(world, grid, q, h) for q in range(size)]
+
+    def plane_of(q):
+        g = geos[q]
+        gx = ((np.arange(g.W) + g.ox) % world[0])[:, None] + np.zeros((1, g.H), dtype=np.int64)
+        gy = ((np.arange(g.H) + g.oy) % world[1])[None, :] + np.zeros((g.W, 1), dtype=np.int64)
+        return _value(q, gx, gy), gx, gy
+    mine, _, _ = plane_of(rank)
+    plane = torch.from_numpy(mine.view(np.int64).copy())
+    halo_merge_max(plane, geos[rank], comm)
+    g = geos[rank]
+    want = mine.copy()
+    for q in range(size):                      # every rank's halo cells that are images of my interior cells
+        vals, gx, gy = plane_of(q)
+        gq = geos[q]
+        halo = np.ones((gq.W, gq.H), dtype=bool)
+        halo[gq.h:gq.h + gq.Wi, gq.h:gq.h + gq.Hi] = False
+        inside = halo & (gx >= g.x0) & (gx < g.x0 + g.Wi) & (gy >= g.y0) & (gy < g.y0 + g.Hi)
+        li, lj = gx[inside] - g.ox, gy[inside] - g.oy
+        np.maximum.at(want, (li, lj), vals[inside])
+    got = plane.numpy().view(np.uint64)
+    ri, ci = g.interior()
+    assert np.array_equal(got[ri, ci], want[ri, ci]), f'rank {rank}: merged interior differs'
+    mask = np.ones_like(got, dtype=bool)
+    mask[ri, ci] = False
+    assert np.array_equal(got[mask], mine[mask])      # the halo itself is left alone
+
+
+@pytest.mark.parametrize('size,world,grid,h', [(2, (12, 16), (1, 2), 3), (2, (16, 12), (2, 1), 4), (4, (16, 24), (2, 2), 5),
+                                                (4, (32, 8), (4, 1), 2), (1, (8, 8), (1, 1), 3)])
+def test_halo_claim_merge_takes_the_maximum_over_all_images(size, world, grid, h):
+    _run(size, _merge_case, world, grid, h)
 
 
 def _route_case(rank, size, n):

@@ -26,7 +26,7 @@ def _state(W, H, N, K, seed):
     return medium, agents, dir0
 
 
-def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, out_path):
+def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -37,7 +37,7 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, out_
         medium, agents, dir0 = _state(W, H, N, K, 5)
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
         env = DistEnv.from_global_numpy(medium, agents, grid, probe_reach=11, device='cuda:0', sort_every=sort_every,
-                                        overlap=overlap)
+                                        overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6)
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
         local = torch.zeros(cap, dtype=torch.float32, device='cuda:0')
@@ -55,8 +55,10 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, out_
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('grid,sort_every,overlap', [((1, 2), 0, True), ((2, 1), 3, False), ((2, 2), 0, False), ((2, 2), 2, True)])
-def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, overlap):
+@pytest.mark.parametrize('grid,sort_every,overlap,migrate_every', [((1, 2), 0, True, 1), ((2, 1), 3, False, 1), ((2, 2), 0, False, 1),
+                                                                    ((2, 2), 2, True, 1), ((2, 2), 2, True, 4), ((1, 2), 0, False, 3),
+                                                                    ((2, 1), 3, True, 5)])
+def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, overlap, migrate_every):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import torch.multiprocessing as mp
@@ -64,7 +66,7 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     W, H, N, K, steps = 128, 96, 2000, 1800, 12
     out = str(tmp_path / 'dist.npz')
     size = grid[0] * grid[1]
-    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, overlap, out), nprocs=size, join=True)
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out), nprocs=size, join=True)
     got = np.load(out)
 
     medium, agents, dir0 = _state(W, H, N, K, 5)
