@@ -34,7 +34,10 @@ def parse():
     p.add_argument('--kernel-reps', type=int, default=20)
     p.add_argument('--sort-every', type=int, default=8)
     p.add_argument('--fields', choices=['f32', 'f16'], default='f32', help='dtype of the field channels (configs[4] uses f16)')
-    p.add_argument('--migrate-every', type=int, default=8, help='decomposed runs: hand strays over every M steps (1 = every step)')
+    p.add_argument('--migrate-every', type=int, default=8, help='decomposed runs: agents / ghosts cross ranks every M steps (1 = every step)')
+    p.add_argument('--dist-mode', choices=['ghost', 'guard'], default='ghost',
+                   help='decomposed runs: ghost = communication-avoiding (ghost agents, nothing crosses ranks for M steps); '
+                        'guard = claims merged and halos exchanged every step, strays handed over every M steps')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
@@ -177,17 +180,41 @@ def main():
             agent_kw.update(scale=1.53 / (max(gW, gH) - 1), sense_offset=10.2 / (max(gW, gH) - 1))
             denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
                            device=device, seed=args.seed, sort_every=args.sort_every,
-                           migrate_every=args.migrate_every, max_step_cells=1.6)
-            mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, halo {denv.geo.h}, strays handed over every '
-                    f'{denv.migrate_every} steps, '
+                           migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost')
+            how = (f'ghost agents, halo ({denv.geo.hx}, {denv.geo.hy}) re-seated every {denv.migrate_every} steps' if denv.ghosts else
+                   f'halo {denv.geo.h}, claims merged every step, strays handed over every {denv.migrate_every} steps')
+            mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, {how}, '
                     f'{"RCCL" if backend == "nccl" else backend} point-to-point')
         except Exception as e:           # keep the scaling run alive: independent replicas, and say so
             denv = None
             mode = f'{world} independent grid replicas (decomposition unavailable: {type(e).__name__}: {e})'
     if denv is not None:
+        # two trial steps before committing to the decomposed path: a transport that fails at the first exchange
+        # must not cost the scaling run its line (all ranks agree on the outcome; on failure: replicas, and say so)
+        ok, why = 1, ''
+        try:
+            trial_agent = die_amd.PhysarumAgent(max_agents=denv.capacity, seed=args.seed, **agent_kw)   # one seed: streams are keyed by world slot id
+            o = denv._get_current_obs
+            for _ in range(2):
+                o, *_ = denv.step(trial_agent.forward(o))
+            torch.cuda.synchronize()
+        except Exception as e:
+            ok, why = 0, f'{type(e).__name__}: {e}'
+        try:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        except Exception as e:
+            ok, why = 0, why or f'{type(e).__name__}: {e}'
+        if ok:
+            agent = trial_agent
+        else:
+            denv = None
+            agent_kw.update(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+            mode = f'{world} independent grid replicas (decomposed step failed: {why or "on another rank"})'
+    if denv is not None:
         env = denv
         K = env.agents.N
-        agent = die_amd.PhysarumAgent(max_agents=env.capacity, seed=args.seed + rank, **agent_kw)
     else:
         env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
                           max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
@@ -203,17 +230,19 @@ def main():
         obs, res, *_ = env.step(agent.forward(obs))
         return res
 
+    def barrier():
+        if dist_on:
+            dist.barrier()
+
     for _ in range(args.warmup):
         one_step()
-    if dist_on:
-        dist.barrier()
+    barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         results.append(one_step())
     torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
+    barrier()
     dt = time.perf_counter() - t0
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)

@@ -72,12 +72,16 @@ struct die_geo {
     int W, H;        // local plane dims (pitch = H)
     int gW, gH;      // world size used for coordinate → cell
     int ox, oy;      // global cell of local element (0, 0)
+    int own_x0, own_y0, own_x1, own_y1;   // local cells this rank accounts for in reward / num_alive (x1 == 0: all)
 };
 static inline die_geo die_geo_of(const die_medium* m) {
     die_geo g;
     g.W = m->W; g.H = m->H;
     g.gW = m->gW > 0 ? m->gW : m->W; g.gH = m->gW > 0 ? m->gH : m->H;
     g.ox = m->gW > 0 ? m->ox : 0; g.oy = m->gW > 0 ? m->oy : 0;
+    const bool own = m->gW > 0 && m->own_x1 > 0;
+    g.own_x0 = own ? m->own_x0 : 0; g.own_y0 = own ? m->own_y0 : 0;
+    g.own_x1 = own ? m->own_x1 : 0; g.own_y1 = own ? m->own_y1 : 0;
     return g;
 }
 // world cell → element of the local planes.  In a decomposed world the halo holds periodic images, so a
@@ -91,6 +95,15 @@ __device__ __forceinline__ int64_t die_local(const die_geo& g, int gx, int gy) {
     lx = lx < 0 ? 0 : (lx >= g.W ? g.W - 1 : lx);
     ly = ly < 0 ? 0 : (ly >= g.H ? g.H - 1 : ly);
     return (int64_t)lx * g.H + ly;
+}
+
+// does this rank account for the agent standing on world cell (gx, gy)?  (ghost-agent decomposition)
+__device__ __forceinline__ bool die_owned(const die_geo& g, int gx, int gy) {
+    if (g.own_x1 == 0) return true;
+    int lx = gx - g.ox, ly = gy - g.oy;
+    lx = lx >= g.W ? lx - g.gW : (lx < 0 ? lx + g.gW : lx);
+    ly = ly >= g.H ? ly - g.gH : (ly < 0 ? ly + g.gH : ly);
+    return lx >= g.own_x0 && lx < g.own_x1 && ly >= g.own_y0 && ly < g.own_y1;
 }
 
 // ---- wave / block reductions -------------------------------------------------------------

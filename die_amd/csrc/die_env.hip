@@ -69,7 +69,7 @@ __device__ __forceinline__ void block_sum_store(double g, long long c, double* p
 // One slot of _agent_move + claim + _agent_feed (alive slots); returns its `gained` (0 for dead slots).
 template <typename T>
 __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t n, uint32_t X, uint32_t Y, const float dx,
-                                                const float dy, const float dep, const uint32_t sid) {
+                                                const float dy, const float dep, const uint32_t sid, long long& owned_alive) {
     const T* food = (const T*)a.food;
     const die_geo g = a.g;
     if (a.do_move) {
@@ -107,6 +107,8 @@ __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t
 #ifndef DIE_ABL_NOAF
         a.agent_food[n] += gained;
 #endif
+        if (!die_owned(g, cx, cy)) return 0.f;        // a ghost: the rank that owns this cell accounts for it
+        ++owned_alive;
         return gained;
     }
     if (a.has_dead) a.stash[n] = consumed;
@@ -116,19 +118,24 @@ __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t
 template <typename T>
 __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
     double gsum = 0.0;
+    long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
-        gsum += (double)move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid);
+        gsum += (double)move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid, cnt);
     }
-    if (a.do_claim) block_sum_store(gsum, 0, a.part_gain, nullptr);
+    if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
 
 // Agent.forward fused with the first half of Env.step: the action stays in registers between the two
 // (it is still written out for the caller, but never read back), x / y / slot are loaded once.
+#ifndef DIE_FMC_ATTR
+#define DIE_FMC_ATTR
+#endif
 template <typename T, int KIND>
-__global__ __launch_bounds__(DIE_BLOCK) void k_forward_move_claim(FwdArgs f, StepArgs a) {
+__global__ __launch_bounds__(DIE_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(FwdArgs f, StepArgs a) {
     double gsum = 0.0;
+    long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
@@ -137,12 +144,12 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_forward_move_claim(FwdArgs f, Ste
         f.heading[n] = o.heading;
 #ifdef DIE_NT_ACTION
         if (f.dx) { __builtin_nontemporal_store(o.dx, &f.dx[n]); __builtin_nontemporal_store(o.dy, &f.dy[n]); __builtin_nontemporal_store(o.dep, &f.dep[n]); }
-#else
+#elif !defined(DIE_ABL_NOACT)
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
 #endif
-        gsum += (double)move_claim_one<T>(a, n, X, Y, o.dx, o.dy, o.dep, sid);
+        gsum += (double)move_claim_one<T>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt);
     }
-    if (a.do_claim) block_sum_store(gsum, 0, a.part_gain, nullptr);
+    if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
 
 // Second half of the claim: raise every cell's word to the maximum over its claimants.
@@ -166,7 +173,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t X = a.x[n], Y = a.y[n];
-        const int64_t c = die_local(a.g, die_cell((int64_t)X, a.g.gW), die_cell((int64_t)Y, a.g.gH));
+        const int cx = die_cell((int64_t)X, a.g.gW), cy = die_cell((int64_t)Y, a.g.gH);
+        const int64_t c = die_local(a.g, cx, cy);
+        const bool owned = die_owned(a.g, cx, cy);
         bool alive = a.alive[n] != 0;
         if (alive && !a.skip_scatter) {
             if ((uint32_t)(a.owner[c] >> 32) == die_owner_word(a.epoch, a.slot ? (int64_t)a.slot[n] : n)) {       // highest alive slot on the cell
@@ -180,13 +189,13 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
             const float consumed = die_claim_occupied(a.owner[c], a.epoch) ? a.stash[n] : 0.f;
             const float gained = consumed - action_cost(a, a.dx[n], a.dy[n], a.dep[n]);
             a.agent_food[n] += gained;
-            gsum += (double)gained;
+            if (owned) gsum += (double)gained;
         }
         if (a.agents_die && !(a.agent_food[n] > 1e-4f)) {         // where(have_food, 0): every channel
             a.x[n] = 0; a.y[n] = 0; a.alive[n] = 0; a.agent_food[n] = 0.f;
             alive = false;
         }
-        alive_cnt += alive ? 1 : 0;
+        alive_cnt += (alive && owned) ? 1 : 0;
     }
     block_sum_store(gsum, alive_cnt, a.part_gain, a.part_alive);
 }
@@ -293,6 +302,7 @@ struct RowsArgs {
     void* food;                        // FUSED only
     int W, H, epoch, food_infinite;
     int halo;                          // tile mode: cells within `halo` of the array border belong to neighbours
+    int wrapx, wrapy;                  // tile mode: this axis spans the whole world (one rank along it) and is periodic
     float keep, rate_feed;
     float w[2 * 4 + 1];
 };
@@ -329,8 +339,10 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     const int nout = min(DIF_WCOLS, H - yb) / 4;            // output lanes are 1..nout (H % 4 == 0)
     const bool need = lane <= nout + 1;                     // + the two halo lanes
     const bool outl = lane >= 1 && lane <= nout;
-    const int col = WRAP ? wrap_idx(yb + 4 * (lane - 1), H)  // 16-byte aligned since H % 4 == 0
-                         : min(max(yb + 4 * (lane - 1), 0), H - 4);   // tile: clamp, border ring is don't-care
+    const bool wx = WRAP || a.wrapx, wy = WRAP || a.wrapy;
+    const int hx = wx ? 0 : a.halo, hy = wy ? 0 : a.halo;
+    const int col = wy ? wrap_idx(yb + 4 * (lane - 1), H)    // 16-byte aligned since H % 4 == 0
+                       : min(max(yb + 4 * (lane - 1), 0), H - 4);     // tile: clamp, border ring is don't-care
     const int x0 = blockIdx.y * DIF_ROWS;
     const int rows = min(DIF_ROWS, W - x0);
 
@@ -341,7 +353,7 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     auto load_row = [&](int i, float v[4]) {
         v[0] = v[1] = v[2] = v[3] = 0.f;
         if (!need) return;
-        const int r = WRAP ? wrap_idx(x0 + i, W) : min(max(x0 + i, 0), W - 1);
+        const int r = wx ? wrap_idx(x0 + i, W) : min(max(x0 + i, 0), W - 1);
         const int64_t off = (int64_t)r * H + col;
         Vec4<T>::ld(src + off, v);
         if (FUSED) {
@@ -356,13 +368,13 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
                 any |= occ[j];
             }
             // feeding: this wave owns rows [x0, x0+rows) × its output lanes (tile mode: interior cells only)
-            const bool own_row = i >= 0 && i < rows && (WRAP || (r >= a.halo && r < W - a.halo));
+            const bool own_row = i >= 0 && i < rows && r >= hx && r < W - hx;
             if (any && outl && own_row && !a.food_infinite) {
                 float f[4];
                 Vec4<T>::ld(food + off, f);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool mine = WRAP || (col + j >= a.halo && col + j < H - a.halo);
+                    const bool mine = col + j >= hy && col + j < H - hy;
                     if (occ[j] && mine) f[j] = f[j] - a.rate_feed * f[j];
                 }
                 Vec4<T>::st(food + off, f);
@@ -472,6 +484,7 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
         ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+        ra.wrapx = ra.wrapy = 1;
         ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
         for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
         int rc2 = dtype == DIE_F32 ? launch_rows<float, false>(ra, R, (hipStream_t)stream)
@@ -546,7 +559,9 @@ static int fill_args(StepArgs& k, const die_medium* m, const die_agents* a, cons
     k.skip_scatter = 0;
     k.claim_by_store = getenv("DIE_STORE_CLAIM") ? 1 : 0;   // measured: store 70 µs + fix 38 µs vs atomic 105 µs — no gain
     char* w = (char*)ws;
-    k.part_gain = nullptr; k.part_alive = nullptr;
+    k.part_gain = nullptr;
+    // ghost-agent tiles: num_alive is the number of alive slots on OWNED cells, counted by the claim pass
+    k.part_alive = k.g.own_x1 > 0 ? (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS) : nullptr;
     k.stash = (float*)(w + WS_PARTS + die_ws_scan_bytes(m->W, m->H));
     return DIE_OK;
 }
@@ -643,6 +658,7 @@ extern "C" int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(sigma, wd);
     ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+    ra.wrapx = ra.wrapy = 0;
     ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc = dtype == DIE_F32 ? launch_rows<float, false, false>(ra, R, (hipStream_t)stream)
@@ -672,8 +688,10 @@ extern "C" int die_step_reduce_ex(const die_agents* a, die_step_result* result, 
     DIE_REQUIRE(a && result && ws, "die_step_reduce_ex: null argument");
     DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_step_reduce_ex: workspace too small");
     const int g = step_grid(a->N);
+    // with_second_pass: 0 = claim-pass gains, num_alive = alive_const; 1 = + the dead-slot pass's gains and its
+    // alive count; 2 = claim-pass gains and the claim pass's count of owned alive slots (ghost-agent tiles)
     k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
-                                                  with_second_pass ? g : 0,
+                                                  with_second_pass == 1 ? g : 0,
                                                   (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
                                                   with_second_pass ? g : 0, result, with_second_pass ? -1 : alive_const);
     DIE_CHECK_LAUNCH("die_step_reduce_ex");
@@ -819,6 +837,7 @@ static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int 
     gaussian_taps(d->diffuse_sigma, wd);
     ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.food = m->food;
     ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo;
+    ra.wrapx = tile && m->gW > 0 && m->W == m->gW; ra.wrapy = tile && m->gW > 0 && m->H == m->gH;
     ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc;

@@ -58,7 +58,7 @@ class DeviceMedium:
     def c_struct(self) -> _lib.Medium:
         return _lib.Medium(self.W, self.H, _lib.DIE_F32 if self.dtype == torch.float32 else _lib.DIE_F16, self.epoch,
                            _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next),
-                           *(self.world or (0, 0, 0, 0)))
+                           *(self.world or (0, 0, 0, 0)), *(getattr(self, 'own', None) or (0, 0, 0, 0)))
 
     def next_epoch(self):
         """Advance the ownership epoch; zero the plane when the 3-bit tag wraps."""

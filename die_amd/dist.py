@@ -19,6 +19,7 @@ CPU tests and for several ranks sharing one GPU, staged through host memory).  R
 depend on the decomposition: Philox counters and ownership are keyed by global slot ids.
 """
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -29,19 +30,27 @@ import torch.distributed as dist
 class TileGeometry:
     """Pure index arithmetic of the decomposition (no device, no communication)."""
 
-    def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], rank: int, halo: int):
+    def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], rank: int, halo):
+        """`halo`: cells of padding per side, one number or (hx, hy).  An axis with halo 0 must have one rank
+        along it: the tile spans the world there and the kernels wrap on it natively."""
         gW, gH = int(world[0]), int(world[1])
         Px, Py = int(grid[0]), int(grid[1])
         if gW % Px or gH % Py:
             raise ValueError(f'world {world} is not divisible by the rank grid {grid}')
-        self.gW, self.gH, self.Px, self.Py, self.rank, self.h = gW, gH, Px, Py, int(rank), int(halo)
+        hx, hy = (int(halo), int(halo)) if np.isscalar(halo) else (int(halo[0]), int(halo[1]))
+        if (hx == 0 and Px != 1) or (hy == 0 and Py != 1):
+            raise ValueError('an axis without halo needs exactly one rank along it')
+        self.gW, self.gH, self.Px, self.Py, self.rank = gW, gH, Px, Py, int(rank)
+        self.hx, self.hy, self.h = hx, hy, max(hx, hy)
         self.px, self.py = divmod(self.rank, Py)
         self.Wi, self.Hi = gW // Px, gH // Py
-        if self.h > self.Wi or self.h > self.Hi:
+        if hx > self.Wi or hy > self.Hi:
             raise ValueError(f'halo {halo} wider than the tile {(self.Wi, self.Hi)}')
         self.x0, self.y0 = self.px * self.Wi, self.py * self.Hi
-        self.W, self.H = self.Wi + 2 * self.h, self.Hi + 2 * self.h
-        self.ox, self.oy = self.x0 - self.h, self.y0 - self.h
+        self.W, self.H = self.Wi + 2 * hx, self.Hi + 2 * hy
+        self.ox, self.oy = self.x0 - hx, self.y0 - hy
+        # the sides that have a halo, sorted: negation reverses the list
+        self.DIRS = [(dx, dy) for dx, dy in self.ALL_DIRS if (dx == 0 or hx > 0) and (dy == 0 or hy > 0)]
 
     @property
     def size(self) -> int:
@@ -57,22 +66,22 @@ class TileGeometry:
         return (np.asarray(ix) // self.Wi) * self.Py + np.asarray(iy) // self.Hi
 
     def interior(self) -> Tuple[slice, slice]:
-        return slice(self.h, self.h + self.Wi), slice(self.h, self.h + self.Hi)
+        return slice(self.hx, self.hx + self.Wi), slice(self.hy, self.hy + self.Hi)
 
-    DIRS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]     # sorted: negation reverses it
+    ALL_DIRS = [(-1, -1), (-1, 0), (-1, 1), (0, -1), (0, 1), (1, -1), (1, 0), (1, 1)]
 
     def _band(self, dx, dy):
         """Interior cells adjacent to side (dx, dy) — what the neighbour on that side needs as its halo."""
-        h, Wi, Hi = self.h, self.Wi, self.Hi
-        rows = {-1: slice(h, 2 * h), 0: slice(h, h + Wi), 1: slice(Wi, Wi + h)}[dx]
-        cols = {-1: slice(h, 2 * h), 0: slice(h, h + Hi), 1: slice(Hi, Hi + h)}[dy]
+        hx, hy, Wi, Hi = self.hx, self.hy, self.Wi, self.Hi
+        rows = {-1: slice(hx, 2 * hx), 0: slice(hx, hx + Wi), 1: slice(Wi, Wi + hx)}[dx]
+        cols = {-1: slice(hy, 2 * hy), 0: slice(hy, hy + Hi), 1: slice(Hi, Hi + hy)}[dy]
         return rows, cols
 
     def _halo(self, dx, dy):
         """Halo cells on side (dx, dy) (edge strips exclude the corners, which are their own blocks)."""
-        h, Wi, Hi, W, H = self.h, self.Wi, self.Hi, self.W, self.H
-        rows = {-1: slice(0, h), 0: slice(h, h + Wi), 1: slice(h + Wi, W)}[dx]
-        cols = {-1: slice(0, h), 0: slice(h, h + Hi), 1: slice(h + Hi, H)}[dy]
+        hx, hy, Wi, Hi, W, H = self.hx, self.hy, self.Wi, self.Hi, self.W, self.H
+        rows = {-1: slice(0, hx), 0: slice(hx, hx + Wi), 1: slice(hx + Wi, W)}[dx]
+        cols = {-1: slice(0, hy), 0: slice(hy, hy + Hi), 1: slice(hy + Hi, H)}[dy]
         return rows, cols
 
     def plan8(self):
@@ -91,26 +100,6 @@ class TileGeometry:
         merges = [(self.neighbour(dx, dy), self._band(dx, dy)) for dx, dy in reversed(self.DIRS)]
         return sends, merges
 
-    def reverse_plan(self):
-        """Claim merge (guard-band mode): the forward plan with roles swapped — each halo strip travels to the
-        rank that owns those cells and is max-merged into its interior band; rows first, then columns, so a
-        corner's claims arrive in two hops.  [(phase, send_to, send_view, recv_from, merge_view)]."""
-        return [(ph, frm, rview, to, sview) for ph, to, sview, frm, rview in self.halo_plan()]
-
-    def halo_plan(self):
-        """[(phase, send_to, send_view, recv_from, recv_view)] as index tuples into a padded plane.
-        Phase 0 moves columns between y-neighbours (interior rows only), phase 1 moves full-width
-        rows between x-neighbours, so corner cells arrive in two hops."""
-        h, Wi, Hi, W, H = self.h, self.Wi, self.Hi, self.W, self.H
-        rows = slice(h, h + Wi)
-        allc = slice(0, H)
-        return [
-            (0, self.neighbour(0, -1), (rows, slice(h, 2 * h)), self.neighbour(0, +1), (rows, slice(h + Hi, H))),
-            (0, self.neighbour(0, +1), (rows, slice(Hi, Hi + h)), self.neighbour(0, -1), (rows, slice(0, h))),
-            (1, self.neighbour(-1, 0), (slice(h, 2 * h), allc), self.neighbour(+1, 0), (slice(h + Wi, W), allc)),
-            (1, self.neighbour(+1, 0), (slice(Wi, Wi + h), allc), self.neighbour(-1, 0), (slice(0, h), allc)),
-        ]
-
 
 class Comm:
     """Point-to-point transport over torch.distributed; `stage_cpu` routes device tensors through
@@ -122,24 +111,29 @@ class Comm:
         self.size = dist.get_world_size(group)
         backend = dist.get_backend(group)
         self.stage_cpu = (backend == 'gloo') if stage_cpu is None else stage_cpu
+        # DIE_DIST_SELF_VIA_BACKEND=1: messages a rank sends to itself (periodic self-neighbours) also go through
+        # the backend's send/recv instead of a local copy — lets a single GPU rehearse the RCCL call pattern
+        # (grouping, several messages per peer, matching order) that multi-GPU runs use.
+        self.self_local = os.environ.get('DIE_DIST_SELF_VIA_BACKEND', '0') != '1'
 
     def exchange(self, sends: Sequence[Tuple[int, torch.Tensor]], recvs: Sequence[Tuple[int, torch.Tensor]]):
         """Send every (peer, tensor) and fill every (peer, buffer).  Self-messages are copied."""
-        self_send = [t for p, t in sends if p == self.rank]
-        self_recv = [t for p, t in recvs if p == self.rank]
+        me = self.rank if self.self_local else -1
+        self_send = [t for p, t in sends if p == me]
+        self_recv = [t for p, t in recvs if p == me]
         assert len(self_send) == len(self_recv)
         for s, r in zip(self_send, self_recv):
             r.copy_(s.reshape(r.shape))
         ops, staged = [], []
         for p, t in sends:
-            if p == self.rank:
+            if p == me:
                 continue
             buf = t.contiguous()
             if self.stage_cpu and buf.is_cuda:
                 buf = buf.cpu()
             ops.append(dist.P2POp(dist.isend, buf, p, self.group))
         for p, t in recvs:
-            if p == self.rank:
+            if p == me:
                 continue
             if (self.stage_cpu and t.is_cuda) or not t.is_contiguous():
                 buf = torch.empty(t.shape, dtype=t.dtype, device='cpu' if self.stage_cpu else t.device)
@@ -219,10 +213,11 @@ def _exchange_blocks(planes, sends, recvs, comm: Comm, merge_max: bool, tag: str
         rmsg = [(peer, rbuf[roffs[k]:roffs[k + 1]]) for k, (peer, v) in enumerate(recvs)]
         ops = None
         if not comm.stage_cpu:                      # RCCL: the P2P ops over the persistent buffers are built once
-            selfs = [t for p_, t in smsg if p_ == comm.rank]
-            selfr = [t for p_, t in rmsg if p_ == comm.rank]
-            ops = ([dist.P2POp(dist.isend, t, p_, comm.group) for p_, t in smsg if p_ != comm.rank] +
-                   [dist.P2POp(dist.irecv, t, p_, comm.group) for p_, t in rmsg if p_ != comm.rank], list(zip(selfr, selfs)))
+            me = comm.rank if comm.self_local else -1
+            selfs = [t for p_, t in smsg if p_ == me]
+            selfr = [t for p_, t in rmsg if p_ == me]
+            ops = ([dist.P2POp(dist.isend, t, p_, comm.group) for p_, t in smsg if p_ != me] +
+                   [dist.P2POp(dist.irecv, t, p_, comm.group) for p_, t in rmsg if p_ != me], list(zip(selfr, selfs)))
         plan = (schunks, rchunks, sbuf, rbuf, smsg, rmsg, ops, planes)     # `planes` keeps the pointers alive
         cache[key] = plan
     schunks, rchunks, sbuf, rbuf, smsg, rmsg, ops, _ = plan
@@ -318,7 +313,7 @@ class DistEnv:
     def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], dynamics=None, *, probe_reach: int,
                  capacity: Optional[int] = None, device=None, group=None, field_dtype=torch.float32,
                  seed: int = 0, init: bool = True, sort_every: int = 8, overlap: bool = True,
-                 migrate_every: int = 1, max_step_cells: float = 2.0):
+                 migrate_every: int = 1, max_step_cells: float = 2.0, ghosts: bool = False):
         from . import _lib
         from .data_init import DataInitializer
         from .device_array import DeviceAgents, DeviceMedium
@@ -330,16 +325,38 @@ class DistEnv:
         # guard band: agents may stay on a rank for `migrate_every` steps after leaving its interior (their
         # claims are merged across ranks every step instead); a lifecycle that teleports slots needs M = 1
         self.migrate_every = 1 if self.dynamics.agents_die else max(1, int(migrate_every))
+        self.ghosts = bool(ghosts) and not self.dynamics.agents_die
         self.band = 0 if self.migrate_every == 1 else int(np.ceil(self.migrate_every * float(max_step_cells))) + 1
-        halo = self.band + int(probe_reach) + 1 + R
-        while (world[1] // grid[1] + 2 * halo) % 4:                    # die_diffuse_decay_tile needs H % 4 == 0
-            halo += 1
+        if self.ghosts:
+            # ghost agents: nothing crosses ranks for M steps.  Per step the exactly-known depth of the halo shrinks
+            # by (probe reach + 1 tap) + (longest step) + (diffusion radius): a ghost on the frontier senses that far
+            # beyond itself, its deposit diffuses R further (see _step_ghost).  One rank along an axis: no halo there.
+            self.band = 0
+            self._loss = int(probe_reach) + 1 + int(np.ceil(float(max_step_cells))) + R
+            deep = self.migrate_every * self._loss
+            hx = 0 if int(grid[0]) == 1 else deep
+            hy = 0 if int(grid[1]) == 1 else deep
+            while hy and (world[1] // grid[1] + 2 * hy) % 4:
+                hy += 1
+            if (hx and 2 * hx > world[0] // grid[0]) or (hy and 2 * hy > world[1] // grid[1]):
+                raise ValueError(f'ghost halo {(hx, hy)} needs tiles of at least twice that size (tile '
+                                 f'{(world[0] // grid[0], world[1] // grid[1])}): lower migrate_every')
+            halo = (hx, hy)
+        else:
+            halo = self.band + int(probe_reach) + 1 + R
+            while (world[1] // grid[1] + 2 * halo) % 4:                    # die_diffuse_decay_tile needs H % 4 == 0
+                halo += 1
+        self._probe_reach = int(probe_reach)
         self.geo = TileGeometry(world, grid, self.comm.rank, halo)
         self.R = R
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         g = self.geo
         self.medium = DeviceMedium((g.W, g.H), self.device, field_dtype)
         self.medium.world = (g.gW, g.gH, g.ox, g.oy)
+        if self.ghosts:
+            self.medium.own = (g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi)
+        self._ghosts_fresh = False
+        self._profile, self._prof = os.environ.get('DIE_DIST_PROFILE', '0') == '1', {}
         self._seed = int(seed)
         self._sort_every = int(sort_every)
         self._overlap = bool(overlap)
@@ -359,7 +376,9 @@ class DistEnv:
     def _alloc_agents(self, n_local: int):
         from .device_array import DeviceAgents
         from .data_init import DataInitializer
-        cap = self.capacity or max(int(n_local * 1.5) + 1024, 4096)
+        g = self.geo
+        grow = (1 + 2 * g.hx / g.Wi) * (1 + 2 * g.hy / g.Hi) if self.ghosts else 1.0
+        cap = self.capacity or max(int(n_local * 1.5 * grow) + 1024, 4096)
         self.capacity = cap
         A = DeviceAgents(cap, self.device)
         A.N = n_local
@@ -418,7 +437,8 @@ class DistEnv:
         local = medium[:, ix][:, :, iy]
         occ = local[0].copy()
         occ_int = np.zeros_like(occ)
-        occ_int[g.h:g.h + g.Wi, g.h:g.h + g.Hi] = occ[g.h:g.h + g.Wi, g.h:g.h + g.Hi]
+        ri, ci = g.interior()
+        occ_int[ri, ci] = occ[ri, ci]
         env.medium.upload(np.stack([occ_int, local[1], local[2]]))
         qx, qy = to_q32(agents[0]).astype(np.uint64), to_q32(agents[1]).astype(np.uint64)
         cx = ((qx * np.uint64(g.gW - 1) + np.uint64(2 ** 31)) >> np.uint64(32)).astype(np.int64)
@@ -518,9 +538,177 @@ class DistEnv:
     def step(self, action):
         """One decomposed env step.  Returns (obs, result_tensor): result is the LOCAL
         die_step_result; `read_result` all-reduces it."""
+        if self.ghosts:
+            return self._step_ghost(action)
         if self.migrate_every > 1:
             return self._step_guard_band(action)
         return self._step_migrate_each(action)
+
+    # ------------------------------------------------------------------ ghost-agent mode
+    def _step_ghost(self, action):
+        """Communication-avoiding mode: besides its own agents a rank steps GHOSTS, copies of the neighbours' agents
+        that stand in its halo.  Every per-agent computation is keyed by the world slot id, so a ghost and its
+        original do the same thing bit for bit as long as what they sense is the same; claims, feeding, deposits and
+        diffusion of the halo are recomputed locally instead of exchanged.  The depth to which the halo is exact
+        shrinks by probe reach + 1 + step + radius cells per step, so with a halo of M times that
+            M steps run with NO communication and no host synchronisation (the single-GPU kernels on the padded tile),
+        then `_refresh_ghosts` re-seats everything: agents are re-assigned by the cell they stand on (a rank already
+        holds a valid copy of whoever walked into its interior: nothing is handed over), ghosts are dropped and
+        re-sent from the owners' border bands, chem and food halos are exchanged — one message per neighbour.
+        reward / num_agents count the agents standing on interior cells (die_medium.own_*)."""
+        from .device_array import PendingAction, _ptr, stream_ptr
+        lib, A, M = self._lib, self.agents, self.medium
+        if not self._ghosts_fresh:
+            self._refresh_ghosts(action)
+        sp = stream_ptr(self.device)
+        d = self._c_dynamics()
+        M.next_epoch()
+        result = torch.empty(2, dtype=torch.float64, device=self.device)
+        ws, wsn = _ptr(self._workspace), self._workspace.numel()
+        second = not self._all_alive
+        if A.N > 0:
+            m, a = M.c_struct(), self._struct(A)
+            if isinstance(action, PendingAction) and action.pending and action.agents is A and action.medium is M:
+                self._check_reach(action)
+                self._check_seed(int(action.g_struct.seed))
+                u = action.raw_struct()
+                lib.check(lib.lib.die_forward_move_claim_tile(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u),
+                                                              C.byref(d), ws, wsn, sp), 'die_forward_move_claim_tile')
+                action.agent._forward_consumed(action)
+            else:
+                action.N = A.N
+                u = action.c_struct()
+                lib.check(lib.lib.die_agent_move_claim(C.byref(m), C.byref(a), C.byref(u), C.byref(d), ws, wsn, sp),
+                          'die_agent_move_claim')
+            u = action.c_struct()
+            if second:
+                lib.check(lib.lib.die_agent_dead_slots(C.byref(m), C.byref(a), C.byref(u), C.byref(d), ws, wsn, sp),
+                          'die_agent_dead_slots')
+            lib.check(lib.lib.die_step_reduce_ex(C.byref(a), _ptr(result), ws, wsn, 1 if second else 2, -1, sp),
+                      'die_step_reduce_ex')
+        else:
+            result.zero_()
+        m = M.c_struct()
+        lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), 0, sp),
+                  'die_medium_deposit_feed_diffuse_tile')
+        M.swap_chem()
+        self._steps += 1
+        if self._steps % self.migrate_every == 0:
+            self._refresh_ghosts(action)
+        if self._sort_every > 0 and self._steps % self._sort_every == 0 and A.N > 1:
+            self.sort_agents()
+        self.last_result = result
+        return self._get_current_obs, result
+
+    def _check_seed(self, seed: int):
+        """A ghost must draw what its original draws: every rank's Agent needs the same seed (once per seed value)."""
+        if getattr(self, '_seed_checked', None) == seed:
+            return
+        seeds = self.comm.all_gather_counts(torch.tensor([seed & 0x7FFFFFFFFFFFFFFF], dtype=torch.int64, device=self.device))
+        if int(seeds.min()) != int(seeds.max()):
+            raise ValueError('ghost-agent mode: the Agent objects of all ranks must be built with the same seed '
+                             '(random streams are keyed by world slot id, not by rank)')
+        self._seed_checked = seed
+
+    def _cells(self):
+        """World cell of every local agent, as offsets from this rank's interior origin (periodic)."""
+        A, g = self.agents, self.geo
+        n = A.N
+        cx = ((A.x[:n].to(torch.int64) & 0xFFFFFFFF) * (g.gW - 1) + (1 << 31)) >> 32
+        cy = ((A.y[:n].to(torch.int64) & 0xFFFFFFFF) * (g.gH - 1) + (1 << 31)) >> 32
+        return (cx - g.x0) % g.gW, (cy - g.y0) % g.gH
+
+    def owned_mask(self) -> torch.Tensor:
+        """Which local agents this rank accounts for (ghost mode: those standing on interior cells)."""
+        if not self.ghosts:
+            return torch.ones(self.agents.N, dtype=torch.bool, device=self.device)
+        lx, ly = self._cells()
+        return (lx < self.geo.Wi) & (ly < self.geo.Hi)
+
+    def _tick(self, name=None):
+        """DIE_DIST_PROFILE=1: synchronising phase timer for _refresh_ghosts (scratch/ghost_phases.py reads self._prof)."""
+        if not self._profile:
+            return
+        import time
+        torch.cuda.synchronize(self.device)
+        now = time.perf_counter()
+        if name is not None:
+            self._prof[name] = self._prof.get(name, 0.0) + now - self._t_last
+        self._t_last = now
+
+    def _refresh_ghosts(self, action):
+        from .device_array import stream_ptr
+        A, g, comm, lib = self.agents, self.geo, self.comm, self._lib
+        n = A.N
+        self._tick()
+        lx, ly = self._cells()
+        keep = (lx < g.Wi) & (ly < g.Hi)
+        near = {(-1, 0): lx < g.hx, (1, 0): lx >= g.Wi - g.hx, (0, -1): ly < g.hy, (0, 1): ly >= g.Hi - g.hy}
+        idx = []
+        for dx, dy in g.DIRS:                                  # copies for the neighbour on side (dx, dy)
+            m = keep
+            if dx:
+                m = m & near[(dx, 0)]
+            if dy:
+                m = m & near[(0, dy)]
+            idx.append(torch.nonzero(m, as_tuple=False).squeeze(1))
+        nd = len(g.DIRS)
+        counts = torch.tensor([int(i.numel()) for i in idx] + [int(keep.sum())], dtype=torch.int64, device=self.device)
+        self._tick('plan (cells, masks, index lists)')
+        matrix = comm.all_gather_counts(counts)                # host: matrix[rank] = (per-side counts…, owned)
+        self._tick('count all_gather')
+        owned_world = int(matrix[:, -1].sum())
+        if owned_world != self.world_agents:
+            raise RuntimeError(f'ghost refresh: {owned_world} agents are owned, the world has {self.world_agents}: an agent moved '
+                               f'further than max_step_cells per step or sensed further than probe_reach')
+        tensors = self._per_agent_tensors(action)
+        arrs, ptrs, esz = self._record_arrays(tensors)
+        sp = stream_ptr(self.device)
+        sends, recvs, parts = [], [], []
+        if nd:
+            out_idx = torch.cat(idx)
+            L = int(out_idx.numel())
+            rec = torch.empty((len(arrs), max(L, 1)), dtype=torch.int32, device=self.device)
+            if L:
+                lib.check(lib.lib.die_records_gather(ptrs, esz, len(arrs), C.c_void_p(out_idx.data_ptr()), L,
+                                                     C.c_void_p(rec.data_ptr()), sp), 'die_records_gather')
+            start = 0
+            for k, (dx, dy) in enumerate(g.DIRS):              # k-th send to a peer meets the k-th receive posted for it
+                c = int(matrix[comm.rank, k])
+                if c:
+                    sends.append((g.neighbour(dx, dy), rec[:, start:start + c].contiguous()))
+                start += c
+            for dx, dy in reversed(g.DIRS):                    # what arrives for my side (dx, dy) left as side (−dx, −dy)
+                peer = g.neighbour(dx, dy)
+                c = int(matrix[peer, g.DIRS.index((-dx, -dy))])
+                if c:
+                    buf = torch.empty((len(arrs), c), dtype=torch.int32, device=self.device)
+                    recvs.append((peer, buf))
+                    parts.append(buf)
+            self._tick('records gather')
+            comm.exchange(sends, recvs)
+            self._tick('records exchange')
+        arrivals = torch.cat(parts, dim=1).contiguous() if parts else None
+        n_arr = int(arrivals.shape[1]) if arrivals is not None else 0
+        n_new, arr_dst, mv_src, mv_dst = fill_holes(n, ~keep if n else torch.zeros(1, dtype=torch.bool, device=self.device), n_arr)
+        if n_new > self.capacity:
+            raise RuntimeError(f'rank {comm.rank}: {n_new} agents (ghosts included) exceed the local capacity {self.capacity}')
+        if mv_src.numel():
+            tmp = torch.empty((len(arrs), int(mv_src.numel())), dtype=torch.int32, device=self.device)
+            lib.check(lib.lib.die_records_gather(ptrs, esz, len(arrs), C.c_void_p(mv_src.data_ptr()), mv_src.numel(),
+                                                 C.c_void_p(tmp.data_ptr()), sp), 'die_records_gather')
+            lib.check(lib.lib.die_records_scatter(ptrs, esz, len(arrs), C.c_void_p(mv_dst.data_ptr()), mv_dst.numel(),
+                                                  C.c_void_p(tmp.data_ptr()), sp), 'die_records_scatter')
+        if n_arr:
+            lib.check(lib.lib.die_records_scatter(ptrs, esz, len(arrs), C.c_void_p(arr_dst.data_ptr()), n_arr,
+                                                  C.c_void_p(arrivals.data_ptr()), sp), 'die_records_scatter')
+        A.N = n_new
+        action.N = n_new
+        self._tick('compaction + scatter')
+        if nd:
+            halo_exchange([self.medium.chem, self.medium.food], g, comm, self._plans)
+        self._tick('chem + food halo exchange')
+        self._ghosts_fresh = True
 
     # ------------------------------------------------------------------ guard-band mode
     def _step_guard_band(self, action):
@@ -617,6 +805,11 @@ class DistEnv:
 
     def _check_reach(self, action):
         g = self.geo
+        if self.ghosts:
+            reach = int(np.ceil(abs(float(action.g_struct.sense_offset)) * (max(g.gW, g.gH) - 1)))
+            if reach > self._probe_reach:
+                raise ValueError(f'the agent senses {reach} cells ahead, DistEnv was built for probe_reach={self._probe_reach}')
+            return
         reach = int(np.ceil(abs(float(action.g_struct.sense_offset)) * (max(g.gW, g.gH) - 1))) + 1 + self.R + self.band
         if reach > g.h:
             raise ValueError(f'probe reach + guard band = {reach} cells exceeds the halo {g.h}: build DistEnv with a larger '
@@ -740,10 +933,11 @@ class DistEnv:
         tile = np.stack([self.medium.sel(c)[ri, ci].to(torch.float64).cpu().numpy() for c in self.medium.channels])
         n = A.N
         from .device_array import Q32
+        own = self.owned_mask().cpu().numpy()
         rows = np.stack([(A.x[:n].to(torch.int64) & 0xFFFFFFFF).to(torch.float64).cpu().numpy() / Q32,
                          (A.y[:n].to(torch.int64) & 0xFFFFFFFF).to(torch.float64).cpu().numpy() / Q32,
-                         A.alive[:n].to(torch.float64).cpu().numpy(), A.agent_food[:n].to(torch.float64).cpu().numpy()])
-        slots = A.slot[:n].cpu().numpy().astype(np.int64)
+                         A.alive[:n].to(torch.float64).cpu().numpy(), A.agent_food[:n].to(torch.float64).cpu().numpy()])[:, own]
+        slots = A.slot[:n].cpu().numpy().astype(np.int64)[own]
         payload = (g.rank, tile, rows, slots)
         out = [None] * self.comm.size
         dist.all_gather_object(out, payload, group=self.comm.group)
@@ -752,7 +946,7 @@ class DistEnv:
         medium = np.zeros((3, g.gW, g.gH))
         agents = np.zeros((4, self.world_agents))
         for r, t, rw, sl in out:
-            tg = TileGeometry((g.gW, g.gH), (g.Px, g.Py), r, g.h)
+            tg = TileGeometry((g.gW, g.gH), (g.Px, g.Py), r, (g.hx, g.hy))
             medium[:, tg.x0:tg.x0 + tg.Wi, tg.y0:tg.y0 + tg.Hi] = t
             agents[:, sl] = rw
         return medium, agents

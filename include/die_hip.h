@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 7
+#define DIE_ABI_VERSION 8
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -75,6 +75,11 @@ typedef struct die_medium {
      * inside the tile (the halo is filled by the caller's exchange). */
     int32_t gW, gH;
     int32_t ox, oy;
+    /* Ghost-agent decomposition: a rank also steps copies of its neighbours' agents that stand in
+     * its halo, so reward / num_alive must only count the agents standing on the cells this rank accounts for:
+     * local rows [own_x0, own_x1) × columns [own_y0, own_y1).  own_x1 == 0: every cell counts.
+     * An axis with W == gW (one rank along it) has no halo and is periodic inside the tile. */
+    int32_t own_x0, own_y0, own_x1, own_y1;
 } die_medium;
 
 /* The (4, N) agent array of core/data_init.py:114-150, structure of arrays. */

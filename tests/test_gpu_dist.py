@@ -26,18 +26,23 @@ def _state(W, H, N, K, seed):
     return medium, agents, dir0
 
 
-def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path):
+def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=size)
+    if backend == 'nccl':        # one rank: its periodic self-neighbour messages go through RCCL send/recv
+        os.environ['DIE_DIST_SELF_VIA_BACKEND'] = '1'
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device('cuda:0'))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=size)
     try:
         import die_amd
         from die_amd.dist import DistEnv
         medium, agents, dir0 = _state(W, H, N, K, 5)
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
         env = DistEnv.from_global_numpy(medium, agents, grid, probe_reach=11, device='cuda:0', sort_every=sort_every,
-                                        overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6)
+                                        overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts)
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
         local = torch.zeros(cap, dtype=torch.float32, device='cuda:0')
@@ -55,10 +60,13 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('grid,sort_every,overlap,migrate_every', [((1, 2), 0, True, 1), ((2, 1), 3, False, 1), ((2, 2), 0, False, 1),
-                                                                    ((2, 2), 2, True, 1), ((2, 2), 2, True, 4), ((1, 2), 0, False, 3),
-                                                                    ((2, 1), 3, True, 5)])
-def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, overlap, migrate_every):
+@pytest.mark.parametrize('grid,sort_every,overlap,migrate_every,backend', [
+    ((1, 2), 0, True, 1, 'gloo'), ((2, 1), 3, False, 1, 'gloo'), ((2, 2), 0, False, 1, 'gloo'), ((2, 2), 2, True, 1, 'gloo'),
+    ((2, 2), 2, True, 4, 'gloo'), ((1, 2), 0, False, 3, 'gloo'), ((2, 1), 3, True, 5, 'gloo'),
+    # the RCCL transport itself: a 1x1 "decomposition" whose 8 periodic neighbours are the rank itself, every halo /
+    # claim-merge message sent and received through RCCL (8 messages to one peer per exchange, matched in issue order)
+    ((1, 1), 2, True, 1, 'nccl'), ((1, 1), 0, True, 4, 'nccl')])
+def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, overlap, migrate_every, backend):
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import torch.multiprocessing as mp
@@ -66,7 +74,8 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     W, H, N, K, steps = 128, 96, 2000, 1800, 12
     out = str(tmp_path / 'dist.npz')
     size = grid[0] * grid[1]
-    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out), nprocs=size, join=True)
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out, backend),
+             nprocs=size, join=True)
     got = np.load(out)
 
     medium, agents, dir0 = _state(W, H, N, K, 5)
@@ -84,6 +93,44 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     assert np.array_equal(got['medium'][1], m[1])
     assert np.array_equal(got['medium'][2], m[2])
     r = np.array(rewards)
+    assert np.array_equal(got['rewards'][:, 1], r[:, 1])
+    assert np.allclose(got['rewards'][:, 0], r[:, 0], rtol=1e-12, atol=1e-12)
+
+
+def _single_device_run(W, H, N, K, steps):
+    import die_amd
+    medium, agents, dir0 = _state(W, H, N, K, 5)
+    env = die_amd.Env.from_numpy(medium, agents, sort_every=0)
+    agent = die_amd.PhysarumAgent(max_agents=N, seed=9, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
+    agent.set_state(dir0)
+    obs = env._get_current_obs
+    rewards = []
+    for _ in range(steps):
+        obs, rew, _, _, info = env.step(agent.forward(obs))
+        rewards.append((rew, info['num_agents']))
+    return env.medium.to_numpy(), env.agents.to_numpy(), np.array(rewards)
+
+
+@pytest.mark.parametrize('grid,sort_every,refresh_every,backend', [
+    ((1, 2), 0, 2, 'gloo'), ((2, 1), 3, 3, 'gloo'), ((2, 2), 2, 2, 'gloo'), ((2, 2), 0, 3, 'gloo'), ((2, 2), 4, 1, 'gloo'),
+    ((1, 1), 2, 4, 'nccl')])
+def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, refresh_every, backend):
+    """Communication-avoiding mode: ghosts of the neighbours' border agents are stepped locally, nothing crosses
+    ranks for `refresh_every` steps; world state and rewards must equal the single-device run bit for bit
+    (dead slots included: N > K)."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    W, H, N, K, steps = 256, 192, 7000, 6400, 13
+    out = str(tmp_path / 'dist.npz')
+    size = grid[0] * grid[1]
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, False, refresh_every, out, backend, True),
+             nprocs=size, join=True)
+    got = np.load(out)
+    m, a, r = _single_device_run(W, H, N, K, steps)
+    assert np.array_equal(got['agents'], a)
+    for c in range(3):
+        assert np.array_equal(got['medium'][c], m[c])
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
     assert np.allclose(got['rewards'][:, 0], r[:, 0], rtol=1e-12, atol=1e-12)
 
