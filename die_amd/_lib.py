@@ -109,6 +109,13 @@ _SIGNATURES = {
     'die_rects_unpack_max': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_records_gather': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_records_scatter': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    'die_ghost_workspace_bytes': (C.c_int64, [C.c_int64]),
+    'die_ghost_plan': (C.c_int, [_P(Medium), _P(Agents), C.c_int32, _P(C.c_int8), _P(C.c_void_p), _P(C.c_int64), C.c_void_p,
+                                 C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_records_gather_dev': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
+    'die_records_scatter_at': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                         C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
                                   C.c_int64, C.c_void_p]),

@@ -313,7 +313,7 @@ class DistEnv:
     def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], dynamics=None, *, probe_reach: int,
                  capacity: Optional[int] = None, device=None, group=None, field_dtype=torch.float32,
                  seed: int = 0, init: bool = True, sort_every: int = 8, overlap: bool = True,
-                 migrate_every: int = 1, max_step_cells: float = 2.0, ghosts: bool = False):
+                 migrate_every: int = 1, max_step_cells: float = 2.0, ghosts: bool = False, ghost_headroom: float = 2.0):
         from . import _lib
         from .data_init import DataInitializer
         from .device_array import DeviceAgents, DeviceMedium
@@ -333,6 +333,7 @@ class DistEnv:
             # beyond itself, its deposit diffuses R further (see _step_ghost).  One rank along an axis: no halo there.
             self.band = 0
             self._loss = int(probe_reach) + 1 + int(np.ceil(float(max_step_cells))) + R
+            self._loss += int(os.environ.get('DIE_GHOST_LOSS_DELTA', '0'))      # testing: shows the bound is tight
             deep = self.migrate_every * self._loss
             hx = 0 if int(grid[0]) == 1 else deep
             hy = 0 if int(grid[1]) == 1 else deep
@@ -356,6 +357,8 @@ class DistEnv:
         if self.ghosts:
             self.medium.own = (g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi)
         self._ghosts_fresh = False
+        self._ghost_headroom = float(ghost_headroom)
+        self._owned = None
         self._profile, self._prof = os.environ.get('DIE_DIST_PROFILE', '0') == '1', {}
         self._seed = int(seed)
         self._sort_every = int(sort_every)
@@ -637,6 +640,150 @@ class DistEnv:
         self._t_last = now
 
     def _refresh_ghosts(self, action):
+        """Re-seat owners, ghosts and the chem / food halos (see _step_ghost)."""
+        if self.device.type == 'cuda' and os.environ.get('DIE_GHOST_REFRESH', 'native') != 'torch':
+            return self._refresh_ghosts_native(action)
+        return self._refresh_ghosts_torch(action)
+
+    # -- native refresh: one classification pass, records packed straight into fixed-size messages that also carry the
+    #    field bands, ONE grouped send/recv per refresh, one host read (counts) -------------------------------------
+    def _build_ghost_plan(self, F: int):
+        from types import SimpleNamespace
+        lib, g, dev = self._lib, self.geo, self.device
+        nd = len(g.DIRS)
+        P = SimpleNamespace(F=F, nd=nd, rects={})
+        dens = self.world_agents / float(g.gW * g.gH)
+        P.caps = []
+        for dx, dy in g.DIRS:                         # identical on every rank: depends on the side's shape only
+            rs, cs = g._band(dx, dy)
+            cells = (rs.stop - rs.start) * (cs.stop - cs.start)
+            P.caps.append(int(min(self.capacity, np.ceil(cells * dens * self._ghost_headroom) + 1024)))
+        P.lists = [torch.empty(c, dtype=torch.int32, device=dev) for c in P.caps] + \
+                  [torch.empty(self.capacity, dtype=torch.int32, device=dev)]
+        P.list_ptrs = (C.c_void_p * (nd + 1))(*[t.data_ptr() for t in P.lists])
+        P.list_caps = (C.c_int64 * (nd + 1))(*(P.caps + [self.capacity]))
+        P.dirs = (C.c_int8 * max(2 * nd, 1))(*[v for d in g.DIRS for v in d])
+        P.totals = torch.zeros(nd + 2, dtype=torch.int64, device=dev)
+        P.ws = torch.empty(lib.lib.die_ghost_workspace_bytes(self.capacity), dtype=torch.uint8, device=dev)
+        esz = self.medium.chem.element_size()
+        P.off, off = [], 0                             # per side: (header, records, chem block, food block, end)
+        for k, (dx, dy) in enumerate(g.DIRS):
+            rs, cs = g._band(dx, dy)
+            blk = ((rs.stop - rs.start) * (cs.stop - cs.start) * esz + 7) & ~7
+            hdr, rec = off, off + 16
+            chem = rec + F * P.caps[k] * 4
+            chem = (chem + 7) & ~7
+            food = chem + blk
+            off = food + blk
+            P.off.append((hdr, rec, chem, food, off))
+        P.sbuf = torch.zeros(max(off, 8), dtype=torch.uint8, device=dev)
+        P.rbuf = torch.zeros(max(off, 8), dtype=torch.uint8, device=dev)
+        # the message arriving for my side d was packed by the neighbour as its side −d: same shape, same size
+        P.recv_order = list(reversed(range(nd)))       # receives are posted in reversed side order (see plan8)
+        P.smsg = [(g.neighbour(*g.DIRS[k]), P.sbuf[P.off[k][0]:P.off[k][4]]) for k in range(nd)]
+        P.rmsg = [(g.neighbour(*g.DIRS[k]), P.rbuf[P.off[k][0]:P.off[k][4]]) for k in P.recv_order]
+        P.hdr_idx = torch.tensor([P.off[k][0] // 8 for k in range(nd)], dtype=torch.int64, device=dev)
+        P.ops = None
+        if nd and not self.comm.stage_cpu:
+            P.ops = ([dist.P2POp(dist.isend, t, p_, self.comm.group) for p_, t in P.smsg] +
+                     [dist.P2POp(dist.irecv, t, p_, self.comm.group) for p_, t in P.rmsg])
+        return P
+
+    def _ghost_field_rects(self, P):
+        lib, g, M = self._lib, self.geo, self.medium
+        key = (M.chem.data_ptr(), M.food.data_ptr())
+        r = P.rects.get(key)
+        if r is None:
+            send, recv = [], []
+            for k, (dx, dy) in enumerate(g.DIRS):
+                send += [_slice_rect(lib, M.chem, g._band(dx, dy), P.off[k][2]), _slice_rect(lib, M.food, g._band(dx, dy), P.off[k][3])]
+                recv += [_slice_rect(lib, M.chem, g._halo(dx, dy), P.off[k][2]), _slice_rect(lib, M.food, g._halo(dx, dy), P.off[k][3])]
+            chunk = lambda rects: [((lib.Rect * len(c))(*c), len(c)) for c in (rects[i:i + 16] for i in range(0, len(rects), 16))]
+            r = (chunk(send), chunk(recv), (M.chem, M.food))
+            P.rects[key] = r
+        return r
+
+    def _refresh_ghosts_native(self, action):
+        from .device_array import _ptr, stream_ptr
+        A, g, comm, lib, dev = self.agents, self.geo, self.comm, self._lib, self.device
+        n = A.N
+        self._tick()
+        tensors = self._per_agent_tensors(action)
+        arrs, ptrs, esz = self._record_arrays(tensors)
+        F = len(arrs)
+        P = getattr(self, '_gplan', None)
+        if P is None or P.F != F:
+            P = self._gplan = self._build_ghost_plan(F)
+        nd, sp = P.nd, stream_ptr(dev)
+        m, a = self.medium.c_struct(), self._struct(A)
+        lib.check(lib.lib.die_ghost_plan(C.byref(m), C.byref(a), nd, P.dirs, P.list_ptrs, P.list_caps, _ptr(P.totals),
+                                         _ptr(P.ws), P.ws.numel(), sp), 'die_ghost_plan')
+        sb, rb = P.sbuf.data_ptr(), P.rbuf.data_ptr()
+        for k in range(nd):
+            lib.check(lib.lib.die_records_gather_dev(ptrs, esz, F, _ptr(P.lists[k]), C.c_void_p(P.totals.data_ptr() + 8 * k),
+                                                     P.caps[k], C.c_void_p(sb + P.off[k][1]), C.c_void_p(sb + P.off[k][0]), sp),
+                      'die_records_gather_dev')
+        self._tick('plan + record pack')
+        if nd:
+            send_r, recv_r, _ = self._ghost_field_rects(P)
+            for arr, cnt in send_r:
+                lib.check(lib.lib.die_rects_pack(arr, cnt, C.c_void_p(sb), sp), 'die_rects_pack')
+            self._tick('field pack')
+            if P.ops is None:
+                comm.exchange(P.smsg, P.rmsg)
+            else:
+                for req in dist.batch_isend_irecv(P.ops):
+                    req.wait()
+            self._tick('exchange (records + fields, one message per side)')
+            for arr, cnt in recv_r:
+                lib.check(lib.lib.die_rects_unpack(arr, cnt, C.c_void_p(rb), sp), 'die_rects_unpack')
+            t = torch.cat([P.totals, P.rbuf.view(torch.int64)[P.hdr_idx]]).cpu().tolist()        # the one host read
+        else:
+            t = P.totals.cpu().tolist()
+        sent, H, kept, arrived = t[:nd], t[nd], t[nd + 1], t[nd + 2:]
+        self._tick('field unpack + counts to host')
+        if kept + H != n:
+            raise RuntimeError(f'ghost refresh: {kept} owned + {H} dropped != {n} local agents')
+        for k in range(nd):
+            if sent[k] > P.caps[k] or arrived[k] > P.caps[k]:
+                raise RuntimeError(f'ghost refresh: {max(sent[k], arrived[k])} agents in the band of side {g.DIRS[k]}, the messages hold '
+                                   f'{P.caps[k]}: build DistEnv with a larger ghost_headroom (agents cluster at this border)')
+        self._owned = kept
+        n_arr = sum(arrived)
+        holes = P.lists[nd][:H]
+        if n_arr >= H:
+            n_new = n + n_arr - H
+            arr_dst = torch.cat([holes, torch.arange(n, n_new, dtype=torch.int32, device=dev)]) if n_arr > H else holes
+        else:
+            n_new = n - (H - n_arr)
+            arr_dst = holes[:n_arr]
+            rest = holes[n_arr:].to(torch.int64)
+            low = rest[rest < n_new]                                   # holes that stay inside the new prefix …
+            mask = torch.ones(n - n_new, dtype=torch.bool, device=dev)
+            mask[rest[rest >= n_new] - n_new] = False
+            tail = torch.nonzero(mask, as_tuple=False).squeeze(1) + n_new   # … are filled by the kept entries of the cut tail
+            if tail.numel():
+                tmp = torch.empty((F, int(tail.numel())), dtype=torch.int32, device=dev)
+                lib.check(lib.lib.die_records_gather(ptrs, esz, F, C.c_void_p(tail.data_ptr()), tail.numel(),
+                                                     C.c_void_p(tmp.data_ptr()), sp), 'die_records_gather')
+                lib.check(lib.lib.die_records_scatter(ptrs, esz, F, C.c_void_p(low.data_ptr()), low.numel(),
+                                                      C.c_void_p(tmp.data_ptr()), sp), 'die_records_scatter')
+        if n_new > self.capacity:
+            raise RuntimeError(f'rank {comm.rank}: {n_new} agents (ghosts included) exceed the local capacity {self.capacity}')
+        start = 0
+        for k in range(nd):                       # message k of the receive buffer = what arrived for my side DIRS[k]
+            c = arrived[k]
+            if c:
+                lib.check(lib.lib.die_records_scatter_at(ptrs, esz, F, C.c_void_p(arr_dst.data_ptr() + 4 * start), c, P.caps[k],
+                                                         C.c_void_p(rb + P.off[k][1]), sp), 'die_records_scatter_at')
+            start += c
+        A.N = n_new
+        action.N = n_new
+        self._tick('compaction + record unpack')
+        self._ghosts_fresh = True
+
+    # -- the same refresh written with torch index operations (cross-check of the native path: DIE_GHOST_REFRESH=torch) --
+    def _refresh_ghosts_torch(self, action):
         from .device_array import stream_ptr
         A, g, comm, lib = self.agents, self.geo, self.comm, self._lib
         n = A.N
@@ -657,6 +804,7 @@ class DistEnv:
         self._tick('plan (cells, masks, index lists)')
         matrix = comm.all_gather_counts(counts)                # host: matrix[rank] = (per-side counts…, owned)
         self._tick('count all_gather')
+        self._owned = int(matrix[comm.rank, -1])
         owned_world = int(matrix[:, -1].sum())
         if owned_world != self.world_agents:
             raise RuntimeError(f'ghost refresh: {owned_world} agents are owned, the world has {self.world_agents}: an agent moved '
@@ -917,12 +1065,18 @@ class DistEnv:
         self._workspace[n:3 * n].zero_()
 
     def read_result(self, result: torch.Tensor) -> Tuple[float, int]:
-        """World-wide (reward, num_agents): scalar all-reduce of the local results."""
+        """World-wide (reward, num_agents): scalar all-reduce of the local results.  Ghost mode also sums the owned
+        agents counted at the last refresh: every world agent must have exactly one owner."""
         host = result.cpu()
-        pair = torch.tensor([float(host[0]), float(int(host.view(torch.int64)[1]))], dtype=torch.float64)
+        owned = float(self._owned) if (self.ghosts and self._owned is not None) else -1.0
+        trip = torch.tensor([float(host[0]), float(int(host.view(torch.int64)[1])), owned], dtype=torch.float64)
         if not self.comm.stage_cpu:
-            pair = pair.to(self.device)
-        tot = self.comm.all_reduce_sum(pair).cpu()
+            trip = trip.to(self.device)
+        tot = self.comm.all_reduce_sum(trip).cpu()
+        if owned >= 0 and int(round(float(tot[2]))) != self.world_agents:
+            raise RuntimeError(f'ghost-agent mode: {int(round(float(tot[2])))} agents were owned at the last refresh, the world has '
+                               f'{self.world_agents}: an agent moved further than max_step_cells per step or sensed further than '
+                               f'probe_reach (ghosts diverged from their originals)')
         return float(tot[0]), int(round(float(tot[1])))
 
     # ------------------------------------------------------------------ gathering (tests, checkpoints)

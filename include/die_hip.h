@@ -297,6 +297,25 @@ int die_records_gather(void* const* arrays, const int32_t* elem_bytes, int32_t n
 int die_records_scatter(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int64_t* idx, int64_t count,
                         const int32_t* records_in, void* stream);
 
+/* ---- Ghost-agent refresh (die_amd/dist.py DistEnv._refresh_ghosts; no reference counterpart) ----
+ * die_ghost_plan classifies every local agent of a ghost-agent tile (die_medium.own_* set): agents standing on an
+ * interior cell are owned; of those, the ones within the halo depth (own_x0 / own_y0 cells) of side
+ * (dirs[2k], dirs[2k+1]) ∈ {-1,0,1}² are listed in lists[k] — their copies become that neighbour's ghosts; every
+ * other agent (a ghost, or an agent that walked out) is listed in lists[n_dirs] (holes).  Lists hold ascending
+ * 32-bit array indices (deterministic: count per block, scan, fill), at most caps[k] entries each;
+ * totals[0..n_dirs) = full list lengths (may exceed caps: the caller checks), totals[n_dirs] = holes,
+ * totals[n_dirs + 1] = owned agents.  ws: die_ghost_workspace_bytes(N) bytes of device memory. */
+int64_t die_ghost_workspace_bytes(int64_t N);
+int die_ghost_plan(const die_medium* medium, const die_agents* agents, int32_t n_dirs, const int8_t* dirs,
+                   int32_t* const* lists, const int64_t* caps, int64_t* totals, void* ws, int64_t ws_bytes, void* stream);
+/* die_records_gather with the count on the device: packs min(*count_dev, cap) records of the 32-bit index list into
+ * the (n, cap) matrix of a message and writes the true count to header_out (may be NULL). */
+int die_records_gather_dev(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int32_t* idx,
+                           const int64_t* count_dev, int64_t cap, int32_t* records_out, int64_t* header_out, void* stream);
+/* die_records_scatter for a 32-bit index list and a record matrix with row pitch `pitch` >= count. */
+int die_records_scatter_at(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int32_t* idx, int64_t count,
+                           int64_t pitch, const int32_t* records_in, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,8 +6,23 @@ def free_port():
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0)); return s.getsockname()[1]
 
+GHOST = os.environ.get('FUZZ_GHOST', '0') == '1'
+
 def make_case(seed):
     rs = np.random.RandomState(seed)
+    if GHOST:        # ghost-agent mode: bounded steps only, tiles at least twice the halo
+        grid = [(1, 2), (2, 1), (2, 2), (1, 3), (3, 1), (1, 4)][rs.randint(6)]
+        me = int(rs.choice([1, 2, 3]))
+        Wi = int(rs.choice([112, 128, 160])); Hi = int(rs.choice([112, 128, 144]))
+        W, H = Wi * grid[0], Hi * grid[1]
+        N = int(rs.choice([1500, 9000])); K = int(N * rs.choice([0.6, 1.0]))
+        reach = int(np.ceil(max(6.2 / (W - 1), 0.03) * (max(W, H) - 1)))
+        step = max(1.53 / (W - 1), 0.01 * 1.5) * (max(W, H) - 1) + 0.5
+        loss = reach + 1 + int(np.ceil(step)) + 2
+        while me > 1 and 2 * (me * loss + 3) > min(Wi if grid[0] > 1 else 10 ** 6, Hi if grid[1] > 1 else 10 ** 6):
+            me -= 1
+        return dict(grid=grid, W=W, H=H, N=N, K=K, agent=str(rs.choice(['physarum', 'gradient'])), boundary=str(rs.choice(['wrap', 'limit'])),
+                    agents_die=False, steps=int(rs.choice([7, 10])), migrate_every=me, sort_every=int(rs.choice([0, 2, 3])), seed=seed, ghosts=True)
     grid = [(1, 2), (2, 1), (2, 2), (1, 4), (4, 1), (1, 3), (3, 1)][rs.randint(7)]
     Wi = int(rs.choice([48, 64, 80])); Hi = int(rs.choice([44, 64, 96]))
     W, H = Wi * grid[0], Hi * grid[1]
@@ -46,7 +61,7 @@ def worker(rank, size, port, case, out):
         from die_amd.dist import DistEnv
         medium, agents, dir0, prev, dyn = build(case, die_amd)
         env = DistEnv.from_global_numpy(medium, agents, case['grid'], dyn, probe_reach=int(np.ceil(max(6.2 / (case['W'] - 1), 0.03) * (max(case['W'], case['H']) - 1))), device='cuda:0', sort_every=case['sort_every'],
-                                        capacity=case['N'] + 64, migrate_every=case['migrate_every'],
+                                        capacity=case['N'] + 64, migrate_every=case['migrate_every'], ghosts=case.get('ghosts', False),
                                         max_step_cells=max(1.53 / (case['W'] - 1), 0.01 * 1.5) * (max(case['W'], case['H']) - 1) + 0.5)
         ag = make_agent(case, die_amd, env.capacity)
         if case['agent'] != 'brownian':
@@ -91,5 +106,5 @@ if __name__ == '__main__':
             assert np.array_equal(got['medium'], m), 'medium'
             print('ok  ', case, flush=True)
         except Exception as e:
-            fails += 1; print('FAIL', case, type(e).__name__, str(e)[:300], flush=True)
+            fails += 1; print('FAIL', case, type(e).__name__, str(e)[-400:].replace(chr(10), ' | '), flush=True)
     print(f'fuzz dist: {fails} failures', flush=True)

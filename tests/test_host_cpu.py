@@ -40,7 +40,7 @@ def test_header_symbols_exported(built_lib):
 def test_struct_layouts_match_header(built_lib):
     from die_amd import _lib
     # sizes follow from the field lists in include/die_hip.h under the x86-64 SysV ABI
-    assert C.sizeof(_lib.Medium) == 4 * 4 + 4 * 8 + 4 * 4
+    assert C.sizeof(_lib.Medium) == 4 * 4 + 4 * 8 + 4 * 4 + 4 * 4
     assert C.sizeof(_lib.Agents) == 8 + 5 * 8
     assert C.sizeof(_lib.Action) == 8 + 3 * 8
     assert C.sizeof(_lib.Dynamics) == 10 * 4
