@@ -45,6 +45,15 @@ def test_tile_geometry():
         TileGeometry((64, 48), (2, 2), 0, 40)
     g1 = TileGeometry((16, 16), (1, 1), 0, 4)
     assert g1.neighbour(1, 0) == 0 and g1.neighbour(0, -1) == 0
+    # per-axis halos (ghost-agent mode): one rank along x → no halo there, only the y sides exchange
+    g2 = TileGeometry((64, 48), (1, 2), 1, (0, 8))
+    assert (g2.W, g2.H, g2.ox, g2.oy, g2.hx, g2.hy) == (64, 24 + 16, 0, 24 - 8, 0, 8)
+    assert g2.DIRS == [(0, -1), (0, 1)] and g2.interior() == (slice(0, 64), slice(8, 32))
+    assert g2._band(0, -1) == (slice(0, 64), slice(8, 16)) and g2._halo(0, 1) == (slice(0, 64), slice(32, 40))
+    sends, recvs = g2.plan8()
+    assert [p for p, _ in sends] == [0, 0] and [v for _, v in recvs] == [g2._halo(0, 1), g2._halo(0, -1)]
+    with pytest.raises(ValueError):
+        TileGeometry((64, 48), (2, 2), 0, (0, 8))          # an axis without halo needs exactly one rank
 
 
 def _halo_case(rank, size, world, grid, h):
@@ -62,7 +71,8 @@ def _halo_case(rank, size, world, grid, h):
 
 
 @pytest.mark.parametrize('size,world,grid,h', [(2, (12, 16), (1, 2), 3), (2, (16, 12), (2, 1), 4), (4, (16, 24), (2, 2), 5),
-                                                (1, (8, 8), (1, 1), 3), (4, (32, 8), (4, 1), 2)])
+                                                (1, (8, 8), (1, 1), 3), (4, (32, 8), (4, 1), 2),
+                                                (2, (12, 16), (1, 2), (0, 4)), (4, (32, 8), (4, 1), (3, 0))])
 def test_halo_exchange_is_periodic_including_corners(size, world, grid, h):
     _run(size, _halo_case, world, grid, h)
 
