@@ -123,6 +123,22 @@ def time_kernels(env, agent, reps):
     return out
 
 
+def copy_ceiling_gbs(device, mb=512, reps=10):
+    """Measured device-copy ceiling of this box: read + write bytes of a plain D2D copy per second."""
+    import torch
+    src = torch.empty(mb << 20, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * (mb << 20) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def cpu_baseline(env, agent_kw, n_steps, seed):
     """The float64 numpy/scipy oracle on the same initial state (downloaded from the device)."""
     import numpy as np
@@ -283,6 +299,7 @@ def main():
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},
+            'copy_ceiling_gbs': round(copy_ceiling_gbs(device), 1),
             'step': {'algorithmic_bytes': B['step'],
                      'achieved': round(B['step'] / (dt / args.steps) / 1e9, 1),
                      'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -216,3 +216,42 @@ extern "C" int die_init_heading(float* heading, float* prev_gx, float* prev_gy, 
     DIE_CHECK_LAUNCH("die_init_heading");
     return DIE_OK;
 }
+
+// ---- food flow: WaveSequence.get_flow_operator (core/data_init.py:29-38,71-89) --------------------------------
+// food ← scale·z(x, y, t) + (1 − decay)·food with the reference's running-wave field z; x varies along the last
+// axis and y along the first (core/utils.py:113-118 builds the grid from the reversed sizes).  float64 arithmetic,
+// one rounding to the field dtype.  Tiles evaluate z at their world cells.
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_food_flow_wave(T* food, die_geo g, double t, double scale, double keep) {
+    const int64_t total = (int64_t)g.W * g.H;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const double pi = 3.141592653589793;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int li = (int)(i / g.H), lj = (int)(i - (int64_t)li * g.H);
+        int gi = (li + g.ox) % g.gW, gj = (lj + g.oy) % g.gH;
+        gi = gi < 0 ? gi + g.gW : gi;
+        gj = gj < 0 ? gj + g.gH : gj;
+        // np.linspace(0, 1, n)[k] = k·(1/(n−1)); then (v − 0.5)·2
+        const double x = ((double)gj * (1.0 / (double)(g.gH - 1)) - 0.5) * 2.0;
+        const double y = ((double)gi * (1.0 / (double)(g.gW - 1)) - 0.5) * 2.0;
+        const double r = sqrt(x * x + y * y);
+        const double rwave = r + cos(pi * x) + sin(0.4 * pi * y);
+        const double z_waves = cos(1.0 * pi * (rwave + t));
+        const double z_islands = sin(pi * x * 3.0 + t) + cos(pi * y * 3.0 + t);
+        const double z = (1.0 - 0.25) * z_waves + 0.25 * z_islands;
+        die_st(food, i, (float)(scale * z + keep * (double)die_ld(food, i)));
+    }
+}
+
+extern "C" int die_food_flow_wave(const die_medium* m, double t, double scale, double decay, void* stream) {
+    DIE_REQUIRE(m && m->food && m->W >= 1 && m->H >= 1, "die_food_flow_wave: bad medium");
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "die_food_flow_wave: bad field dtype %d", m->dtype);
+    const die_geo g = die_geo_of(m);
+    DIE_REQUIRE(g.gW >= 2 && g.gH >= 2, "die_food_flow_wave: the world must be at least 2x2");
+    const int64_t total = (int64_t)m->W * m->H;
+    const int grid = init_grid(total);
+    if (m->dtype == DIE_F32) k_food_flow_wave<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((float*)m->food, g, t, scale, 1.0 - decay);
+    else k_food_flow_wave<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((__half*)m->food, g, t, scale, 1.0 - decay);
+    DIE_CHECK_LAUNCH("die_food_flow_wave");
+    return DIE_OK;
+}

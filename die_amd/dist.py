@@ -595,6 +595,7 @@ class DistEnv:
         lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), 0, sp),
                   'die_medium_deposit_feed_diffuse_tile')
         M.swap_chem()
+        self._food_flow()
         self._steps += 1
         if self._steps % self.migrate_every == 0:
             self._refresh_ghosts(action)
@@ -612,6 +613,18 @@ class DistEnv:
             raise ValueError('ghost-agent mode: the Agent objects of all ranks must be built with the same seed '
                              '(random streams are keyed by world slot id, not by rank)')
         self._seed_checked = seed
+
+    def _food_flow(self):
+        """Env._medium_resource_dynamics (core/env.py:147-150) on the padded tile: the WaveSequence operator evaluates
+        its field at world cells, so halo cells get what their owners compute."""
+        from .env import _identity_food_flow
+        op = self.dynamics.op_food_flow
+        if op is _identity_food_flow:
+            return
+        from .data_init import WaveFoodFlow
+        if not isinstance(op, WaveFoodFlow):
+            raise NotImplementedError('decomposed worlds run device-side food-flow operators only (WaveSequence.get_flow_operator)')
+        op.apply(self.medium)
 
     def _cells(self):
         """World cell of every local agent, as offsets from this rank's interior origin (periodic)."""
@@ -908,6 +921,7 @@ class DistEnv:
         lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), 0, sp),
                   'die_medium_deposit_feed_diffuse_tile')
         M.swap_chem()
+        self._food_flow()
         self._steps += 1
         if self._steps % self.migrate_every == 0:
             self._hand_over_strays(action)
@@ -1020,6 +1034,7 @@ class DistEnv:
         lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), g.h, sp),
                   'die_medium_deposit_feed_diffuse_tile')
         M.swap_chem()
+        self._food_flow()
         self._steps += 1
         if self._sort_every > 0 and self._steps % self._sort_every == 0 and A.N > 1:
             self.sort_agents()

@@ -205,7 +205,7 @@ class Env(_EnvBase):
                        'die_env_step')
         self.medium.swap_chem()
         if self.dynamics.op_food_flow is not _identity_food_flow:
-            self._host_food_flow()
+            self._food_flow()
         self._steps += 1
         if self._sort_every > 0 and self._steps % self._sort_every == 0:
             self.sort_agents()
@@ -225,8 +225,14 @@ class Env(_EnvBase):
         host = result.cpu()
         return float(host[0]), int(host.view(torch.int64)[1])
 
-    def _host_food_flow(self):
-        """core/env.py:147-150 for arbitrary Python operators: host round trip."""
+    def _food_flow(self):
+        """core/env.py:147-150.  The WaveSequence operator runs on the device (die_food_flow_wave); an arbitrary Python
+        operator needs a host round trip.  (It touches env_food only, so running it after the chem sweep instead of
+        before it, as the reference does, gives the same state.)"""
+        from .data_init import WaveFoodFlow
+        if isinstance(self.dynamics.op_food_flow, WaveFoodFlow):
+            self.dynamics.op_food_flow.apply(self.medium)
+            return
         food = self.medium.food.to(torch.float64).cpu().numpy()
         self.medium.upload_channel('env_food', np.asarray(self.dynamics.op_food_flow(food)))
 

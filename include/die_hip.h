@@ -266,6 +266,11 @@ int die_init_agents(const die_medium* m, const die_agents* a, uint64_t seed, int
 int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, float turn_radians,
                      uint64_t seed, void* stream);
 
+/* Env._medium_resource_dynamics (core/env.py:147-150) with the flow operator of WaveSequence.get_flow_operator
+ * (core/data_init.py:29-38): food <- scale * z(x, y, t) + (1 - decay) * food, z = WaveSequence.__getitem__(t)
+ * (core/data_init.py:71-89) evaluated at the world cell of every local element; float64 arithmetic. */
+int die_food_flow_wave(const die_medium* medium, double t, double scale, double decay, void* stream);
+
 /* ---- spatial re-ordering of the agent arrays (no reference counterpart; see die_sort.hip) ----
  * Writes `in` permuted into `out` (different arrays, out->slot required) so that array
  * neighbours are grid neighbours: stable sort by the (ix/8, iy/64) bucket of each agent's cell.

@@ -26,7 +26,13 @@ def _state(W, H, N, K, seed):
     return medium, agents, dir0
 
 
-def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False):
+def _wave_dynamics(die_amd, W, H):
+    """'dyn-pred' of examples/simple_agents.py:95-100: food flows in running waves."""
+    return die_amd.Dynamics(op_food_flow=die_amd.WaveSequence((W, H), dt=0.01).get_flow_operator(scale=0.5, decay=0.5))
+
+
+def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
+            wave=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -41,7 +47,8 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         from die_amd.dist import DistEnv
         medium, agents, dir0 = _state(W, H, N, K, 5)
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
-        env = DistEnv.from_global_numpy(medium, agents, grid, probe_reach=11, device='cuda:0', sort_every=sort_every,
+        env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H) if wave else None, probe_reach=11,
+                                        device='cuda:0', sort_every=sort_every,
                                         overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts)
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
@@ -97,10 +104,10 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     assert np.allclose(got['rewards'][:, 0], r[:, 0], rtol=1e-12, atol=1e-12)
 
 
-def _single_device_run(W, H, N, K, steps):
+def _single_device_run(W, H, N, K, steps, wave=False):
     import die_amd
     medium, agents, dir0 = _state(W, H, N, K, 5)
-    env = die_amd.Env.from_numpy(medium, agents, sort_every=0)
+    env = die_amd.Env.from_numpy(medium, agents, _wave_dynamics(die_amd, W, H) if wave else None, sort_every=0)
     agent = die_amd.PhysarumAgent(max_agents=N, seed=9, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
     agent.set_state(dir0)
     obs = env._get_current_obs
@@ -111,10 +118,10 @@ def _single_device_run(W, H, N, K, steps):
     return env.medium.to_numpy(), env.agents.to_numpy(), np.array(rewards)
 
 
-@pytest.mark.parametrize('grid,sort_every,refresh_every,backend', [
-    ((1, 2), 0, 2, 'gloo'), ((2, 1), 3, 3, 'gloo'), ((2, 2), 2, 2, 'gloo'), ((2, 2), 0, 3, 'gloo'), ((2, 2), 4, 1, 'gloo'),
-    ((1, 1), 2, 4, 'nccl')])
-def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, refresh_every, backend):
+@pytest.mark.parametrize('grid,sort_every,refresh_every,backend,wave', [
+    ((1, 2), 0, 2, 'gloo', False), ((2, 1), 3, 3, 'gloo', False), ((2, 2), 2, 2, 'gloo', False), ((2, 2), 0, 3, 'gloo', True),
+    ((2, 2), 4, 1, 'gloo', False), ((1, 1), 2, 4, 'nccl', True)])
+def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, refresh_every, backend, wave):
     """Communication-avoiding mode: ghosts of the neighbours' border agents are stepped locally, nothing crosses
     ranks for `refresh_every` steps; world state and rewards must equal the single-device run bit for bit
     (dead slots included: N > K)."""
@@ -124,10 +131,10 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
     W, H, N, K, steps = 256, 192, 7000, 6400, 13
     out = str(tmp_path / 'dist.npz')
     size = grid[0] * grid[1]
-    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, False, refresh_every, out, backend, True),
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, False, refresh_every, out, backend, True, wave),
              nprocs=size, join=True)
     got = np.load(out)
-    m, a, r = _single_device_run(W, H, N, K, steps)
+    m, a, r = _single_device_run(W, H, N, K, steps, wave)
     assert np.array_equal(got['agents'], a)
     for c in range(3):
         assert np.array_equal(got['medium'][c], m[c])

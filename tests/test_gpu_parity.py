@@ -783,6 +783,44 @@ def test_custom_food_flow_and_render(die):
     assert frames[2][..., 3].sum() == K
 
 
+@pytest.mark.parametrize('W,H', [(48, 48), (40, 64)])
+def test_wave_sequence_food_flow_on_device(die, W, H):
+    """WaveSequence.get_flow_operator (core/data_init.py:29-38,71-89; the 'dyn-pred' dynamics of
+    examples/simple_agents.py:95-100) as a device kernel: the field itself and an env run that uses it as
+    Dynamics.op_food_flow, against the oracle's restatement (pinned by the reference-made vectors in tests/golden)."""
+    N, K = 500, 400
+    seq = die.WaveSequence((W, H), dt=0.01)
+    assert len(seq) == 1000 and 3.0 in seq and 10.0 not in seq
+    for t in (0.0, 0.37, 9.99):
+        assert np.abs(seq[t] - R.wave_field(W, H, t)).max() < 5e-7          # stored as fp32
+    rs = np.random.RandomState(3)
+    medium, agents = random_state(W, H, N, K, rs)
+    ts = np.arange(0, 10, 0.01)
+    calls = [0]
+
+    def ref_flow(food):                                                     # scale·next(it) + (1 − decay)·current
+        z = R.wave_field(W, H, ts[calls[0] % len(ts)])
+        calls[0] += 1
+        return 0.5 * z + (1 - 0.5) * food
+
+    dyn = die.Dynamics(op_food_flow=seq.get_flow_operator(scale=0.5, decay=0.5))
+    rdyn = R.RefDynamics(op_food_flow=ref_flow, rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)))
+    env, ref = die.Env.from_numpy(medium, agents, dyn), R.RefEnv(medium, agents, rdyn)
+    for _ in range(4):
+        action = quantised_action(N, rs, 2.0 / W)
+        _, rew, *_ = env.step(action)
+        _, rrew, *_ = ref.step(action)
+        assert abs(rew - rrew) <= 1e-5 * max(1.0, abs(rrew))
+    m = env.medium.to_numpy()
+    assert np.allclose(m[1], ref.medium[1], rtol=RTOL, atol=2e-6)
+    assert np.allclose(m[2], ref.medium[2], rtol=RTOL, atol=1e-7)
+    assert np.array_equal(m[0], ref.medium[0])
+    # the operator also accepts host arrays, as the reference's does
+    op = seq.get_flow_operator(scale=2.0, decay=0.25)
+    f0 = rs.rand(W, H)
+    assert np.abs(op(f0) - (2.0 * R.wave_field(W, H, 0.0) + 0.75 * f0)).max() < 1e-6
+
+
 def test_minimal_run_example(die):
     """The port of the reference's examples/minimal_run.py runs end to end (both agents)."""
     import importlib.util
