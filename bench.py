@@ -56,7 +56,7 @@ def algorithmic_bytes(C, K):
     }
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v4_pmc_traffic_per_kernel_avg.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v4_pmc_traffic_per_kernel_avg.json')   # the kernels' traffic has not changed since
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
