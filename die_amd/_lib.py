@@ -105,6 +105,8 @@ _SIGNATURES = {
     'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
     'die_food_flow_wave': (C.c_int, [_P(Medium), C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    'die_render_frames': (C.c_int, [_P(Medium), C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]),
     'die_rects_pack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_rects_unpack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_rects_unpack_max': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),

@@ -313,8 +313,16 @@ class Env(_EnvBase):
         return np.stack(np.meshgrid(*xcs))
 
     def render(self):
-        """core/env.py:133-134: [medium RGB (W, H, 3), agent-trace RGBA, agents RGBA]."""
-        from .render import EnvRenderer
+        """core/env.py:133-134: [medium RGB (W, H, 3), agent-trace RGBA, agents RGBA], built on the device
+        (die_render_frames) and downloaded as float32 images."""
+        from .render import DeviceRenderer
         if self._renderer is None:
-            self._renderer = EnvRenderer(self._field_size)
-        return self._renderer.render(self.medium.to_numpy(), self.agents.to_numpy())
+            self._renderer = DeviceRenderer(self._field_size, self.device)
+        return self._renderer.render(self.medium, self.agents)
+
+    def render_rgb8(self) -> np.ndarray:
+        """The medium frame as one (W, H, 3) uint8 image — what a per-step plot loop needs to download."""
+        from .render import DeviceRenderer
+        if self._renderer is None:
+            self._renderer = DeviceRenderer(self._field_size, self.device)
+        return self._renderer.rgb8(self.medium)

@@ -271,6 +271,14 @@ int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, 
  * (core/data_init.py:71-89) evaluated at the world cell of every local element; float64 arithmetic. */
 int die_food_flow_wave(const die_medium* medium, double t, double scale, double decay, void* stream);
 
+/* EnvRenderer.render (core/render.py:76-110) on the device, one sweep: rgb_out (W, H, 3) float32 = (agents,
+ * env_food, chem1); trace <- trace * trace_decay + agents (FieldTrace.update, :29-30) and rgba_out (W, H, 4) =
+ * lut[index(trace)] with matplotlib's Colormap.__call__ index rule, lut = (lut_n + 3, 4) float32 (colours, under,
+ * over, bad); rgb8_out (W, H, 3) uint8 = clip(rgb, 0, 1) * 255.  Any output may be NULL (trace may be NULL when
+ * rgba_out is). */
+int die_render_frames(const die_medium* medium, float* trace, float trace_decay, const float* lut, int32_t lut_n,
+                      float* rgb_out, float* rgba_out, uint8_t* rgb8_out, void* stream);
+
 /* ---- spatial re-ordering of the agent arrays (no reference counterpart; see die_sort.hip) ----
  * Writes `in` permuted into `out` (different arrays, out->slot required) so that array
  * neighbours are grid neighbours: stable sort by the (ix/8, iy/64) bucket of each agent's cell.

@@ -783,6 +783,33 @@ def test_custom_food_flow_and_render(die):
     assert frames[2][..., 3].sum() == K
 
 
+def test_device_render_matches_the_host_renderer(die):
+    """Env.render() builds the frames of core/render.py:76-132 on the device (die_render_frames); the checker is the
+    same renderer run on downloaded float64 arrays, as the reference does it, over several steps (the trace has state)."""
+    from die_amd.render import EnvRenderer
+    W, H, N, K = 40, 56, 700, 520
+    rs = np.random.RandomState(4)
+    medium, agents = random_state(W, H, N, K, rs)
+    env = die.Env.from_numpy(medium, agents)
+    host = EnvRenderer((W, H))
+    for step in range(6):
+        env.step(quantised_action(N, rs, 2.0 / W))
+        frames = env.render()
+        want = host.render(env.medium.to_numpy(), env.agents.to_numpy())
+        assert [f.shape for f in frames] == [w.shape for w in want]
+        assert np.array_equal(frames[0], want[0].astype(np.float32))                 # the three channels, bit for bit
+        assert np.array_equal(frames[2], want[2].astype(np.float32))
+        # trace image: fp32 vs float64 accumulation may pick the neighbouring colour of the 256-entry table
+        assert np.abs(frames[1] - want[1]).max() < 0.02
+        assert (np.abs(frames[1] - want[1]).max(axis=-1) > 1e-6).mean() < 0.01
+    assert np.allclose(env._renderer._trace.cpu().numpy(), host._agent_trace.trace, rtol=1e-6, atol=1e-7)
+    img = env.render_rgb8()
+    assert img.dtype == np.uint8 and img.shape == (W, H, 3)
+    m = env.medium.to_numpy()
+    want8 = (np.clip(np.stack([m[0], m[1], m[2]], axis=-1), 0, 1).astype(np.float32) * np.float32(255) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(img, want8)
+
+
 @pytest.mark.parametrize('W,H', [(48, 48), (40, 64)])
 def test_wave_sequence_food_flow_on_device(die, W, H):
     """WaveSequence.get_flow_operator (core/data_init.py:29-38,71-89; the 'dyn-pred' dynamics of
