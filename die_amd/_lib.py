@@ -17,14 +17,15 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class Medium(C.Structure):
     _fields_ = [('W', C.c_int32), ('H', C.c_int32), ('dtype', C.c_int32), ('epoch', C.c_int32),
                 ('owner', C.c_void_p), ('food', C.c_void_p), ('chem', C.c_void_p), ('chem_next', C.c_void_p),
                 ('gW', C.c_int32), ('gH', C.c_int32), ('ox', C.c_int32), ('oy', C.c_int32),
-                ('own_x0', C.c_int32), ('own_y0', C.c_int32), ('own_x1', C.c_int32), ('own_y1', C.c_int32)]
+                ('own_x0', C.c_int32), ('own_y0', C.c_int32), ('own_x1', C.c_int32), ('own_y1', C.c_int32),
+                ('sense_mask', C.c_void_p)]
 
 
 class Agents(C.Structure):
@@ -105,6 +106,7 @@ _SIGNATURES = {
     'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
     'die_food_flow_wave': (C.c_int, [_P(Medium), C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    'die_sense_mask': (C.c_int, [_P(Medium), C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'die_render_frames': (C.c_int, [_P(Medium), C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     'die_rects_pack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),

@@ -72,7 +72,7 @@ int die_fill_fwd_args(FwdArgs& k, const die_medium* m, const die_agents* a, cons
     DIE_REQUIRE(g->kind == DIE_AGENT_GRADIENT || g->kind == DIE_AGENT_PHYSARUM, "%s: bad kind %d", who, g->kind);
     DIE_REQUIRE(g->inertia == 0.f || (g->prev_gx && g->prev_gy), "%s: inertia needs prev_gx/prev_gy", who);
     k.g = geo; k.N = a->N;
-    k.chem = m->chem; k.food = m->food; k.x = a->x; k.y = a->y; k.slot = a->slot;
+    k.chem = m->chem; k.food = m->food; k.mask = m->sense_mask; k.x = a->x; k.y = a->y; k.slot = a->slot;
     k.heading = g->heading; k.pgx = g->prev_gx; k.pgy = g->prev_gy; k.turn_sign = g->turn_sign;
     k.dx = out ? out->dx : nullptr; k.dy = out ? out->dy : nullptr; k.dep = out ? out->deposit : nullptr;
     k.scale = g->scale; k.deposit = g->deposit; k.inertia = g->inertia; k.sense_offset = g->sense_offset;

@@ -10,6 +10,7 @@ struct FwdArgs {
     int64_t N;
     const void* chem;
     const void* food;
+    const uint8_t* mask;       // Dynamics.apply_sense_mask: cells with 0 read as 0 (core/env.py:276-295); NULL = all visible
     const uint32_t* x;
     const uint32_t* y;
     const uint32_t* slot;
@@ -89,15 +90,17 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
 #ifdef DIE_ABL_NOGATHER
     const float cxm = (float)xm, cxp = (float)xp * 1.5f, cym = (float)ym, cyp = (float)(yp + py);
 #else
-    const float cxm = die_ld(chem, die_local(g, xm, py)), cxp = die_ld(chem, die_local(g, xp, py));
-    const float cym = die_ld(chem, die_local(g, px, ym)), cyp = die_ld(chem, die_local(g, px, yp));
+    // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
+    auto seen = [&](const T* p, const int64_t i) { return (a.mask && !a.mask[i]) ? 0.f : die_ld(p, i); };
+    const float cxm = seen(chem, die_local(g, xm, py)), cxp = seen(chem, die_local(g, xp, py));
+    const float cym = seen(chem, die_local(g, px, ym)), cyp = seen(chem, die_local(g, px, yp));
 #endif
     // food under the agent (gradient.py:114-116)
     const int cx = die_cell((int64_t)X, W), cy = die_cell((int64_t)Y, H);
 #ifdef DIE_ABL_NOFOOD
     const float f_own = (float)(cx + cy);
 #else
-    const float f_own = die_ld(food, die_local(g, cx, cy));
+    const float f_own = (a.mask && !a.mask[die_local(g, cx, cy)]) ? 0.f : die_ld(food, die_local(g, cx, cy));
 #endif
     const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
     const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);

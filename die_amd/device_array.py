@@ -58,7 +58,8 @@ class DeviceMedium:
     def c_struct(self) -> _lib.Medium:
         return _lib.Medium(self.W, self.H, _lib.DIE_F32 if self.dtype == torch.float32 else _lib.DIE_F16, self.epoch,
                            _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next),
-                           *(self.world or (0, 0, 0, 0)), *(getattr(self, 'own', None) or (0, 0, 0, 0)))
+                           *(self.world or (0, 0, 0, 0)), *(getattr(self, 'own', None) or (0, 0, 0, 0)),
+                           _ptr(self.sense_mask) if getattr(self, 'sense_mask', None) is not None else None)
 
     def next_epoch(self):
         """Advance the ownership epoch; zero the plane when the 3-bit tag wraps."""
@@ -69,6 +70,13 @@ class DeviceMedium:
 
     def swap_chem(self):
         self.chem, self.chem_next = self.chem_next, self.chem
+
+    def observed_numpy(self) -> np.ndarray:
+        """What the agents see (core/env.py:292-295): the medium with the cells outside the sense mask zeroed.
+        Without Dynamics.apply_sense_mask this is to_numpy()."""
+        m = self.to_numpy()
+        mask = getattr(self, 'sense_mask', None)
+        return m if mask is None else np.where(mask.cpu().numpy().astype(bool), m, 0.)
 
     def occupied(self) -> torch.Tensor:
         """Boolean (W, H): the 'agents' channel > 0."""

@@ -320,6 +320,8 @@ class DistEnv:
         from .env import Dynamics
         self._lib = _lib
         self.dynamics = dynamics or Dynamics()
+        if self.dynamics.apply_sense_mask:
+            raise NotImplementedError('apply_sense_mask is implemented for single-tile worlds only')
         self.comm = Comm(group)
         R = int(4.0 * float(self.dynamics.diffuse_sigma) + 0.5)
         # guard band: agents may stay on a rank for `migrate_every` steps after leaving its interior (their

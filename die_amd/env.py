@@ -96,8 +96,6 @@ class Env(_EnvBase):
         d = self.dynamics
         if d.diffuse_mode != 'wrap':
             raise NotImplementedError(f"diffuse_mode={d.diffuse_mode!r}: only 'wrap' is implemented on device")
-        if d.apply_sense_mask:
-            raise NotImplementedError('apply_sense_mask is not implemented on device')
         if d.op_action_cost not in (linear_action_cost, zero_cost):
             raise NotImplementedError('op_action_cost must be linear_action_cost or zero_cost on device')
         if self._field_size[0] < 2 or self._field_size[1] < 2:
@@ -117,6 +115,19 @@ class Env(_EnvBase):
         self._shadow = None
         self._sort_ws = None
         self._fuse_forward = True           # False once die_forward_env_step reports the shape unsupported
+        self.medium.sense_mask = None
+        if self.dynamics.apply_sense_mask:
+            W, H = self._field_size
+            self.medium.sense_mask = torch.ones((W, H), dtype=torch.uint8, device=self.device)
+            self._sense_tmp = torch.empty((W, H), dtype=torch.float64, device=self.device)
+            self._update_sense_mask()
+
+    def _update_sense_mask(self):
+        """Env._get_sense_mask (core/env.py:276-290): the neighbourhood of the agents channel the next forward() may
+        see — sigma 2.0, 3 decimals, as the reference hard-codes them."""
+        m = self.medium.c_struct()
+        _lib.check(_lib.lib.die_sense_mask(C.byref(m), 2.0, 3, _ptr(self.medium.sense_mask), _ptr(self._sense_tmp),
+                                           stream_ptr(self.device)), 'die_sense_mask')
 
 
     @classmethod
@@ -206,6 +217,8 @@ class Env(_EnvBase):
         self.medium.swap_chem()
         if self.dynamics.op_food_flow is not _identity_food_flow:
             self._food_flow()
+        if self.dynamics.apply_sense_mask:
+            self._update_sense_mask()
         self._steps += 1
         if self._sort_every > 0 and self._steps % self._sort_every == 0:
             self.sort_agents()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 8
+#define DIE_ABI_VERSION 9
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -80,6 +80,9 @@ typedef struct die_medium {
      * local rows [own_x0, own_x1) × columns [own_y0, own_y1).  own_x1 == 0: every cell counts.
      * An axis with W == gW (one rank along it) has no halo and is periodic inside the tile. */
     int32_t own_x0, own_y0, own_x1, own_y1;
+    /* Dynamics.apply_sense_mask (core/env.py:276-295): W*H bytes from die_sense_mask; the forward kernels read the
+     * chem / food of a cell with mask 0 as 0.  NULL: everything is visible. */
+    const uint8_t* sense_mask;
 } die_medium;
 
 /* The (4, N) agent array of core/data_init.py:114-150, structure of arrays. */
@@ -270,6 +273,11 @@ int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, 
  * (core/data_init.py:29-38): food <- scale * z(x, y, t) + (1 - decay) * food, z = WaveSequence.__getitem__(t)
  * (core/data_init.py:71-89) evaluated at the world cell of every local element; float64 arithmetic. */
 int die_food_flow_wave(const die_medium* medium, double t, double scale, double decay, void* stream);
+
+/* Env._get_sense_mask (core/env.py:276-290): mask = ceil(round(gaussian(agents channel, sigma, mode 'nearest',
+ * truncate 4), decimals)) as W*H bytes (the reference uses sigma 2.0, 3 decimals); float64 accumulation, axis 0
+ * then axis 1 as scipy does.  tmp: W*H doubles of device scratch.  Periodic single-tile planes only. */
+int die_sense_mask(const die_medium* medium, float sigma, int32_t decimals, uint8_t* mask_out, double* tmp, void* stream);
 
 /* EnvRenderer.render (core/render.py:76-110) on the device, one sweep: rgb_out (W, H, 3) float32 = (agents,
  * env_food, chem1); trace <- trace * trace_decay + agents (FieldTrace.update, :29-30) and rgba_out (W, H, 4) =

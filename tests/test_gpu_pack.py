@@ -138,7 +138,7 @@ def test_ghost_plan_matches_numpy_classification(lib, grid, rank, halo):
     plane = torch.zeros((g.W, g.H), dtype=torch.float32, device='cuda')
     own = torch.zeros((g.W, g.H), dtype=torch.int64, device='cuda')
     m = lib.Medium(g.W, g.H, lib.DIE_F32, 1, own.data_ptr(), plane.data_ptr(), plane.data_ptr(), plane.data_ptr(),
-                   gW, gH, g.ox, g.oy, g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi)
+                   gW, gH, g.ox, g.oy, g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi, None)
     a = lib.Agents(n, x.data_ptr(), y.data_ptr(), None, None, None)
     caps = [n] * (nd + 1)
     caps[0] = 5                                                     # a list shorter than its population: truncated, total still exact

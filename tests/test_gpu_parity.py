@@ -848,6 +848,43 @@ def test_wave_sequence_food_flow_on_device(die, W, H):
     assert np.abs(op(f0) - (2.0 * R.wave_field(W, H, 0.0) + 0.75 * f0)).max() < 1e-6
 
 
+def test_sense_mask_parity(die):
+    """Dynamics.apply_sense_mask (core/env.py:276-295): the agents only see the medium within the blurred
+    neighbourhood of the agents channel.  Mask plane bit for bit against the oracle (scipy gaussian, mode 'nearest',
+    round(3), ceil), the masked observation, and forward() on it, over two env steps."""
+    W, H, N, K = 96, 80, 120, 70
+    rs = np.random.RandomState(12)
+    medium, agents = random_state(W, H, N, K, rs)
+    dyn = die.Dynamics(apply_sense_mask=True)
+    rdyn = R.RefDynamics(apply_sense_mask=True, rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)))
+    env, ref = die.Env.from_numpy(medium, agents, dyn), R.RefEnv(medium, agents, rdyn)
+    kw = dict(scale=0.01, deposit=4.5, inertia=0.9, sense_offset=0.05, noise_scale=0.0)
+    prev = f32(rs.normal(0, .4, (2, N)))
+    ragent = R.RefGradientAgent(N, init_noise=prev, seed=5, **kw)
+    ragent._direction_rads = f32(ragent._direction_rads)
+    agent = die.GradientAgent(max_agents=N, seed=5, **kw)
+    agent.set_state(ragent._direction_rads.copy(), prev)
+    for step in range(3):
+        want_mask = ref.sense_mask().astype(bool)
+        assert 0.2 < want_mask.mean() < 0.9                                   # the mask hides a real part of the field
+        assert np.array_equal(env.medium.sense_mask.cpu().numpy().astype(bool), want_mask)
+        seen = env.medium.observed_numpy()
+        assert np.allclose(seen, ref.obs[1], rtol=RTOL, atol=1e-7) and (seen[2][~want_mask] == 0).all()
+        # teacher forcing: both sides sense the device's (fp32) medium through the same mask
+        robs = (env.agents.to_numpy(), np.where(want_mask, env.medium.to_numpy(), 0.))
+        ragent._prev_grad = agent.prev_grad_numpy().astype(np.float64)
+        ragent._direction_rads = agent.direction_rads_numpy().astype(np.float64)
+        want = ragent.forward(robs)
+        got = agent.forward(env._get_current_obs).to_numpy()
+        assert np.allclose(got, want, rtol=RTOL, atol=2e-8)
+        hidden_probe = ~want_mask[R.cell(robs[0][0] + 0.05 * np.cos(ragent._direction_rads), W),
+                                  R.cell(robs[0][1] + 0.05 * np.sin(ragent._direction_rads), H)]
+        action = quantised_action(N, rs, 2.0 / W)
+        env.step(action)
+        ref.medium, ref.agents = env.medium.to_numpy(), env.agents.to_numpy()    # keep the oracle on the device state
+    assert hidden_probe.shape == (N,)
+
+
 def test_minimal_run_example(die):
     """The port of the reference's examples/minimal_run.py runs end to end (both agents)."""
     import importlib.util

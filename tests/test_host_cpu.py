@@ -40,7 +40,7 @@ def test_header_symbols_exported(built_lib):
 def test_struct_layouts_match_header(built_lib):
     from die_amd import _lib
     # sizes follow from the field lists in include/die_hip.h under the x86-64 SysV ABI
-    assert C.sizeof(_lib.Medium) == 4 * 4 + 4 * 8 + 4 * 4 + 4 * 4
+    assert C.sizeof(_lib.Medium) == 4 * 4 + 4 * 8 + 4 * 4 + 4 * 4 + 8
     assert C.sizeof(_lib.Agents) == 8 + 5 * 8
     assert C.sizeof(_lib.Action) == 8 + 3 * 8
     assert C.sizeof(_lib.Dynamics) == 10 * 4
@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu(built_lib):
     assert _lib.lib.die_workspace_bytes(4096, 4096, 4096 * 4096) >= 4096 * 4096 * 4
     rc = _lib.lib.die_diffuse_decay(None, None, 8, 8, 0, 0.5, 0.1, None)
     assert rc == -1 and b'non-null' in _lib.lib.die_last_error()
-    m = _lib.Medium(1, 1, 0, 1, None, None, None, None, 0, 0, 0, 0)
+    m = _lib.Medium(1, 1, 0, 1, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, None)
     a = _lib.Agents(0, None, None, None, None, None)
     g = _lib.GradientAgent()
     u = _lib.Action(0, None, None, None)
