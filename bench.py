@@ -205,14 +205,15 @@ def main():
             denv = None
             mode = f'{world} independent grid replicas (decomposition unavailable: {type(e).__name__}: {e})'
     if denv is not None:
-        # two trial steps before committing to the decomposed path: a transport that fails at the first exchange
-        # must not cost the scaling run its line (all ranks agree on the outcome; on failure: replicas, and say so)
+        # trial steps before committing to the decomposed path: a transport that fails at the first exchanges must
+        # not cost the scaling run its line (all ranks agree on the outcome; on failure: replicas, and say so)
         ok, why = 1, ''
         try:
             trial_agent = die_amd.PhysarumAgent(max_agents=denv.capacity, seed=args.seed, **agent_kw)   # one seed: streams are keyed by world slot id
             o = denv._get_current_obs
-            for _ in range(2):
-                o, *_ = denv.step(trial_agent.forward(o))
+            for _ in range(2 * denv.migrate_every + 1):          # covers two refreshes / hand-overs over the real transport
+                o, res, *_ = denv.step(trial_agent.forward(o))
+            denv.read_result(res)                                # ghost mode: every world agent has exactly one owner
             torch.cuda.synchronize()
         except Exception as e:
             ok, why = 0, f'{type(e).__name__}: {e}'
@@ -228,44 +229,62 @@ def main():
             denv = None
             agent_kw.update(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
             mode = f'{world} independent grid replicas (decomposed step failed: {why or "on another rank"})'
-    if denv is not None:
-        env = denv
-        K = env.agents.N
-    else:
-        env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
-                          max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
-                          field_dtype=torch.float16 if args.fields == 'f16' else torch.float32)
-        K = env.agents.N
-        agent = die_amd.PhysarumAgent(max_agents=K, seed=args.seed + rank, **agent_kw)
-
-    obs = env._get_current_obs
-    results = []
-
-    def one_step():
-        nonlocal obs
-        obs, res, *_ = env.step(agent.forward(obs))
-        return res
-
     def barrier():
         if dist_on:
-            dist.barrier()
+            try:
+                dist.barrier()
+            except Exception:
+                if denv is not None:       # the decomposed run needs it; replicas after a transport failure do not
+                    raise
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        results.append(one_step())
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed_run(env, agent):
+        obs = env._get_current_obs
+        results = []
+        for _ in range(args.warmup):
+            obs, res, *_ = env.step(agent.forward(obs))
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            obs, res, *_ = env.step(agent.forward(obs))
+            results.append(res)
+        torch.cuda.synchronize()
+        barrier()
+        return time.perf_counter() - t0, results
+
+    def replica():
+        e = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
+                        max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
+                        field_dtype=torch.float16 if args.fields == 'f16' else torch.float32)
+        return e, die_amd.PhysarumAgent(max_agents=e.agents.N, seed=args.seed + rank, **agent_kw)
+
+    if denv is not None:
+        env = denv
+        ok, why = 1, ''
+        try:
+            dt, results = timed_run(env, agent)
+            last_reward, last_alive = env.read_result(results[-1])
+        except Exception as e:                                   # e.g. a ghost refresh that overflows its messages
+            ok, why = 0, f'{type(e).__name__}: {e}'
+        try:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        except Exception as e:
+            ok, why = 0, why or f'{type(e).__name__}: {e}'
+        if not ok:
+            denv = None
+            agent_kw.update(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+            mode = f'{world} independent grid replicas (decomposed run failed: {why or "on another rank"})'
+    if denv is None:
+        env, agent = replica()
+        dt, results = timed_run(env, agent)
+        last_reward, last_alive = env.read_result(results[-1])
+    K = env.agents.N
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    last_reward, last_alive = env.read_result(results[-1])
-
     # whole job: the world is `world` tiles of W×H cells, so one world step = `world` 4096²-grid steps
     steps_per_s = args.steps / dt * world
     line = {

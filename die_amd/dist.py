@@ -656,6 +656,10 @@ class DistEnv:
 
     def _refresh_ghosts(self, action):
         """Re-seat owners, ghosts and the chem / food halos (see _step_ghost)."""
+        if not self.geo.DIRS:                      # one rank: the tile is the world, nobody to exchange with
+            self._owned = self.agents.N
+            self._ghosts_fresh = True
+            return
         if self.device.type == 'cuda' and os.environ.get('DIE_GHOST_REFRESH', 'native') != 'torch':
             return self._refresh_ghosts_native(action)
         return self._refresh_ghosts_torch(action)
