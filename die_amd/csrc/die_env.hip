@@ -67,7 +67,7 @@ __device__ __forceinline__ void block_sum_store(double g, long long c, double* p
 }
 
 // One slot of _agent_move + claim + _agent_feed (alive slots); returns its `gained` (0 for dead slots).
-template <typename T>
+template <typename T, bool EXT = true>
 __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t n, uint32_t X, uint32_t Y, const float dx,
                                                 const float dy, const float dep, const uint32_t sid, long long& owned_alive) {
     const T* food = (const T*)a.food;
@@ -107,8 +107,10 @@ __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t
 #ifndef DIE_ABL_NOAF
         a.agent_food[n] += gained;
 #endif
-        if (!die_owned(g, cx, cy)) return 0.f;        // a ghost: the rank that owns this cell accounts for it
-        ++owned_alive;
+        if (EXT) {                                     // ghost-agent tiles (compiled out of the single-tile kernel)
+            if (!die_owned(g, cx, cy)) return 0.f;     // a ghost: the rank that owns this cell accounts for it
+            ++owned_alive;
+        }
         return gained;
     }
     if (a.has_dead) a.stash[n] = consumed;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
 #ifndef DIE_FMC_ATTR
 #define DIE_FMC_ATTR
 #endif
-template <typename T, int KIND>
+template <typename T, int KIND, bool EXT = true>
 __global__ __launch_bounds__(DIE_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(FwdArgs f, StepArgs a) {
     double gsum = 0.0;
     long long cnt = 0;
@@ -140,14 +142,14 @@ __global__ __launch_bounds__(DIE_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(F
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
         const uint32_t X = a.x[n], Y = a.y[n];
-        const FwdOut o = die_forward_agent<T, KIND>(f, X, Y, f.heading[n], sid, n);
+        const FwdOut o = die_forward_agent<T, KIND, EXT>(f, X, Y, f.heading[n], sid, n);
         f.heading[n] = o.heading;
 #ifdef DIE_NT_ACTION
         if (f.dx) { __builtin_nontemporal_store(o.dx, &f.dx[n]); __builtin_nontemporal_store(o.dy, &f.dy[n]); __builtin_nontemporal_store(o.dep, &f.dep[n]); }
 #elif !defined(DIE_ABL_NOACT)
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
 #endif
-        gsum += (double)move_claim_one<T>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt);
+        gsum += (double)move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt);
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
@@ -773,13 +775,21 @@ static int forward_move_claim(const die_medium* m, const die_agents* a, die_grad
     k.part_gain = (double*)ws;
     const int grid = step_grid(a->N);
     hipStream_t s = (hipStream_t)stream;
+    // the sense-mask and ownership tests are compiled out of the plain single-tile kernel (they cost ≈ 5 % there)
+#ifndef DIE_FORCE_EXT
+#define DIE_FORCE_EXT 0
+#endif
+    const bool ext = DIE_FORCE_EXT || f.mask != nullptr || k.g.own_x1 > 0;
+#define DIE_FMC(T, KIND) do { if (ext) k_forward_move_claim<T, KIND, true><<<grid, DIE_BLOCK, 0, s>>>(f, k); \
+                              else k_forward_move_claim<T, KIND, false><<<grid, DIE_BLOCK, 0, s>>>(f, k); } while (0)
     if (m->dtype == DIE_F32) {
-        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim<float, DIE_AGENT_PHYSARUM><<<grid, DIE_BLOCK, 0, s>>>(f, k);
-        else k_forward_move_claim<float, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+        if (g->kind == DIE_AGENT_PHYSARUM) DIE_FMC(float, DIE_AGENT_PHYSARUM);
+        else DIE_FMC(float, DIE_AGENT_GRADIENT);
     } else {
-        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim<__half, DIE_AGENT_PHYSARUM><<<grid, DIE_BLOCK, 0, s>>>(f, k);
-        else k_forward_move_claim<__half, DIE_AGENT_GRADIENT><<<grid, DIE_BLOCK, 0, s>>>(f, k);
+        if (g->kind == DIE_AGENT_PHYSARUM) DIE_FMC(__half, DIE_AGENT_PHYSARUM);
+        else DIE_FMC(__half, DIE_AGENT_GRADIENT);
     }
+#undef DIE_FMC
     if (k.claim_by_store) k_claim_fix<<<grid, DIE_BLOCK, 0, s>>>(k);
     DIE_CHECK_LAUNCH(who);
     return DIE_OK;

@@ -72,7 +72,8 @@ struct FwdOut {
 
 // Reads the 4 chem taps around the probe cell and the food under the agent, decides the turn,
 // applies momentum, updates _prev_grad in place (when kept) and returns heading' and the action.
-template <typename T, int KIND>
+// EXT = false compiles the sense-mask test out (the benchmark path; chosen at launch when mask == NULL).
+template <typename T, int KIND, bool EXT = true>
 __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint32_t X, const uint32_t Y, const float d,
                                                    const uint32_t sid, const int64_t n) {
     const T* chem = (const T*)a.chem;
@@ -91,7 +92,7 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
     const float cxm = (float)xm, cxp = (float)xp * 1.5f, cym = (float)ym, cyp = (float)(yp + py);
 #else
     // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
-    auto seen = [&](const T* p, const int64_t i) { return (a.mask && !a.mask[i]) ? 0.f : die_ld(p, i); };
+    auto seen = [&](const T* p, const int64_t i) { return (EXT && a.mask && !a.mask[i]) ? 0.f : die_ld(p, i); };
     const float cxm = seen(chem, die_local(g, xm, py)), cxp = seen(chem, die_local(g, xp, py));
     const float cym = seen(chem, die_local(g, px, ym)), cyp = seen(chem, die_local(g, px, yp));
 #endif
@@ -100,7 +101,7 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
 #ifdef DIE_ABL_NOFOOD
     const float f_own = (float)(cx + cy);
 #else
-    const float f_own = (a.mask && !a.mask[die_local(g, cx, cy)]) ? 0.f : die_ld(food, die_local(g, cx, cy));
+    const float f_own = seen(food, die_local(g, cx, cy));
 #endif
     const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
     const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
