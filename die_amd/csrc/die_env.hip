@@ -15,7 +15,9 @@
 #include "die_forward.h"
 #include <stdlib.h>
 
+#ifndef DIE_MAX_PARTIALS
 #define DIE_MAX_PARTIALS 8192
+#endif
 
 struct StepArgs {
     die_geo g;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(DIE_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(F
     double gsum = 0.0;
     long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // (giving every XCD a contiguous eighth of the sorted array instead of round-robin workgroups: 178 µs vs 122 µs)
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
         const uint32_t X = a.x[n], Y = a.y[n];
