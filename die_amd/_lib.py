@@ -17,7 +17,7 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class Medium(C.Structure):
@@ -50,7 +50,7 @@ class GradientAgent(C.Structure):
                 ('grad_clip', C.c_float), ('turn_radians', C.c_float), ('sense_radians', C.c_float),
                 ('turn_tolerance', C.c_float), ('reserved', C.c_int32), ('heading', C.c_void_p),
                 ('prev_gx', C.c_void_p), ('prev_gy', C.c_void_p), ('turn_sign', C.c_void_p),
-                ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32)]
+                ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32), ('step_base', C.c_void_p)]
 
 
 class Rect(C.Structure):

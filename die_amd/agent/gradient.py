@@ -48,6 +48,7 @@ class GradientAgent(Agent):
         self._turn_sign: Optional[torch.Tensor] = None            # test hook: per-slot ±1 instead of Philox
         self._order: Optional[torch.Tensor] = None                # slot tensor the state arrays are aligned with
         self._pending = None                                      # forward() whose kernel has not run yet
+        self._step_base: Optional[torch.Tensor] = None            # device word added to the step counter (Env.run graphs)
         self.lazy = True                                          # let Env.step fuse forward with the step
 
     @property
@@ -142,7 +143,8 @@ class GradientAgent(Agent):
             self._sense_offset_scale, self._noise_scale, -1.0 if self._grad_clip is None else self._grad_clip,
             self._turn_radians, self._sense_radians, self._rtol, 0, _ptr(self._direction_rads),
             _ptr(pg[0]) if pg is not None else None, _ptr(pg[1]) if pg is not None else None,
-            _ptr(self._turn_sign), self._seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF, 0)
+            _ptr(self._turn_sign), self._seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF, 0,
+            _ptr(self._step_base))
         self._calls += 1
         action = PendingAction(self, agents, medium, g, (self._direction_rads, pg, self._turn_sign))
         self._pending = action

@@ -78,7 +78,7 @@ int die_fill_fwd_args(FwdArgs& k, const die_medium* m, const die_agents* a, cons
     k.scale = g->scale; k.deposit = g->deposit; k.inertia = g->inertia; k.sense_offset = g->sense_offset;
     k.noise_scale = g->noise_scale; k.grad_clip = g->grad_clip; k.turn_rad = g->turn_radians;
     k.sense_rad = g->sense_radians; k.rtol = g->turn_tolerance; k.normalized = g->normalized_grad;
-    k.seed = g->seed; k.step = g->step;
+    k.seed = g->seed; k.step = g->step; k.step_base = g->step_base;
     return DIE_OK;
 }
 

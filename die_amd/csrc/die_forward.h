@@ -25,6 +25,7 @@ struct FwdArgs {
     int normalized;
     uint64_t seed;
     uint32_t step;
+    const uint32_t* step_base;   // device word added to step (graph replay), or NULL
 };
 
 #define DIE_PI_F 3.14159265358979323846f
@@ -132,7 +133,7 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
         float sgn;
         if (und) {
             if (a.turn_sign) sgn = (float)a.turn_sign[sid];
-            else sgn = (die_draw(a.seed, a.step, (uint64_t)sid, DIE_STREAM_TURN).v[0] & 1u) ? 1.f : -1.f;
+            else sgn = (die_draw(a.seed, a.step + (a.step_base ? *a.step_base : 0u), (uint64_t)sid, DIE_STREAM_TURN).v[0] & 1u) ? 1.f : -1.f;
         } else {
             sgn = delta > atol ? -1.f : 1.f;  // right (clockwise) / left
         }
@@ -150,7 +151,7 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
     if (a.inertia != 0.f || a.noise_scale != 0.f) {
         float nx = 0.f, ny = 0.f;
         if (a.noise_scale != 0.f) {
-            const die_u32x4 r = die_draw(a.seed, a.step, (uint64_t)sid, DIE_STREAM_NOISE);
+            const die_u32x4 r = die_draw(a.seed, a.step + (a.step_base ? *a.step_base : 0u), (uint64_t)sid, DIE_STREAM_NOISE);
             const float u1 = ((float)r.v[0] + 1.0f) * 2.3283064365386963e-10f;
             const float u2 = (float)r.v[1] * 2.3283064365386963e-10f;
             const float rad = 0.4f * sqrtf(-2.0f * logf(u1));

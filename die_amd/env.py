@@ -238,6 +238,110 @@ class Env(_EnvBase):
         host = result.cpu()
         return float(host[0]), int(host.view(torch.int64)[1])
 
+    # ------------------------------------------------------------------ many steps without the host in the loop
+    def run(self, agent, n_steps: int, graph: Optional[bool] = None) -> torch.Tensor:
+        """`n_steps` × `obs, … = env.step(agent.forward(obs))` (the loop of examples/minimal_run.py:23-25) without reading
+        anything back in between.  Returns the (n_steps, 2) float64 device tensor of die_step_result words
+        (`read_results` decodes it).  `graph=True` (Gradient / Physarum agents): the loop is captured ONCE as a hipGraph
+        of K = lcm(epochs 7, chem planes 2, two re-sorts) steps and replayed; the launch arguments of a graph are
+        frozen, so the Philox step counter comes from a device word (`step_base`).  Same bits as the step-by-step loop
+        (tests/test_gpu_parity.py::test_graph_run_equals_step_loop).  Measured on MI355X / ROCm 7 the replay is NOT
+        faster than the plain launch loop (256²: 33.8 vs 30.4 µs/step, 1024²: 49.0 vs 42.3, 4096²: 243 vs 224 —
+        ≈ 5 µs per graph node), so the default is the loop."""
+        from .agent.gradient import GradientAgent
+        n_steps = int(n_steps)
+        out = torch.empty((max(n_steps, 0), 2), dtype=torch.float64, device=self.device)
+        sync, self._sync = self._sync, False
+        try:
+            ok = isinstance(agent, GradientAgent) and agent.lazy and agent._turn_sign is None and \
+                self.dynamics.op_food_flow is _identity_food_flow and not self.dynamics.agents_die and self._fuse_forward
+            if graph is None:
+                graph = False
+            elif graph and not ok:
+                raise ValueError('Env.run(graph=True) needs a lazy Gradient/Physarum agent, identity food flow, no agents_die')
+            done = 0
+            obs = self._get_current_obs
+            K = self._graph_period()
+            if graph and n_steps >= K:
+                # plain steps first until the lazily created state exists (agent arrays; the slot array of the first
+                # re-sort): the graph must start and end on the same storages
+                while done < n_steps - K and (self._steps == 0 or (self._sort_every > 0 and self.agents.slot is None)):
+                    obs, res, *_ = self.step(agent.forward(obs))
+                    out[done].copy_(res)
+                    done += 1
+                while n_steps - done >= K and self._steps > 0 and (self._sort_every <= 0 or self.agents.slot is not None):
+                    G = self._graph_for(agent, K)
+                    G['base'].fill_((agent._calls - G['calls0']) & 0x7FFFFFFF)
+                    G['graph'].replay()
+                    out[done:done + K].copy_(G['results'])
+                    self._steps += K
+                    agent._calls += K
+                    done += K
+                self.last_result = out[done - 1] if done else self.last_result
+            obs = self._get_current_obs
+            for i in range(done, n_steps):
+                obs, res, *_ = self.step(agent.forward(obs))
+                out[i].copy_(res)
+        finally:
+            self._sync = sync
+        return out
+
+    @staticmethod
+    def read_results(results: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:
+        """(rewards (n,), num_agents (n,)) of the tensor `run` returns (synchronises)."""
+        host = results.cpu()
+        return host[:, 0].numpy().copy(), host[:, 1].contiguous().view(torch.int64).numpy().copy()
+
+    def _graph_period(self) -> int:
+        import math
+        k = math.lcm(_lib.OWNER_EPOCH_MAX, 2)
+        if self._sort_every > 0:
+            k = math.lcm(k, 2 * self._sort_every)
+        return k
+
+    def _graph_for(self, agent, K: int):
+        """The captured K-step graph for the current alignment (epoch, chem plane, sort phase, array storages)."""
+        A, M = self.agents, self.medium
+        key = (id(agent), K, M.epoch, M.chem.data_ptr(), self._steps % max(self._sort_every, 1), A.x.data_ptr(),
+               agent._direction_rads.data_ptr() if agent._direction_rads is not None else 0, A.N)
+        cache = self.__dict__.setdefault('_graphs', {})
+        G = cache.get(key)
+        if G is not None:
+            return G
+        cache.clear()                                  # one alignment at a time: the pools hold K steps of temporaries
+        # everything the K steps may re-seat, and where it has to be again afterwards
+        holders = [(A, n) for n in ('x', 'y', 'alive', 'agent_food', 'slot')] + [(M, 'chem'), (M, 'chem_next')] + \
+                  [(agent, '_direction_rads'), (agent, '_prev_grad'), (agent, '_order'), (self, '_shadow')]
+        init = [(o, n, getattr(o, n)) for o, n in holders]
+        steps0, calls0, epoch0 = self._steps, agent._calls, M.epoch
+        results = torch.empty((K, 2), dtype=torch.float64, device=self.device)
+        base = torch.zeros(1, dtype=torch.int32, device=self.device)
+        agent._step_base = base
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize(self.device)
+        try:
+            with torch.cuda.graph(g):
+                obs = self._get_current_obs
+                for i in range(K):
+                    obs, res, *_ = self.step(agent.forward(obs))
+                    results[i].copy_(res)
+                for o, n, t0 in init:                  # state back into the storages the next replay starts from
+                    cur = getattr(o, n)
+                    if isinstance(t0, torch.Tensor) and cur is not t0 and n not in ('_order', 'chem', 'chem_next'):
+                        t0.copy_(cur)
+                base.add_(K)
+        finally:
+            agent._step_base = None
+            for o, n, t0 in init:                      # capture executed nothing: the host-side bookkeeping goes back too
+                setattr(o, n, t0)
+            self._steps, agent._calls, M.epoch = steps0, calls0, epoch0
+            agent._pending = None
+        if agent._order is not None:
+            agent._order = A.slot
+        G = dict(graph=g, results=results, base=base, calls0=calls0)
+        cache[key] = G
+        return G
+
     def _food_flow(self):
         """core/env.py:147-150.  The WaveSequence operator runs on the device (die_food_flow_wave); an arbitrary Python
         operator needs a host round trip.  (It touches env_food only, so running it after the chem sweep instead of

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 9
+#define DIE_ABI_VERSION 10
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -141,6 +141,8 @@ typedef struct die_gradient_agent {
     uint64_t seed;
     uint32_t step;           /* forward-call counter, the Philox step word */
     uint32_t reserved2;
+    const uint32_t* step_base; /* device word added to `step`, or NULL: lets a captured hipGraph of many steps be replayed
+                                  (the launch arguments are frozen, the counter is not) */
 } die_gradient_agent;
 
 /* Device-resident result of one die_env_step (read it back after synchronising). */

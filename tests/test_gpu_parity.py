@@ -885,6 +885,58 @@ def test_sense_mask_parity(die):
     assert hidden_probe.shape == (N,)
 
 
+@pytest.mark.parametrize('kind,sort_every', [('physarum', 4), ('gradient', 3), ('physarum', 0)])
+def test_graph_run_equals_step_loop(die, kind, sort_every):
+    """Env.run: the forward + step loop captured as a hipGraph of K steps and replayed (Philox step counter from a
+    device word) must leave exactly the state the step-by-step loop leaves, results included; also when plain steps
+    and further runs follow."""
+    W, H, N, K = 64, 48, 900, 700
+    rs = np.random.RandomState(21)
+    medium, agents = random_state(W, H, N, K, rs)
+    if kind == 'physarum':
+        mk = lambda: die.PhysarumAgent(max_agents=N, seed=3, scale=1.53 / (W - 1), sense_offset=6.2 / (W - 1), sense_angle=100)
+    else:
+        mk = lambda: die.GradientAgent(max_agents=N, seed=3, scale=0.01, sense_offset=0.03, inertia=0.9, noise_scale=0.025)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    prev = f32(rs.normal(0, .4, (2, N)))
+    envs, agts = [], []
+    for _ in range(2):
+        env = die.Env.from_numpy(medium, agents, sort_every=sort_every, sync=False)
+        ag = mk()
+        ag.set_state(dir0, prev if kind == 'gradient' else None)
+        envs.append(env)
+        agts.append(ag)
+    period = envs[0]._graph_period()
+    n1, n2, n3 = 2 * period + 9, 5, period + 3
+    # A: run (graph), a few plain steps, run again;  B: the plain loop
+    a_env, a_ag = envs[0], agts[0]
+    r1 = a_env.run(a_ag, n1, graph=True)
+    assert '_graphs' in a_env.__dict__ and len(a_env._graphs) == 1           # the graph path was taken
+    obs = a_env._get_current_obs
+    plain = []
+    for _ in range(n2):
+        obs, res, *_ = a_env.step(a_ag.forward(obs))
+        plain.append(res.clone())
+    r3 = a_env.run(a_ag, n3, graph=True)
+    got_rew, got_alive = die.Env.read_results(torch.cat([r1, torch.stack(plain), r3]))
+    b_env, b_ag = envs[1], agts[1]
+    obs = b_env._get_current_obs
+    want = []
+    for _ in range(n1 + n2 + n3):
+        obs, res, *_ = b_env.step(b_ag.forward(obs))
+        want.append(b_env.read_result(res))
+    want = np.array(want)
+    assert np.array_equal(got_alive, want[:, 1].astype(np.int64))
+    assert np.array_equal(got_rew, want[:, 0])
+    assert np.array_equal(a_env.medium.to_numpy(), b_env.medium.to_numpy())
+    assert np.array_equal(a_env.agents.to_numpy(), b_env.agents.to_numpy())
+    assert np.array_equal(a_ag.direction_rads_numpy(), b_ag.direction_rads_numpy())
+    if kind == 'gradient':
+        assert np.array_equal(a_ag.prev_grad_numpy(), b_ag.prev_grad_numpy())
+    assert a_env._steps == b_env._steps and a_ag._calls == b_ag._calls
+
+
 def test_minimal_run_example(die):
     """The port of the reference's examples/minimal_run.py runs end to end (both agents)."""
     import importlib.util
