@@ -308,6 +308,12 @@ struct RowsArgs {
     int W, H, epoch, food_infinite;
     int halo;                          // tile mode: cells within `halo` of the array border belong to neighbours
     int wrapx, wrapy;                  // tile mode: this axis spans the whole world (one rank along it) and is periodic
+    // k_reduce folded in: workgroup (0, 0) first sums the claim pass's `n_part` partial gains (a kernel boundary lies
+    // between their producer and this sweep) in k_reduce's order and writes the step result — one launch less per step
+    const double* part_gain;
+    int n_part;
+    die_step_result* result;
+    long long alive_const;
     float keep, rate_feed;
     float w[2 * 4 + 1];
 };
@@ -333,6 +339,34 @@ template <> struct Vec4<__half> {
 template <typename T, int R, bool FUSED, bool WRAP>
 __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     static_assert(R >= 1 && R <= 4, "one halo lane of 4 columns per side");
+    if (FUSED && a.result && blockIdx.y == gridDim.y - 1) {
+        // an extra row of workgroups past the field: (0, last) reduces, the others have nothing to do.  (Doing it as a
+        // prologue of workgroup (0, 0) made the whole sweep 10 µs longer: all its workgroups are resident at once, so
+        // the kernel ends when its slowest workgroup does.)
+        if (blockIdx.x != 0) return;
+        // 1024 virtual k_reduce threads, 8 per thread, then the same binary tree: same bits as k_reduce
+        static_assert(DIF_BLOCK == 128, "eight virtual k_reduce threads per thread");
+        __shared__ double s_g[DIF_BLOCK];
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double g = 0.0;
+            for (int i = threadIdx.x + q * DIF_BLOCK; i < a.n_part; i += 1024) g += a.part_gain[i];
+            v[q] = g;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += v[q + 4];          // tree level 512
+        v[0] += v[2]; v[1] += v[3];                            // 256
+        v[0] += v[1];                                          // 128
+        s_g[threadIdx.x] = v[0];
+        __syncthreads();
+        for (int o = DIF_BLOCK / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) s_g[threadIdx.x] += s_g[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { a.result->reward = s_g[0]; a.result->num_alive = a.alive_const; }
+        return;
+    }
     const T* src = (const T*)a.src;
     T* dst = (T*)a.dst;
     T* food = (T*)a.food;
@@ -432,7 +466,7 @@ template <typename T, bool FUSED, bool WRAP = true>
 static int launch_rows(const RowsArgs& a, int R, hipStream_t s) {
     const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
     constexpr int WPB = DIF_BLOCK / DIE_WAVE;
-    dim3 grid((strips + WPB - 1) / WPB, (a.W + DIF_ROWS - 1) / DIF_ROWS);
+    dim3 grid((strips + WPB - 1) / WPB, (a.W + DIF_ROWS - 1) / DIF_ROWS + (FUSED && a.result ? 1 : 0));
     switch (R) {
         case 1: k_diffuse_rows<T, 1, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
         case 2: k_diffuse_rows<T, 2, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
@@ -489,7 +523,7 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
         ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
-        ra.wrapx = ra.wrapy = 1;
+        ra.wrapx = ra.wrapy = 1; ra.part_gain = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
         ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
         for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
         int rc2 = dtype == DIE_F32 ? launch_rows<float, false>(ra, R, (hipStream_t)stream)
@@ -663,7 +697,7 @@ extern "C" int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(sigma, wd);
     ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
-    ra.wrapx = ra.wrapy = 0;
+    ra.wrapx = ra.wrapy = 0; ra.part_gain = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
     ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc = dtype == DIE_F32 ? launch_rows<float, false, false>(ra, R, (hipStream_t)stream)
@@ -715,7 +749,9 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
     return DIE_OK;
 }
 
-static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream, const char* who);
+static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream, const char* who,
+                                const double* part_gain = nullptr, int n_part = 0, die_step_result* result = nullptr,
+                                long long alive_const = 0);
 extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                                     void* ws, int64_t ws_bytes, void* stream);
 
@@ -735,6 +771,9 @@ static int env_step_tail(const die_medium* m, const die_agents* a, const die_act
         if (rc != DIE_OK) return rc;
     }
     const int g = step_grid(a->N);
+    if (!second_pass && !getenv("DIE_NO_FUSED_REDUCE"))     // the sweep's first workgroup does the reduction (same summation order)
+        return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed+reduce)", (const double*)ws, g,
+                                    result, a->N);
     k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
                                                   second_pass ? g : 0,
                                                   (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
@@ -834,7 +873,8 @@ extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, di
 }
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream,
-                                const char* who) {
+                                const char* who, const double* part_gain, int n_part, die_step_result* result,
+                                long long alive_const) {
     DIE_REQUIRE(m && d, "%s: null argument", who);
     DIE_REQUIRE(m->owner && m->food && m->chem && m->chem_next && m->chem_next != m->chem, "%s: null or aliased plane", who);
     DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad dtype %d", who, m->dtype);
@@ -851,6 +891,7 @@ static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int 
     ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.food = m->food;
     ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo;
     ra.wrapx = tile && m->gW > 0 && m->W == m->gW; ra.wrapy = tile && m->gW > 0 && m->H == m->gH;
+    ra.part_gain = part_gain; ra.n_part = n_part; ra.result = result; ra.alive_const = alive_const;
     ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc;
