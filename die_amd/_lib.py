@@ -98,6 +98,8 @@ _SIGNATURES = {
     'die_step_reduce': (C.c_int, [_P(Agents), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_medium_deposit_feed_diffuse': (C.c_int, [_P(Medium), _P(Dynamics), C.c_void_p]),
     'die_medium_deposit_feed_diffuse_tile': (C.c_int, [_P(Medium), _P(Dynamics), C.c_int32, C.c_void_p]),
+    'die_tile_sweep_reduce': (C.c_int, [_P(Medium), _P(Agents), _P(Dynamics), C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                        C.c_void_p]),
     'die_agent_dead_slots': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                        C.c_void_p]),
     'die_diffuse_decay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,

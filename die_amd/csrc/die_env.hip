@@ -42,7 +42,7 @@ struct StepArgs {
     int claim_by_store;    // 1: k_move_claim stores, k_claim_fix repairs; 0: atomicMax in k_move_claim
     int skip_scatter;      // fused step: the winner's chem/food writes are done by k_diffuse_rows
     float* stash;          // N floats, only when has_dead
-    double* part_gain;     // gridDim.x doubles
+    long long* part_gain;  // gridDim.x fixed-point sums (die_fix)
     long long* part_alive; // gridDim.x
 };
 
@@ -51,8 +51,14 @@ __device__ __forceinline__ float action_cost(const StepArgs& a, float dx, float 
     return a.cost == DIE_COST_LINEAR ? a.w_dep * fabsf(dep) + a.w_dist * sqrtf(dx * dx + dy * dy) : 0.f;
 }
 
-__device__ __forceinline__ void block_sum_store(double g, long long c, double* pg, long long* pc) {
-    __shared__ double sg[DIE_BLOCK / DIE_WAVE];
+// The reward is accumulated in 32.32 fixed point: integer sums are associative, so reward does not depend on the order
+// of the agent arrays, on the grid size or on the decomposition — bit for bit (a slot's gain is rounded to 2^-32 ≈
+// 2.3e-10 once; the float64 sum it replaces differed by rounding noise between orders).
+#define DIE_FIX_ONE 4294967296.0
+__device__ __forceinline__ long long die_fix(float g) { return __double2ll_rn((double)g * DIE_FIX_ONE); }
+
+__device__ __forceinline__ void block_sum_store(long long g, long long c, long long* pg, long long* pc) {
+    __shared__ long long sg[DIE_BLOCK / DIE_WAVE];
     __shared__ long long sc[DIE_BLOCK / DIE_WAVE];
     g = die_wave_sum(g);
     c = die_wave_sum(c);
@@ -60,7 +66,7 @@ __device__ __forceinline__ void block_sum_store(double g, long long c, double* p
     if (lane == 0) { sg[wv] = g; sc[wv] = c; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double tg = 0.0;
+        long long tg = 0;
         long long tc = 0;
         for (int i = 0; i < DIE_BLOCK / DIE_WAVE; ++i) { tg += sg[i]; tc += sc[i]; }
         if (pg) pg[blockIdx.x] = tg;
@@ -121,12 +127,12 @@ __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t
 
 template <typename T>
 __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
-    double gsum = 0.0;
+    long long gsum = 0;
     long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
-        gsum += (double)move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid, cnt);
+        gsum += die_fix(move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid, cnt));
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_move_claim(StepArgs a) {
 #endif
 template <typename T, int KIND, bool EXT = true>
 __global__ __launch_bounds__(DIE_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(FwdArgs f, StepArgs a) {
-    double gsum = 0.0;
+    long long gsum = 0;
     long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     // (giving every XCD a contiguous eighth of the sorted array instead of round-robin workgroups: 178 µs vs 122 µs)
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(DIE_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(F
 #elif !defined(DIE_ABL_NOACT)
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
 #endif
-        gsum += (double)move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt);
+        gsum += die_fix(move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt));
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
@@ -173,7 +179,7 @@ template <typename T>
 __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
     T* food = (T*)a.food;
     T* chem = (T*)a.chem;
-    double gsum = 0.0;
+    long long gsum = 0;
     long long alive_cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
             const float consumed = die_claim_occupied(a.owner[c], a.epoch) ? a.stash[n] : 0.f;
             const float gained = consumed - action_cost(a, a.dx[n], a.dy[n], a.dep[n]);
             a.agent_food[n] += gained;
-            if (owned) gsum += (double)gained;
+            if (owned) gsum += die_fix(gained);
         }
         if (a.agents_die && !(a.agent_food[n] > 1e-4f)) {         // where(have_food, 0): every channel
             a.x[n] = 0; a.y[n] = 0; a.alive[n] = 0; a.agent_food[n] = 0.f;
@@ -205,13 +211,13 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_resolve(StepArgs a) {
     block_sum_store(gsum, alive_cnt, a.part_gain, a.part_alive);
 }
 
-__global__ __launch_bounds__(1024) void k_reduce(const double* pa, int na, const double* pb, int nb,
+__global__ __launch_bounds__(1024) void k_reduce(const long long* pa, int na, const long long* pb, int nb,
                                                   const long long* pc, int nc, die_step_result* out,
                                                   long long alive_const) {
-    // one block; fixed assignment of partials to threads and a fixed tree: run-to-run deterministic
-    __shared__ double sg[1024];
+    // one block; integer sums (fixed-point gains, counts): exact in any order
+    __shared__ long long sg[1024];
     __shared__ long long sc[1024];
-    double g = 0.0;
+    long long g = 0;
     long long c = 0;
     for (int i = threadIdx.x; i < na; i += 1024) g += pa[i];
     for (int i = threadIdx.x; i < nb; i += 1024) g += pb[i];
@@ -223,7 +229,7 @@ __global__ __launch_bounds__(1024) void k_reduce(const double* pa, int na, const
         if ((int)threadIdx.x < o) { sg[threadIdx.x] += sg[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out->reward = sg[0]; out->num_alive = alive_const >= 0 ? alive_const : sc[0]; }
+    if (threadIdx.x == 0) { out->reward = (double)sg[0] / DIE_FIX_ONE; out->num_alive = alive_const >= 0 ? alive_const : sc[0]; }
 }
 
 // ---- diffusion --------------------------------------------------------------------------
@@ -310,7 +316,8 @@ struct RowsArgs {
     int wrapx, wrapy;                  // tile mode: this axis spans the whole world (one rank along it) and is periodic
     // k_reduce folded in: workgroup (0, 0) first sums the claim pass's `n_part` partial gains (a kernel boundary lies
     // between their producer and this sweep) in k_reduce's order and writes the step result — one launch less per step
-    const double* part_gain;
+    const long long* part_gain;
+    const long long* part_alive;       // NULL: num_alive = alive_const; else the sum of the claim pass's counts (ghost tiles)
     int n_part;
     die_step_result* result;
     long long alive_const;
@@ -344,27 +351,28 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
         // prologue of workgroup (0, 0) made the whole sweep 10 µs longer: all its workgroups are resident at once, so
         // the kernel ends when its slowest workgroup does.)
         if (blockIdx.x != 0) return;
-        // 1024 virtual k_reduce threads, 8 per thread, then the same binary tree: same bits as k_reduce
-        static_assert(DIF_BLOCK == 128, "eight virtual k_reduce threads per thread");
-        __shared__ double s_g[DIF_BLOCK];
-        double v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            double g = 0.0;
-            for (int i = threadIdx.x + q * DIF_BLOCK; i < a.n_part; i += 1024) g += a.part_gain[i];
-            v[q] = g;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += v[q + 4];          // tree level 512
-        v[0] += v[2]; v[1] += v[3];                            // 256
-        v[0] += v[1];                                          // 128
-        s_g[threadIdx.x] = v[0];
+        __shared__ long long s_g[DIF_BLOCK];
+        long long g = 0;
+        for (int i = threadIdx.x; i < a.n_part; i += DIF_BLOCK) g += a.part_gain[i];      // fixed point: any order
+        s_g[threadIdx.x] = g;
         __syncthreads();
         for (int o = DIF_BLOCK / 2; o > 0; o >>= 1) {
             if ((int)threadIdx.x < o) s_g[threadIdx.x] += s_g[threadIdx.x + o];
             __syncthreads();
         }
-        if (threadIdx.x == 0) { a.result->reward = s_g[0]; a.result->num_alive = a.alive_const; }
+        long long cnt = 0;
+        if (a.part_alive) {                                    // integer sum: any order
+            __shared__ long long s_c[DIF_BLOCK];
+            for (int i = threadIdx.x; i < a.n_part; i += DIF_BLOCK) cnt += a.part_alive[i];
+            s_c[threadIdx.x] = cnt;
+            __syncthreads();
+            for (int o = DIF_BLOCK / 2; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) s_c[threadIdx.x] += s_c[threadIdx.x + o];
+                __syncthreads();
+            }
+            cnt = s_c[0];
+        }
+        if (threadIdx.x == 0) { a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = a.part_alive ? cnt : a.alive_const; }
         return;
     }
     const T* src = (const T*)a.src;
@@ -523,7 +531,7 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
         ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
-        ra.wrapx = ra.wrapy = 1; ra.part_gain = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
+        ra.wrapx = ra.wrapy = 1; ra.part_gain = nullptr; ra.part_alive = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
         ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
         for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
         int rc2 = dtype == DIE_F32 ? launch_rows<float, false>(ra, R, (hipStream_t)stream)
@@ -600,7 +608,7 @@ static int fill_args(StepArgs& k, const die_medium* m, const die_agents* a, cons
     char* w = (char*)ws;
     k.part_gain = nullptr;
     // ghost-agent tiles: num_alive is the number of alive slots on OWNED cells, counted by the claim pass
-    k.part_alive = k.g.own_x1 > 0 ? (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS) : nullptr;
+    k.part_alive = k.g.own_x1 > 0 ? (long long*)ws + 2 * DIE_MAX_PARTIALS : nullptr;
     k.stash = (float*)(w + WS_PARTS + die_ws_scan_bytes(m->W, m->H));
     return DIE_OK;
 }
@@ -611,7 +619,7 @@ extern "C" int die_agent_move_claim(const die_medium* m, const die_agents* a, co
     int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_move_claim");
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(act, "die_agent_move_claim: null action");
-    k.part_gain = (double*)ws;
+    k.part_gain = (long long*)ws;
     const int grid = step_grid(a->N);
     if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_move_claim<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
@@ -674,7 +682,7 @@ extern "C" int die_agent_claim_feed(const die_medium* m, const die_agents* a, co
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(act, "die_agent_claim_feed: null action");
     k.do_move = 0;
-    k.part_gain = (double*)ws;
+    k.part_gain = (long long*)ws;
     const int grid = step_grid(a->N);
     if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_move_claim<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
@@ -697,7 +705,7 @@ extern "C" int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(sigma, wd);
     ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
-    ra.wrapx = ra.wrapy = 0; ra.part_gain = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
+    ra.wrapx = ra.wrapy = 0; ra.part_gain = nullptr; ra.part_alive = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
     ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc = dtype == DIE_F32 ? launch_rows<float, false, false>(ra, R, (hipStream_t)stream)
@@ -713,8 +721,8 @@ extern "C" int die_agent_resolve(const die_medium* m, const die_agents* a, const
     int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_resolve");
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(act, "die_agent_resolve: null action");
-    k.part_gain = (double*)ws + DIE_MAX_PARTIALS;
-    k.part_alive = (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS);
+    k.part_gain = (long long*)ws + DIE_MAX_PARTIALS;
+    k.part_alive = (long long*)ws + 2 * DIE_MAX_PARTIALS;
     const int grid = step_grid(a->N);
     if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_resolve<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
@@ -729,9 +737,9 @@ extern "C" int die_step_reduce_ex(const die_agents* a, die_step_result* result, 
     const int g = step_grid(a->N);
     // with_second_pass: 0 = claim-pass gains, num_alive = alive_const; 1 = + the dead-slot pass's gains and its
     // alive count; 2 = claim-pass gains and the claim pass's count of owned alive slots (ghost-agent tiles)
-    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const long long*)ws, g, (const long long*)ws + DIE_MAX_PARTIALS,
                                                   with_second_pass == 1 ? g : 0,
-                                                  (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
+                                                  (const long long*)ws + 2 * DIE_MAX_PARTIALS,
                                                   with_second_pass ? g : 0, result, with_second_pass ? -1 : alive_const);
     DIE_CHECK_LAUNCH("die_step_reduce_ex");
     return DIE_OK;
@@ -742,16 +750,16 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
     DIE_REQUIRE(a && d && result && ws, "die_step_reduce: null argument");
     DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_step_reduce: workspace too small");
     const int g = step_grid(a->N);
-    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS, g,
-                                                       (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS), g,
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const long long*)ws, g, (const long long*)ws + DIE_MAX_PARTIALS, g,
+                                                       (const long long*)ws + 2 * DIE_MAX_PARTIALS, g,
                                                        result, -1);
     DIE_CHECK_LAUNCH("die_step_reduce");
     return DIE_OK;
 }
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream, const char* who,
-                                const double* part_gain = nullptr, int n_part = 0, die_step_result* result = nullptr,
-                                long long alive_const = 0);
+                                const long long* part_gain = nullptr, int n_part = 0, die_step_result* result = nullptr,
+                                long long alive_const = 0, const long long* part_alive = nullptr);
 extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                                     void* ws, int64_t ws_bytes, void* stream);
 
@@ -772,11 +780,11 @@ static int env_step_tail(const die_medium* m, const die_agents* a, const die_act
     }
     const int g = step_grid(a->N);
     if (!second_pass && !getenv("DIE_NO_FUSED_REDUCE"))     // the sweep's first workgroup does the reduction (same summation order)
-        return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed+reduce)", (const double*)ws, g,
+        return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed+reduce)", (const long long*)ws, g,
                                     result, a->N);
-    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const double*)ws, g, (const double*)ws + DIE_MAX_PARTIALS,
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const long long*)ws, g, (const long long*)ws + DIE_MAX_PARTIALS,
                                                   second_pass ? g : 0,
-                                                  (const long long*)((const double*)ws + 2 * DIE_MAX_PARTIALS),
+                                                  (const long long*)ws + 2 * DIE_MAX_PARTIALS,
                                                   second_pass ? g : 0, result, second_pass ? -1 : a->N);
     DIE_CHECK_LAUNCH("die_env_step(reduce)");
     return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed)");
@@ -814,7 +822,7 @@ static int forward_move_claim(const die_medium* m, const die_agents* a, die_grad
     StepArgs k;
     rc = fill_args(k, m, a, act, d, ws, ws_bytes, who);
     if (rc != DIE_OK) return rc;
-    k.part_gain = (double*)ws;
+    k.part_gain = (long long*)ws;
     const int grid = step_grid(a->N);
     hipStream_t s = (hipStream_t)stream;
     // the sense-mask and ownership tests are compiled out of the plain single-tile kernel (they cost ≈ 5 % there)
@@ -873,8 +881,8 @@ extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, di
 }
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream,
-                                const char* who, const double* part_gain, int n_part, die_step_result* result,
-                                long long alive_const) {
+                                const char* who, const long long* part_gain, int n_part, die_step_result* result,
+                                long long alive_const, const long long* part_alive) {
     DIE_REQUIRE(m && d, "%s: null argument", who);
     DIE_REQUIRE(m->owner && m->food && m->chem && m->chem_next && m->chem_next != m->chem, "%s: null or aliased plane", who);
     DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad dtype %d", who, m->dtype);
@@ -891,7 +899,7 @@ static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int 
     ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.food = m->food;
     ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo;
     ra.wrapx = tile && m->gW > 0 && m->W == m->gW; ra.wrapy = tile && m->gW > 0 && m->H == m->gH;
-    ra.part_gain = part_gain; ra.n_part = n_part; ra.result = result; ra.alive_const = alive_const;
+    ra.part_gain = part_gain; ra.part_alive = part_alive; ra.n_part = n_part; ra.result = result; ra.alive_const = alive_const;
     ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc;
@@ -914,14 +922,24 @@ extern "C" int die_medium_deposit_feed_diffuse_tile(const die_medium* m, const d
     return deposit_feed_diffuse(m, d, halo, true, stream, "die_medium_deposit_feed_diffuse_tile");
 }
 
+extern "C" int die_tile_sweep_reduce(const die_medium* m, const die_agents* a, const die_dynamics* d, int32_t halo,
+                                     die_step_result* result, void* ws, int64_t ws_bytes, void* stream) {
+    DIE_REQUIRE(m && a && d && result && ws, "die_tile_sweep_reduce: null argument");
+    DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_tile_sweep_reduce: workspace too small");
+    DIE_REQUIRE(!(d->has_dead_slots || d->agents_die), "die_tile_sweep_reduce: a dead-slot pass needs die_step_reduce_ex");
+    const bool counted = m->gW > 0 && m->own_x1 > 0;       // ghost tiles: the claim pass counted the owned alive slots
+    return deposit_feed_diffuse(m, d, halo, true, stream, "die_tile_sweep_reduce", (const long long*)ws, step_grid(a->N), result,
+                                a->N, counted ? (const long long*)ws + 2 * DIE_MAX_PARTIALS : nullptr);
+}
+
 extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                                     void* ws, int64_t ws_bytes, void* stream) {
     StepArgs k;
     int rc = fill_args(k, m, a, act, d, ws, ws_bytes, "die_agent_dead_slots");
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(act, "die_agent_dead_slots: null action");
-    k.part_gain = (double*)ws + DIE_MAX_PARTIALS;
-    k.part_alive = (long long*)((double*)ws + 2 * DIE_MAX_PARTIALS);
+    k.part_gain = (long long*)ws + DIE_MAX_PARTIALS;
+    k.part_alive = (long long*)ws + 2 * DIE_MAX_PARTIALS;
     k.skip_scatter = 1;
     const int grid = step_grid(a->N);
     if (m->dtype == DIE_F32) k_resolve<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);

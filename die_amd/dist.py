@@ -589,13 +589,16 @@ class DistEnv:
             if second:
                 lib.check(lib.lib.die_agent_dead_slots(C.byref(m), C.byref(a), C.byref(u), C.byref(d), ws, wsn, sp),
                           'die_agent_dead_slots')
-            lib.check(lib.lib.die_step_reduce_ex(C.byref(a), _ptr(result), ws, wsn, 1 if second else 2, -1, sp),
-                      'die_step_reduce_ex')
+                lib.check(lib.lib.die_step_reduce_ex(C.byref(a), _ptr(result), ws, wsn, 1, -1, sp), 'die_step_reduce_ex')
         else:
             result.zero_()
         m = M.c_struct()
-        lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), 0, sp),
-                  'die_medium_deposit_feed_diffuse_tile')
+        if A.N > 0 and not second:                  # reduction folded into the sweep launch
+            lib.check(lib.lib.die_tile_sweep_reduce(C.byref(m), C.byref(self._struct(A)), C.byref(d), 0, _ptr(result), ws, wsn, sp),
+                      'die_tile_sweep_reduce')
+        else:
+            lib.check(lib.lib.die_medium_deposit_feed_diffuse_tile(C.byref(m), C.byref(d), 0, sp),
+                      'die_medium_deposit_feed_diffuse_tile')
         M.swap_chem()
         self._food_flow()
         self._steps += 1

@@ -147,7 +147,8 @@ typedef struct die_gradient_agent {
 
 /* Device-resident result of one die_env_step (read it back after synchronising). */
 typedef struct die_step_result {
-    double reward;           /* sum of `gained` over every slot (core/env.py:119-120) */
+    double reward;           /* sum of `gained` over every slot (core/env.py:119-120), accumulated in 32.32 fixed point:
+                                identical bits whatever the order of the agent arrays or the decomposition */
     int64_t num_alive;       /* core/env.py:263-265 */
 } die_step_result;
 
@@ -224,6 +225,10 @@ int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, 
  * must have been exchanged): deposits are applied everywhere, feeding only to the cells at
  * least `halo` away from the array border, the outer `radius` ring of chem_next is unspecified. */
 int die_medium_deposit_feed_diffuse_tile(const die_medium* m, const die_dynamics* d, int32_t halo, void* stream);
+/* die_medium_deposit_feed_diffuse_tile + die_step_reduce_ex in one launch (no dead-slot pass): an extra workgroup of
+ * the sweep sums the claim pass's partials in k_reduce's order (ghost tiles: and its counts of owned alive slots). */
+int die_tile_sweep_reduce(const die_medium* medium, const die_agents* agents, const die_dynamics* dynamics, int32_t halo,
+                          die_step_result* result, void* ws, int64_t ws_bytes, void* stream);
 /* The part of die_agent_resolve that does not touch the field: dead slots finish their feed,
  * lifecycle (agents_die), alive count — for callers that let the field sweep do the scatter. */
 int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,

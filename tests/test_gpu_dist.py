@@ -101,7 +101,7 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     assert np.array_equal(got['medium'][2], m[2])
     r = np.array(rewards)
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
-    assert np.allclose(got['rewards'][:, 0], r[:, 0], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
 
 
 def _single_device_run(W, H, N, K, steps, wave=False):
@@ -139,7 +139,7 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
     for c in range(3):
         assert np.array_equal(got['medium'][c], m[c])
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
-    assert np.allclose(got['rewards'][:, 0], r[:, 0], rtol=1e-12, atol=1e-12)
+    assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
 
 
 # ---------------------------------------------------------------------------------------------------------
