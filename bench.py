@@ -56,9 +56,9 @@ def algorithmic_bytes(C, K):
     }
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v4_pmc_traffic_per_kernel_avg.json')   # the kernels' traffic has not changed since
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v6_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
-             'k_forward_move_claim': 'void k_forward_move_claim<float, 1>',
+             'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
 
 
@@ -300,7 +300,9 @@ def main():
     if rank == 0 and denv is not None:
         Kw = int(getattr(denv, 'world_agents', K * world))
         Bw = (12 * W * H * world + 104 * Kw)
-        line['config'].update(alive_agents=Kw, agent_slots=Kw, alive_agents_rank0=K)
+        line['config'].update(alive_agents=Kw, agent_slots=Kw, local_agents_rank0=K)
+        if getattr(denv, 'ghost_fill', None) is not None:
+            line['config']['ghost_message_fill_max_rank0'] = round(denv.ghost_fill, 3)
         line['roofline'] = {'bound': 'hbm', 'kernel': 'whole step (all ranks)', 'achieved': round(Bw / (dt / args.steps) / 1e9, 1),
                             'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': round(Bw / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
                             'traffic': None, 'algorithmic_bytes_per_launch': Bw}
@@ -314,7 +316,7 @@ def main():
         line['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/r01_v4_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
+            'traffic_source': 'profiles/r01_v6_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},

@@ -771,6 +771,8 @@ class DistEnv:
                 raise RuntimeError(f'ghost refresh: {max(sent[k], arrived[k])} agents in the band of side {g.DIRS[k]}, the messages hold '
                                    f'{P.caps[k]}: build DistEnv with a larger ghost_headroom (agents cluster at this border)')
         self._owned = kept
+        if nd:
+            self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))
         n_arr = sum(arrived)
         holes = P.lists[nd][:H]
         if n_arr >= H:
