@@ -17,7 +17,8 @@ DIE_BOUNDARY_WRAP, DIE_BOUNDARY_LIMIT, DIE_BOUNDARY_NONE = 0, 1, 2
 DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 29, 7, 0x1FFFFFFF
-ABI_VERSION = 10
+DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
+ABI_VERSION = 11
 
 
 class Medium(C.Structure):
@@ -41,7 +42,7 @@ class Dynamics(C.Structure):
     _fields_ = [('rate_feed', C.c_float), ('rate_decay_chem', C.c_float), ('diffuse_sigma', C.c_float),
                 ('boundary', C.c_int32), ('cost', C.c_int32), ('cost_w_deposit', C.c_float),
                 ('cost_w_dist', C.c_float), ('food_infinite', C.c_int32), ('agents_die', C.c_int32),
-                ('has_dead_slots', C.c_int32)]
+                ('has_dead_slots', C.c_int32), ('diffuse_mode', C.c_int32)]
 
 
 class GradientAgent(C.Structure):
@@ -102,6 +103,8 @@ _SIGNATURES = {
                                         C.c_void_p]),
     'die_agent_dead_slots': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                        C.c_void_p]),
+    'die_diffuse_decay_mode': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                         C.c_void_p]),
     'die_diffuse_decay': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                     C.c_void_p]),
     'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),

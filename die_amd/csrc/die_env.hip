@@ -242,12 +242,36 @@ struct DiffuseArgs {
     void* dst;
     int W, H;
     float keep;                 // 1 − decay
+    int mode;                   // die_diffuse_mode: what lies beyond the edges
     float w[2 * DIF_MAXR + 1];  // w[k + R], k = −R..R
 };
 
 __device__ __forceinline__ int wrap_idx(int v, int n) {
     v %= n;
     return v < 0 ? v + n : v;
+}
+
+// scipy.ndimage boundary modes (what skimage.filters.gaussian passes through, core/env.py:140-143): the index that
+// stands in for v outside [0, n), or −1 for 'constant' (cval = 0)
+__device__ __forceinline__ int edge_idx(int v, int n, int mode) {
+    if (v >= 0 && v < n) return v;
+    switch (mode) {
+        case DIE_DIFFUSE_NEAREST: return v < 0 ? 0 : n - 1;
+        case DIE_DIFFUSE_REFLECT: {                    // d c b a | a b c d | d c b a   (period 2n)
+            int m = v % (2 * n);
+            m = m < 0 ? m + 2 * n : m;
+            return m < n ? m : 2 * n - 1 - m;
+        }
+        case DIE_DIFFUSE_MIRROR: {                     // d c b | a b c d | c b a       (period 2n − 2)
+            if (n == 1) return 0;
+            const int p = 2 * n - 2;
+            int m = v % p;
+            m = m < 0 ? m + p : m;
+            return m < n ? m : p - m;
+        }
+        case DIE_DIFFUSE_CONSTANT: return -1;
+        default: return wrap_idx(v, n);
+    }
 }
 
 // LDS-tiled separable gaussian on the torus: the (TX+2R)×(TY+2R) input tile is staged once,
@@ -265,8 +289,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
     constexpr int LWV = DIF_TY + 2 * R;       // valid columns
     for (int idx = threadIdx.x; idx < LH * LWV; idx += DIE_BLOCK) {
         const int li = idx / LWV, lj = idx - li * LWV;
-        const int gx = wrap_idx(x0 - R + li, W), gy = wrap_idx(y0 - R + lj, H);
-        s_in[li * LW + lj] = die_ld(src, (int64_t)gx * H + gy);
+        const int gx = edge_idx(x0 - R + li, W, a.mode), gy = edge_idx(y0 - R + lj, H, a.mode);
+        s_in[li * LW + lj] = (gx < 0 || gy < 0) ? 0.f : die_ld(src, (int64_t)gx * H + gy);
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < DIF_TX * LWV; idx += DIE_BLOCK) {
@@ -513,8 +537,8 @@ static int launch_diffuse(const DiffuseArgs& a, int R, hipStream_t s) {
     return DIE_OK;
 }
 
-extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma,
-                                 float decay, void* stream) {
+static int diffuse_decay_mode(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma, float decay,
+                              int32_t mode, void* stream) {
     DIE_REQUIRE(src && dst && src != dst, "die_diffuse_decay: src/dst must be distinct non-null planes");
     DIE_REQUIRE(W >= 1 && H >= 1, "die_diffuse_decay: bad size %dx%d", W, H);
     DIE_REQUIRE(sigma > 0.f, "die_diffuse_decay: sigma must be positive");
@@ -526,7 +550,8 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
         die_set_error("die_diffuse_decay: sigma %g needs radius %d > %d", (double)sigma, R, DIF_MAXR);
         return DIE_ERR_UNSUPPORTED;
     }
-    if (rows_kernel_applies(W, H, R)) {
+    DIE_REQUIRE(mode >= DIE_DIFFUSE_WRAP && mode <= DIE_DIFFUSE_CONSTANT, "die_diffuse_decay: bad boundary mode %d", mode);
+    if (mode == DIE_DIFFUSE_WRAP && rows_kernel_applies(W, H, R)) {
         RowsArgs ra;
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
@@ -541,7 +566,7 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
         return DIE_OK;
     }
     DiffuseArgs a;
-    a.src = src; a.dst = dst; a.W = W; a.H = H;
+    a.src = src; a.dst = dst; a.W = W; a.H = H; a.mode = mode;
     a.keep = (float)(1.0 - (double)decay);
     double w[2 * DIF_MAXR + 1], sum = 0.0;
     for (int k = -R; k <= R; ++k) { w[k + R] = exp(-0.5 / ((double)sigma * (double)sigma) * k * k); sum += w[k + R]; }
@@ -551,6 +576,16 @@ extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t 
     if (rc != DIE_OK) return rc;
     DIE_CHECK_LAUNCH("die_diffuse_decay");
     return DIE_OK;
+}
+
+extern "C" int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma,
+                                 float decay, void* stream) {
+    return diffuse_decay_mode(src, dst, W, H, dtype, sigma, decay, DIE_DIFFUSE_WRAP, stream);
+}
+
+extern "C" int die_diffuse_decay_mode(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma,
+                                      float decay, int32_t mode, void* stream) {
+    return diffuse_decay_mode(src, dst, W, H, dtype, sigma, decay, mode, stream);
 }
 
 // ---- step driver ----------------------------------------------------------------------
@@ -765,7 +800,8 @@ extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, co
 
 static bool fused_step_applies(const die_medium* m, const die_dynamics* d) {
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    return m->gW <= 0 && rows_kernel_applies(m->W, m->H, R) && R >= 1 && !getenv("DIE_NO_FUSED_STEP");
+    return m->gW <= 0 && d->diffuse_mode == DIE_DIFFUSE_WRAP && rows_kernel_applies(m->W, m->H, R) && R >= 1 &&
+           !getenv("DIE_NO_FUSED_STEP");
 }
 
 // everything of die_env_step after the claims are in place (fused path)
@@ -806,7 +842,8 @@ extern "C" int die_env_step(const die_medium* m, const die_agents* a, const die_
                       "drive die_agent_move / die_agent_claim_feed / die_medium_deposit_feed_diffuse_tile instead");
         return DIE_ERR_UNSUPPORTED;
     }
-    return die_diffuse_decay(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, stream);
+    return diffuse_decay_mode(m->chem, m->chem_next, m->W, m->H, m->dtype, d->diffuse_sigma, d->rate_decay_chem, d->diffuse_mode,
+                              stream);
 }
 
 static int forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,

@@ -322,6 +322,8 @@ class DistEnv:
         self.dynamics = dynamics or Dynamics()
         if self.dynamics.apply_sense_mask:
             raise NotImplementedError('apply_sense_mask is implemented for single-tile worlds only')
+        if self.dynamics.diffuse_mode != 'wrap':
+            raise NotImplementedError("decomposed worlds diffuse on the torus (diffuse_mode='wrap') only")
         self.comm = Comm(group)
         R = int(4.0 * float(self.dynamics.diffuse_sigma) + 0.5)
         # guard band: agents may stay on a rank for `migrate_every` steps after leaving its interior (their
@@ -474,7 +476,7 @@ class DistEnv:
         boundary = lib.DIE_BOUNDARY_WRAP if d.boundary == BoundaryCondition.wrap else lib.DIE_BOUNDARY_LIMIT
         cost = lib.DIE_COST_LINEAR if d.op_action_cost is linear_action_cost else lib.DIE_COST_ZERO
         return lib.Dynamics(d.rate_feed, d.rate_decay_chem, d.diffuse_sigma, boundary, cost, 0.02, 0.01,
-                            int(d.food_infinite), int(d.agents_die), int(not self._all_alive))
+                            int(d.food_infinite), int(d.agents_die), int(not self._all_alive), 0)
 
     def _per_agent_tensors(self, action) -> List[torch.Tensor]:
         """Every per-agent array that must travel with a migrating agent (4-byte views)."""

@@ -94,8 +94,8 @@ class Env(_EnvBase):
     # ------------------------------------------------------------------ construction
     def _check_dynamics(self):
         d = self.dynamics
-        if d.diffuse_mode != 'wrap':
-            raise NotImplementedError(f"diffuse_mode={d.diffuse_mode!r}: only 'wrap' is implemented on device")
+        if d.diffuse_mode not in _lib.DIFFUSE_MODES:
+            raise ValueError(f"diffuse_mode={d.diffuse_mode!r}: one of {sorted(_lib.DIFFUSE_MODES)}")
         if d.op_action_cost not in (linear_action_cost, zero_cost):
             raise NotImplementedError('op_action_cost must be linear_action_cost or zero_cost on device')
         if self._field_size[0] < 2 or self._field_size[1] < 2:
@@ -175,7 +175,7 @@ class Env(_EnvBase):
             boundary = _lib.DIE_BOUNDARY_NONE
         cost = _lib.DIE_COST_LINEAR if d.op_action_cost is linear_action_cost else _lib.DIE_COST_ZERO
         return _lib.Dynamics(d.rate_feed, d.rate_decay_chem, d.diffuse_sigma, boundary, cost, 0.02, 0.01,
-                             int(d.food_infinite), int(d.agents_die), int(not self._all_alive))
+                             int(d.food_infinite), int(d.agents_die), int(not self._all_alive), _lib.DIFFUSE_MODES[d.diffuse_mode])
 
     def _as_action(self, action) -> DeviceAction:
         if isinstance(action, DeviceAction):
@@ -404,9 +404,9 @@ class Env(_EnvBase):
     def _medium_diffuse_decay(self):
         d = self.dynamics
         m = self.medium
-        _lib.check(_lib.lib.die_diffuse_decay(_ptr(m.chem), _ptr(m.chem_next), m.W, m.H, m.c_struct().dtype,
-                                              d.diffuse_sigma, d.rate_decay_chem, stream_ptr(self.device)),
-                   'die_diffuse_decay')
+        _lib.check(_lib.lib.die_diffuse_decay_mode(_ptr(m.chem), _ptr(m.chem_next), m.W, m.H, m.c_struct().dtype,
+                                                   d.diffuse_sigma, d.rate_decay_chem, _lib.DIFFUSE_MODES[d.diffuse_mode],
+                                                   stream_ptr(self.device)), 'die_diffuse_decay_mode')
         m.swap_chem()
 
     # ------------------------------------------------------------------ observation / render

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 10
+#define DIE_ABI_VERSION 11
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -107,6 +107,10 @@ typedef struct die_action {
 } die_action;
 
 /* core/env.py:42-61 Dynamics, the fields the device path honours. */
+/* scipy.ndimage boundary modes as skimage.filters.gaussian passes them through (core/env.py:140-143) */
+typedef enum die_diffuse_mode { DIE_DIFFUSE_WRAP = 0, DIE_DIFFUSE_NEAREST = 1, DIE_DIFFUSE_REFLECT = 2, DIE_DIFFUSE_MIRROR = 3,
+                                DIE_DIFFUSE_CONSTANT = 4 } die_diffuse_mode;
+
 typedef struct die_dynamics {
     float rate_feed;
     float rate_decay_chem;
@@ -118,6 +122,7 @@ typedef struct die_dynamics {
     int32_t food_infinite;
     int32_t agents_die;
     int32_t has_dead_slots;  /* 0: caller guarantees every slot is alive (skips the dead-slot feed pass) */
+    int32_t diffuse_mode;    /* die_diffuse_mode (Dynamics.diffuse_mode, core/env.py:49,142); only WRAP takes the fused sweep */
 } die_dynamics;
 
 /* core/agent/gradient.py:19-28,139-151 constructor arguments + per-agent state. */
@@ -255,6 +260,9 @@ int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int32_t H, int
 /* gaussian(sigma, mode='wrap') × (1 − decay): src → dst, W×H planes of `dtype`. */
 int die_diffuse_decay(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype,
                       float sigma, float decay, void* stream);
+/* … with any of scipy's boundary modes (LDS-tiled kernel; 'wrap' with H % 4 == 0 and radius <= 4 takes the row sweep) */
+int die_diffuse_decay_mode(const void* src, void* dst, int32_t W, int32_t H, int32_t dtype, float sigma, float decay,
+                           int32_t mode, void* stream);
 
 /* ---- DataInitializer (core/data_init.py:92-253, core/env.py:74-86) ------------------- */
 typedef struct die_food_spec {   /* synthetic stand-in for the Perlin food field (:190-196) */

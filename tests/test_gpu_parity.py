@@ -84,6 +84,36 @@ def test_diffuse_decay_parity(die, W, H, sigma):
     assert np.isclose(got.sum(), 0.9 * chem.sum(), rtol=1e-5)
 
 
+@pytest.mark.parametrize('mode', ['nearest', 'reflect', 'mirror', 'constant', 'wrap'])
+@pytest.mark.parametrize('W,H', [(5, 3), (37, 24), (130, 260), (9, 2), (64, 64)])
+def test_diffuse_boundary_modes(die, mode, W, H):
+    """Dynamics.diffuse_mode (core/env.py:49,142): every scipy boundary mode skimage passes through, radius up to 6
+    (wider than the small fields: the reflections repeat), alone and inside an env step."""
+    from die_amd import _lib
+    from die_amd.device_array import _ptr
+    rs = np.random.RandomState(W * 7 + H)
+    for sigma in (0.5, 1.5):
+        chem = f32(rs.rand(W, H) * (rs.rand(W, H) < 0.6))
+        src = torch.from_numpy(chem.astype(np.float32)).cuda()
+        dst = torch.empty_like(src)
+        _lib.check(_lib.lib.die_diffuse_decay_mode(_ptr(src), _ptr(dst), W, H, _lib.DIE_F32, sigma, 0.1, _lib.DIFFUSE_MODES[mode], None),
+                   'diffuse')
+        want = R.diffuse_decay(chem, float(np.float32(sigma)), float(np.float32(0.1)), mode)
+        assert np.allclose(dst.cpu().numpy().astype(np.float64), want, rtol=RTOL, atol=1e-7), (mode, sigma)
+    N, K = 60, 40
+    medium, agents = random_state(W, H, N, K, rs)
+    dyn = die.Dynamics(diffuse_mode=mode)
+    rdyn = R.RefDynamics(diffuse_mode=mode, rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)))
+    env, ref = die.Env.from_numpy(medium, agents, dyn), R.RefEnv(medium, agents, rdyn)
+    for _ in range(2):
+        action = quantised_action(N, rs, 1.0 / max(W, 4))
+        env.step(action)
+        ref.step(action)
+    m = env.medium.to_numpy()
+    assert np.allclose(m[2], ref.medium[2], rtol=RTOL, atol=1e-7) and np.allclose(m[1], ref.medium[1], rtol=RTOL, atol=1e-7)
+    assert np.array_equal(m[0], ref.medium[0])
+
+
 def test_diffuse_impulse_kat(die):
     """Impulse at the torus corner = wrapped outer product of the 5 taps (SURVEY §8c KAT)."""
     from die_amd import _lib
