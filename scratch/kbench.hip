@@ -25,8 +25,17 @@ __global__ __launch_bounds__(256) void k_access(const uint32_t* idx, int64_t n, 
         if (MODE == 4) atomicAdd(&table[c], 1.0f);               // float atomic add
         if (MODE == 6) atomicMax(&((unsigned long long*)table)[c], ((unsigned long long)i << 32) | 7ull);   // u64 atomic max, 8-B cells
         if (MODE == 5) acc += table[c] + table[c + 4096] + table[c + 8192] + table[c + 1] ; // 4 gathers 3 rows
+        if (MODE == 7 || MODE == 8) {                            // the probe's 4 taps: (x±1, y), (x, y±1); 7 = linear plane, 8 = 4x8-cell tiles of 128 B
+            const int x = (int)(c >> 12) + 1, y = (int)(c & 4095);
+            const int ym = y > 0 ? y - 1 : 0, yp = y < 4095 ? y + 1 : 4095;
+            auto at = [&](int xx, int yy) -> int64_t {
+                if (MODE == 7) return (int64_t)xx * 4096 + yy;
+                return ((int64_t)(xx >> 2) * (4096 >> 3) + (yy >> 3)) * 32 + (xx & 3) * 8 + (yy & 7);
+            };
+            acc += table[at(x - 1, y)] + table[at(x + 1, y)] + table[at(x, ym)] + table[at(x, yp)];
+        }
     }
-    if (MODE == 0 || MODE == 5) { if (acc == 12345.678f) out[0] = acc; }
+    if (MODE == 0 || MODE == 5 || MODE == 7 || MODE == 8) { if (acc == 12345.678f) out[0] = acc; }
 }
 
 template <int MODE>
@@ -79,8 +88,9 @@ int main() {
             t[0] = run<0>(d_idx, n, table, out, grid); t[1] = run<1>(d_idx, n, table, out, grid); t[2] = run<2>(d_idx, n, table, out, grid);
             t[3] = run<3>(d_idx, n, table, out, grid); t[4] = run<4>(d_idx, n, table, out, grid); t[5] = run<5>(d_idx, n, table, out, grid);
             float t6 = run<6>(d_idx, n, table, out, grid);
+            float t7 = run<7>(d_idx, n, table, out, grid), t8 = run<8>(d_idx, n, table, out, grid);
             { std::vector<uint32_t> h2(*s.v); CK(hipMemcpy(d_idx, h2.data(), n * 4, hipMemcpyHostToDevice)); }
-            printf("grid %5d %-10s n=%lld : atomicMax64 %.1f us ", grid, s.name, (long long)n, t6);
+            printf("grid %5d %-10s n=%lld : taps linear %.1f us, taps 4x8-tiled %.1f us | atomicMax64 %.1f us ", grid, s.name, (long long)n, t7, t8, t6);
             for (int m = 0; m < 6; ++m) printf("  %s %.1f us (%.0f G/s)", names[m], t[m], n / t[m] * 1e-3 * (m == 5 ? 4 : 1));
             printf("\n");
         }
