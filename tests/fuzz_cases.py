@@ -23,7 +23,8 @@ def fuzz_step(n_cases=100, seed=0, verbose=True):
         sigma = float(rs.choice([0.3, 0.5, 0.8, 1.0, 1.2]))
         dyn = die_amd.Dynamics(boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])), food_infinite=bool(rs.rand() < 0.2),
                                agents_die=bool(rs.rand() < 0.2), op_action_cost=die_amd.zero_cost if rs.rand() < 0.2 else die_amd.linear_action_cost,
-                               diffuse_sigma=sigma, rate_feed=float(rs.choice([0.1, 0.5])), rate_decay_chem=float(rs.choice([0.0, 0.1, 0.3])))
+                               diffuse_sigma=sigma, rate_feed=float(rs.choice([0.1, 0.5])), rate_decay_chem=float(rs.choice([0.0, 0.1, 0.3])),
+                               diffuse_mode=str(rs.choice(['wrap', 'wrap', 'wrap', 'nearest', 'reflect', 'mirror', 'constant'])))
         sort_every = int(rs.choice([0, 1]))
         try:
             medium, agents = random_state(W, H, N, K, rs, collide=float(rs.choice([0.0, 0.3, 0.9])))

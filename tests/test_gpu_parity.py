@@ -63,7 +63,8 @@ def random_state(W, H, N, K, rs, collide=0.3, chem_scale=1.0):
 def ref_dyn(dyn):
     return R.RefDynamics(op_action_cost=R.zero_cost if dyn.op_action_cost.__name__ == 'zero_cost' else R.linear_action_cost,
                          rate_feed=dyn.rate_feed, rate_decay_chem=dyn.rate_decay_chem, boundary=dyn.boundary.value,
-                         diffuse_sigma=dyn.diffuse_sigma, food_infinite=dyn.food_infinite, agents_die=dyn.agents_die)
+                         diffuse_sigma=dyn.diffuse_sigma, food_infinite=dyn.food_infinite, agents_die=dyn.agents_die,
+                         diffuse_mode=dyn.diffuse_mode)
 
 
 # ------------------------------------------------------------------------------------ diffusion
