@@ -36,6 +36,9 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
+    if backend == 'gloo-torch-refresh':          # the ghost refresh written with torch index operations (cross-check path)
+        os.environ['DIE_GHOST_REFRESH'] = 'torch'
+        backend = 'gloo'
     if backend == 'nccl':        # one rank: its periodic self-neighbour messages go through RCCL send/recv
         os.environ['DIE_DIST_SELF_VIA_BACKEND'] = '1'
         torch.cuda.set_device(0)
@@ -120,7 +123,7 @@ def _single_device_run(W, H, N, K, steps, wave=False):
 
 @pytest.mark.parametrize('grid,sort_every,refresh_every,backend,wave', [
     ((1, 2), 0, 2, 'gloo', False), ((2, 1), 3, 3, 'gloo', False), ((2, 2), 2, 2, 'gloo', False), ((2, 2), 0, 3, 'gloo', True),
-    ((2, 2), 4, 1, 'gloo', False), ((1, 1), 2, 4, 'nccl', True)])
+    ((2, 2), 4, 1, 'gloo', False), ((1, 1), 2, 4, 'nccl', True), ((2, 2), 2, 2, 'gloo-torch-refresh', False)])
 def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, refresh_every, backend, wave):
     """Communication-avoiding mode: ghosts of the neighbours' border agents are stepped locally, nothing crosses
     ranks for `refresh_every` steps; world state and rewards must equal the single-device run bit for bit
