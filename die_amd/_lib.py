@@ -126,6 +126,10 @@ _SIGNATURES = {
                                          C.c_void_p, C.c_void_p]),
     'die_records_scatter_at': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                          C.c_void_p]),
+    'die_ghost_pack': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_void_p, _P(C.c_int64),
+                                 _P(C.c_int64), _P(C.c_int64), C.c_void_p, C.c_void_p]),
+    'die_ghost_apply': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, _P(C.c_int64), _P(C.c_int64),
+                                  _P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
                                   C.c_int64, C.c_void_p]),

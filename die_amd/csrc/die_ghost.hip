@@ -240,3 +240,156 @@ extern "C" int die_records_scatter_at(void* const* arrays, const int32_t* elem_b
     DIE_CHECK_LAUNCH("die_records_scatter_at");
     return DIE_OK;
 }
+
+// ---- all sides in one launch; arrivals and compaction entirely on the device ------------------------------------
+// The host used to sit in the middle of a refresh: read the counts, build index tensors, launch one gather / scatter
+// per side — the GPU idled while it did.  die_ghost_pack and die_ghost_apply take the counts from device memory
+// (the plan's totals, the arrived messages' headers); the host reads them once, AFTER everything is enqueued.
+struct GhostIO {
+    int n_arr_arrays;
+    char* arr[GH_ARR_MAX];
+    int esz[GH_ARR_MAX];
+    int nd;
+    int64_t cap[GH_MAXD], hdr_off[GH_MAXD], rec_off[GH_MAXD];
+    char* buf;                       // message buffer (send: written, receive: read)
+    const int32_t* lists[GH_MAXD];   // pack: index list per side
+    const int64_t* totals;           // nd + 2 device words from die_ghost_plan: per side, holes, owned
+    const int32_t* holes;            // apply
+    const uint16_t* mask;            // apply: the plan's membership words (bit GH_MAXD = hole)
+    int64_t n;                       // apply: local agents before the refresh
+    int64_t* n_new;                  // apply: device word, local agents afterwards
+};
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_ghost_pack(GhostIO a) {
+    const int k = blockIdx.y;
+    const int64_t total = a.totals[k];
+    const int64_t count = total < a.cap[k] ? total : a.cap[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *(int64_t*)(a.buf + a.hdr_off[k]) = total;     // the receiver checks total <= cap
+    int32_t* rec = (int32_t*)(a.buf + a.rec_off[k]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < count; j += stride) {
+        const int64_t s = a.lists[k][j];
+        for (int f = 0; f < a.n_arr_arrays; ++f) {
+            int32_t* r = rec + (int64_t)f * a.cap[k] + j;
+            *r = a.esz[f] == 4 ? ((const int32_t*)a.arr[f])[s] : (int32_t)((const uint8_t*)a.arr[f])[s];
+        }
+    }
+}
+
+__device__ __forceinline__ int64_t ghost_arrived(const GhostIO& a, int k) {
+    const int64_t c = *(const int64_t*)(a.buf + a.hdr_off[k]);
+    return c < 0 ? 0 : (c < a.cap[k] ? c : a.cap[k]);
+}
+
+// arrival j (messages in side order) goes into hole j, or behind the old end once the holes are used up
+__global__ __launch_bounds__(DIE_BLOCK) void k_ghost_arrivals(GhostIO a) {
+    const int k = blockIdx.y;
+    int64_t prefix = 0;
+    for (int q = 0; q < k; ++q) prefix += ghost_arrived(a, q);
+    const int64_t count = ghost_arrived(a, k), H = a.totals[a.nd];
+    const int32_t* rec = (const int32_t*)(a.buf + a.rec_off[k]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const int64_t j = prefix + i;
+        const int64_t dst = j < H ? (int64_t)a.holes[j] : a.n + (j - H);
+        for (int f = 0; f < a.n_arr_arrays; ++f) {
+            const int32_t v = rec[(int64_t)f * a.cap[k] + i];
+            if (a.esz[f] == 4) ((int32_t*)a.arr[f])[dst] = v; else ((uint8_t*)a.arr[f])[dst] = (uint8_t)v;
+        }
+    }
+}
+
+// fewer arrivals than holes: the array shrinks to n_new = n − (H − arrivals); the kept entries of the cut tail
+// [n_new, n) move, in order, into the remaining holes below n_new (there are exactly as many).  One workgroup:
+// the net change of a refresh is a small fraction of the band.
+__global__ __launch_bounds__(1024) void k_ghost_tail(GhostIO a) {
+    __shared__ int s[1024];
+    __shared__ long long s_base;
+    int64_t n_arr = 0;
+    for (int q = 0; q < a.nd; ++q) n_arr += ghost_arrived(a, q);
+    const int64_t H = a.totals[a.nd];
+    const int64_t n_new = n_arr >= H ? a.n + (n_arr - H) : a.n - (H - n_arr);
+    if (threadIdx.x == 0) { *a.n_new = n_new; s_base = 0; }
+    __syncthreads();
+    if (n_arr >= H) return;
+    for (int64_t p0 = n_new; p0 < a.n; p0 += 1024) {
+        const int64_t p = p0 + threadIdx.x;
+        const int kept = (p < a.n && !((a.mask[p] >> GH_MAXD) & 1u)) ? 1 : 0;
+        s[threadIdx.x] = kept;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const int t = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (kept) {
+            const int64_t r = (int64_t)s_base + s[threadIdx.x] - 1;
+            const int64_t dst = a.holes[n_arr + r];
+            for (int f = 0; f < a.n_arr_arrays; ++f) {
+                if (a.esz[f] == 4) ((int32_t*)a.arr[f])[dst] = ((const int32_t*)a.arr[f])[p];
+                else ((uint8_t*)a.arr[f])[dst] = ((const uint8_t*)a.arr[f])[p];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base += s[1023];
+        __syncthreads();
+    }
+}
+
+static int fill_io(GhostIO& k, void* const* arrays, const int32_t* esz, int32_t F, int32_t nd, const int64_t* caps,
+                   const int64_t* hdr_off, const int64_t* rec_off, const char* who) {
+    DIE_REQUIRE(arrays && esz && F >= 1 && F <= GH_ARR_MAX, "%s: 1..%d arrays", who, GH_ARR_MAX);
+    DIE_REQUIRE(nd >= 0 && nd <= GH_MAXD && (nd == 0 || (caps && hdr_off && rec_off)), "%s: 0..%d sides", who, GH_MAXD);
+    k.n_arr_arrays = F; k.nd = nd;
+    for (int i = 0; i < GH_ARR_MAX; ++i) {
+        k.arr[i] = i < F ? (char*)arrays[i] : nullptr; k.esz[i] = i < F ? esz[i] : 0;
+        DIE_REQUIRE(i >= F || (arrays[i] && (esz[i] == 4 || esz[i] == 1)), "%s: array %d must be 4- or 1-byte", who, i);
+    }
+    for (int i = 0; i < GH_MAXD; ++i) {
+        k.cap[i] = i < nd ? caps[i] : 0; k.hdr_off[i] = i < nd ? hdr_off[i] : 0; k.rec_off[i] = i < nd ? rec_off[i] : 0;
+        k.lists[i] = nullptr;
+        DIE_REQUIRE(i >= nd || (caps[i] > 0 && hdr_off[i] % 8 == 0 && rec_off[i] % 4 == 0), "%s: bad message layout %d", who, i);
+    }
+    return DIE_OK;
+}
+
+extern "C" int die_ghost_pack(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs,
+                              int32_t* const* lists, const int64_t* totals, const int64_t* caps, const int64_t* hdr_off,
+                              const int64_t* rec_off, void* send_buf, void* stream) {
+    if (n_dirs == 0) return DIE_OK;
+    GhostIO k;
+    int rc = fill_io(k, arrays, elem_bytes, n_arrays, n_dirs, caps, hdr_off, rec_off, "die_ghost_pack");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(lists && totals && send_buf, "die_ghost_pack: null argument");
+    int64_t maxcap = 1;
+    for (int i = 0; i < n_dirs; ++i) { k.lists[i] = lists[i]; DIE_REQUIRE(lists[i], "die_ghost_pack: null list %d", i); if (caps[i] > maxcap) maxcap = caps[i]; }
+    k.totals = totals; k.buf = (char*)send_buf; k.holes = nullptr; k.mask = nullptr; k.n = 0; k.n_new = nullptr;
+    int64_t g = (maxcap + DIE_BLOCK - 1) / DIE_BLOCK;
+    dim3 grid((unsigned)(g < 256 ? g : 256), (unsigned)n_dirs);
+    k_ghost_pack<<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
+    DIE_CHECK_LAUNCH("die_ghost_pack");
+    return DIE_OK;
+}
+
+extern "C" int die_ghost_apply(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs,
+                               const int64_t* totals, const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off,
+                               const void* recv_buf, const int32_t* holes, const void* plan_ws, int64_t n_local,
+                               int64_t* n_new_out, void* stream) {
+    GhostIO k;
+    int rc = fill_io(k, arrays, elem_bytes, n_arrays, n_dirs, caps, hdr_off, rec_off, "die_ghost_apply");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(totals && holes && plan_ws && n_new_out && (n_dirs == 0 || recv_buf) && n_local >= 0, "die_ghost_apply: null argument");
+    k.totals = totals; k.buf = (char*)recv_buf; k.holes = holes; k.mask = (const uint16_t*)plan_ws; k.n = n_local; k.n_new = n_new_out;
+    hipStream_t s = (hipStream_t)stream;
+    if (n_dirs > 0) {
+        int64_t maxcap = 1;
+        for (int i = 0; i < n_dirs; ++i) if (caps[i] > maxcap) maxcap = caps[i];
+        int64_t g = (maxcap + DIE_BLOCK - 1) / DIE_BLOCK;
+        dim3 grid((unsigned)(g < 256 ? g : 256), (unsigned)n_dirs);
+        k_ghost_arrivals<<<grid, DIE_BLOCK, 0, s>>>(k);
+    }
+    k_ghost_tail<<<1, 1024, 0, s>>>(k);
+    DIE_CHECK_LAUNCH("die_ghost_apply");
+    return DIE_OK;
+}

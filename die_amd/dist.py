@@ -707,6 +707,10 @@ class DistEnv:
         P.smsg = [(g.neighbour(*g.DIRS[k]), P.sbuf[P.off[k][0]:P.off[k][4]]) for k in range(nd)]
         P.rmsg = [(g.neighbour(*g.DIRS[k]), P.rbuf[P.off[k][0]:P.off[k][4]]) for k in P.recv_order]
         P.hdr_idx = torch.tensor([P.off[k][0] // 8 for k in range(nd)], dtype=torch.int64, device=dev)
+        P.c_caps = (C.c_int64 * max(nd, 1))(*P.caps)
+        P.c_hdr = (C.c_int64 * max(nd, 1))(*[o[0] for o in P.off])
+        P.c_rec = (C.c_int64 * max(nd, 1))(*[o[1] for o in P.off])
+        P.n_new = torch.zeros(1, dtype=torch.int64, device=dev)
         P.ops = None
         if nd and not self.comm.stage_cpu:
             P.ops = ([dist.P2POp(dist.isend, t, p_, self.comm.group) for p_, t in P.smsg] +
@@ -740,18 +744,17 @@ class DistEnv:
             P = self._gplan = self._build_ghost_plan(F)
         nd, sp = P.nd, stream_ptr(dev)
         m, a = self.medium.c_struct(), self._struct(A)
+        # everything below is enqueued without looking at a count; the host reads them once, at the end
         lib.check(lib.lib.die_ghost_plan(C.byref(m), C.byref(a), nd, P.dirs, P.list_ptrs, P.list_caps, _ptr(P.totals),
                                          _ptr(P.ws), P.ws.numel(), sp), 'die_ghost_plan')
-        sb, rb = P.sbuf.data_ptr(), P.rbuf.data_ptr()
-        for k in range(nd):
-            lib.check(lib.lib.die_records_gather_dev(ptrs, esz, F, _ptr(P.lists[k]), C.c_void_p(P.totals.data_ptr() + 8 * k),
-                                                     P.caps[k], C.c_void_p(sb + P.off[k][1]), C.c_void_p(sb + P.off[k][0]), sp),
-                      'die_records_gather_dev')
+        lib.check(lib.lib.die_ghost_pack(ptrs, esz, F, nd, P.list_ptrs, _ptr(P.totals), P.c_caps, P.c_hdr, P.c_rec,
+                                         _ptr(P.sbuf), sp), 'die_ghost_pack')
         self._tick('plan + record pack')
         if nd:
             send_r, recv_r, _ = self._ghost_field_rects(P)
+            sb, rb = C.c_void_p(P.sbuf.data_ptr()), C.c_void_p(P.rbuf.data_ptr())
             for arr, cnt in send_r:
-                lib.check(lib.lib.die_rects_pack(arr, cnt, C.c_void_p(sb), sp), 'die_rects_pack')
+                lib.check(lib.lib.die_rects_pack(arr, cnt, sb, sp), 'die_rects_pack')
             self._tick('field pack')
             if P.ops is None:
                 comm.exchange(P.smsg, P.rmsg)
@@ -760,52 +763,28 @@ class DistEnv:
                     req.wait()
             self._tick('exchange (records + fields, one message per side)')
             for arr, cnt in recv_r:
-                lib.check(lib.lib.die_rects_unpack(arr, cnt, C.c_void_p(rb), sp), 'die_rects_unpack')
-            t = torch.cat([P.totals, P.rbuf.view(torch.int64)[P.hdr_idx]]).cpu().tolist()        # the one host read
-        else:
-            t = P.totals.cpu().tolist()
-        sent, H, kept, arrived = t[:nd], t[nd], t[nd + 1], t[nd + 2:]
-        self._tick('field unpack + counts to host')
+                lib.check(lib.lib.die_rects_unpack(arr, cnt, rb, sp), 'die_rects_unpack')
+        lib.check(lib.lib.die_ghost_apply(ptrs, esz, F, nd, _ptr(P.totals), P.c_caps, P.c_hdr, P.c_rec, _ptr(P.rbuf),
+                                          _ptr(P.lists[nd]), _ptr(P.ws), n, _ptr(P.n_new), sp), 'die_ghost_apply')
+        self._tick('field unpack + arrivals + compaction')
+        t = torch.cat([P.totals, P.n_new, P.rbuf.view(torch.int64)[P.hdr_idx]] if nd else [P.totals, P.n_new]).cpu().tolist()
+        sent, H, kept, n_new, arrived = t[:nd], t[nd], t[nd + 1], t[nd + 2], t[nd + 3:]
+        self._tick('counts to host')
         if kept + H != n:
             raise RuntimeError(f'ghost refresh: {kept} owned + {H} dropped != {n} local agents')
         for k in range(nd):
             if sent[k] > P.caps[k] or arrived[k] > P.caps[k]:
                 raise RuntimeError(f'ghost refresh: {max(sent[k], arrived[k])} agents in the band of side {g.DIRS[k]}, the messages hold '
                                    f'{P.caps[k]}: build DistEnv with a larger ghost_headroom (agents cluster at this border)')
+        if n_new != n - H + sum(arrived):
+            raise RuntimeError(f'ghost refresh: device count {n_new} != {n} - {H} + {sum(arrived)}')
+        if n_new > self.capacity:
+            raise RuntimeError(f'rank {comm.rank}: {n_new} agents (ghosts included) exceed the local capacity {self.capacity}')
         self._owned = kept
         if nd:
             self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))
-        n_arr = sum(arrived)
-        holes = P.lists[nd][:H]
-        if n_arr >= H:
-            n_new = n + n_arr - H
-            arr_dst = torch.cat([holes, torch.arange(n, n_new, dtype=torch.int32, device=dev)]) if n_arr > H else holes
-        else:
-            n_new = n - (H - n_arr)
-            arr_dst = holes[:n_arr]
-            rest = holes[n_arr:].to(torch.int64)
-            low = rest[rest < n_new]                                   # holes that stay inside the new prefix …
-            mask = torch.ones(n - n_new, dtype=torch.bool, device=dev)
-            mask[rest[rest >= n_new] - n_new] = False
-            tail = torch.nonzero(mask, as_tuple=False).squeeze(1) + n_new   # … are filled by the kept entries of the cut tail
-            if tail.numel():
-                tmp = torch.empty((F, int(tail.numel())), dtype=torch.int32, device=dev)
-                lib.check(lib.lib.die_records_gather(ptrs, esz, F, C.c_void_p(tail.data_ptr()), tail.numel(),
-                                                     C.c_void_p(tmp.data_ptr()), sp), 'die_records_gather')
-                lib.check(lib.lib.die_records_scatter(ptrs, esz, F, C.c_void_p(low.data_ptr()), low.numel(),
-                                                      C.c_void_p(tmp.data_ptr()), sp), 'die_records_scatter')
-        if n_new > self.capacity:
-            raise RuntimeError(f'rank {comm.rank}: {n_new} agents (ghosts included) exceed the local capacity {self.capacity}')
-        start = 0
-        for k in range(nd):                       # message k of the receive buffer = what arrived for my side DIRS[k]
-            c = arrived[k]
-            if c:
-                lib.check(lib.lib.die_records_scatter_at(ptrs, esz, F, C.c_void_p(arr_dst.data_ptr() + 4 * start), c, P.caps[k],
-                                                         C.c_void_p(rb + P.off[k][1]), sp), 'die_records_scatter_at')
-            start += c
         A.N = n_new
         action.N = n_new
-        self._tick('compaction + record unpack')
         self._ghosts_fresh = True
 
     # -- the same refresh written with torch index operations (cross-check of the native path: DIE_GHOST_REFRESH=torch) --

@@ -351,6 +351,18 @@ int die_records_gather_dev(void* const* arrays, const int32_t* elem_bytes, int32
 /* die_records_scatter for a 32-bit index list and a record matrix with row pitch `pitch` >= count. */
 int die_records_scatter_at(void* const* arrays, const int32_t* elem_bytes, int32_t n, const int32_t* idx, int64_t count,
                            int64_t pitch, const int32_t* records_in, void* stream);
+/* The refresh without the host in the middle.  Message k of a buffer = [int64 count at hdr_off[k]] [(n_arrays, caps[k])
+ * int32 record matrix at rec_off[k]] (field blocks follow: die_rects_pack).  die_ghost_pack fills every side's records
+ * and header from the plan's lists / totals in ONE launch.  die_ghost_apply consumes a received buffer: arrival j (sides
+ * in order) overwrites holes[j], or is appended behind n_local once the holes are used up; with fewer arrivals than
+ * holes the kept entries of the cut tail move into the remaining holes (plan_ws = the workspace die_ghost_plan wrote
+ * its membership words to).  All counts are read on the device; *n_new_out = the new number of local agents. */
+int die_ghost_pack(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs, int32_t* const* lists,
+                   const int64_t* totals, const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off, void* send_buf,
+                   void* stream);
+int die_ghost_apply(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs, const int64_t* totals,
+                    const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off, const void* recv_buf,
+                    const int32_t* holes, const void* plan_ws, int64_t n_local, int64_t* n_new_out, void* stream);
 
 #ifdef __cplusplus
 }

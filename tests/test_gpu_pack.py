@@ -156,3 +156,72 @@ def test_ghost_plan_matches_numpy_classification(lib, grid, rank, halo):
         c = min(len(w), caps[k])
         assert np.array_equal(got[:c], w[:c]), f'list {k}'          # ascending array indices
         assert (got[c:] == -1).all()
+
+
+@pytest.mark.parametrize('counts', [(40, 0, 25), (3, 2, 1), (0, 0, 0), (300, 300, 300)])
+def test_ghost_pack_and_apply_against_numpy(lib, counts):
+    """die_ghost_pack → (the buffer travels) → die_ghost_apply, with more / fewer / no arrivals than holes: arrivals
+    overwrite the holes in order, surplus is appended, a cut tail is compacted into the remaining holes."""
+    rs = np.random.RandomState(sum(counts) + 11)
+    n, nd, caps = 2000, 3, [300, 300, 300]
+    arrs, ptrs, esz = _arrays(n + 1000, rs)                       # capacity beyond n for appended arrivals
+    F = 3
+    # sender side: three lists of the given lengths
+    lists = [torch.from_numpy(rs.permutation(n)[:max(c, 1)].astype(np.int32)).cuda() for c in counts]
+    totals = torch.tensor(list(counts) + [0, 0], dtype=torch.int64, device='cuda')
+    off, hdr, rec = 0, [], []
+    for k in range(nd):
+        hdr.append(off)
+        rec.append(off + 16)
+        off += 16 + F * caps[k] * 4
+    buf = torch.zeros(off, dtype=torch.uint8, device='cuda')
+    c64 = lambda v: (C.c_int64 * len(v))(*v)
+    lp = (C.c_void_p * nd)(*[t.data_ptr() for t in lists])
+    lib.check(lib.lib.die_ghost_pack(ptrs, esz, F, nd, lp, C.c_void_p(totals.data_ptr()), c64(caps), c64(hdr), c64(rec),
+                                     C.c_void_p(buf.data_ptr()), _sp()), 'die_ghost_pack')
+    host = buf.cpu().numpy()
+    sent = []
+    for k in range(nd):
+        assert int(host[hdr[k]:hdr[k] + 8].view(np.int64)[0]) == counts[k]
+        m = host[rec[k]:rec[k] + F * caps[k] * 4].view(np.int32).reshape(F, caps[k])[:, :counts[k]]
+        sel = lists[k][:counts[k]].cpu().numpy().astype(np.int64)
+        assert np.array_equal(m[0], arrs[0].cpu().numpy()[sel]) and np.array_equal(m[2], arrs[2].cpu().numpy()[sel].astype(np.int32))
+        sent.append(m)
+    # receiver side: its own arrays with H holes (ascending), a plan workspace whose mask marks them
+    H = 90
+    dst, dptr, _ = _arrays(n + 1000, np.random.RandomState(5))
+    before = [t.cpu().numpy().copy() for t in dst]
+    holes_np = np.sort(rs.permutation(n)[:H]).astype(np.int32)
+    holes_np[-5:] = np.arange(n - 5, n)                            # some holes at the very end of the array
+    holes_np = np.unique(holes_np)
+    H = len(holes_np)
+    holes = torch.from_numpy(holes_np).cuda()
+    mask = np.full(n, 1 << 9, dtype=np.uint16)
+    mask[holes_np] = 1 << 8
+    ws = torch.from_numpy(mask.view(np.uint8)).cuda()
+    rtot = torch.tensor([0, 0, 0, H, n - H], dtype=torch.int64, device='cuda')
+    n_new = torch.zeros(1, dtype=torch.int64, device='cuda')
+    lib.check(lib.lib.die_ghost_apply(dptr, esz, F, nd, C.c_void_p(rtot.data_ptr()), c64(caps), c64(hdr), c64(rec),
+                                      C.c_void_p(buf.data_ptr()), C.c_void_p(holes.data_ptr()), C.c_void_p(ws.data_ptr()), n,
+                                      C.c_void_p(n_new.data_ptr()), _sp()), 'die_ghost_apply')
+    n_arr = sum(counts)
+    arrivals = np.concatenate(sent, axis=1)                        # (F, n_arr) in side order
+    want = [b.copy() for b in before]
+    for f in range(F):
+        view = want[f].view(np.int32) if want[f].dtype != np.uint8 else want[f]
+        for j in range(n_arr):
+            d = holes_np[j] if j < H else n + (j - H)
+            view[d] = arrivals[f, j]
+    if n_arr >= H:
+        exp_n = n + n_arr - H
+    else:
+        exp_n = n - (H - n_arr)
+        rest = holes_np[n_arr:]
+        low = rest[rest < exp_n]
+        tail = np.array([p for p in range(exp_n, n) if p not in set(holes_np.tolist())], dtype=np.int64)
+        assert len(tail) == len(low)
+        for f in range(F):
+            want[f][low] = want[f][tail]
+    assert int(n_new) == exp_n
+    for f in range(F):
+        assert np.array_equal(dst[f].cpu().numpy()[:exp_n], want[f][:exp_n]), f'array {f}'
