@@ -309,7 +309,12 @@ __global__ __launch_bounds__(1024) void k_ghost_tail(GhostIO a) {
     for (int q = 0; q < a.nd; ++q) n_arr += ghost_arrived(a, q);
     const int64_t H = a.totals[a.nd];
     const int64_t n_new = n_arr >= H ? a.n + (n_arr - H) : a.n - (H - n_arr);
-    if (threadIdx.x == 0) { *a.n_new = n_new; s_base = 0; }
+    if (threadIdx.x == 0) {
+        // everything the host wants to know, in one place: [n_new, holes, owned, sent per side…, arrived per side…]
+        a.n_new[0] = n_new; a.n_new[1] = H; a.n_new[2] = a.totals[a.nd + 1];
+        for (int q = 0; q < a.nd; ++q) { a.n_new[3 + q] = a.totals[q]; a.n_new[3 + a.nd + q] = *(const int64_t*)(a.buf + a.hdr_off[q]); }
+        s_base = 0;
+    }
     __syncthreads();
     if (n_arr >= H) return;
     for (int64_t p0 = n_new; p0 < a.n; p0 += 1024) {

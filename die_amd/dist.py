@@ -710,7 +710,7 @@ class DistEnv:
         P.c_caps = (C.c_int64 * max(nd, 1))(*P.caps)
         P.c_hdr = (C.c_int64 * max(nd, 1))(*[o[0] for o in P.off])
         P.c_rec = (C.c_int64 * max(nd, 1))(*[o[1] for o in P.off])
-        P.n_new = torch.zeros(1, dtype=torch.int64, device=dev)
+        P.n_new = torch.zeros(3 + 2 * nd, dtype=torch.int64, device=dev)      # die_ghost_apply's summary for the host
         P.ops = None
         if nd and not self.comm.stage_cpu:
             P.ops = ([dist.P2POp(dist.isend, t, p_, self.comm.group) for p_, t in P.smsg] +
@@ -767,8 +767,8 @@ class DistEnv:
         lib.check(lib.lib.die_ghost_apply(ptrs, esz, F, nd, _ptr(P.totals), P.c_caps, P.c_hdr, P.c_rec, _ptr(P.rbuf),
                                           _ptr(P.lists[nd]), _ptr(P.ws), n, _ptr(P.n_new), sp), 'die_ghost_apply')
         self._tick('field unpack + arrivals + compaction')
-        t = torch.cat([P.totals, P.n_new, P.rbuf.view(torch.int64)[P.hdr_idx]] if nd else [P.totals, P.n_new]).cpu().tolist()
-        sent, H, kept, n_new, arrived = t[:nd], t[nd], t[nd + 1], t[nd + 2], t[nd + 3:]
+        t = P.n_new.cpu().tolist()                                   # the one host read
+        n_new, H, kept, sent, arrived = t[0], t[1], t[2], t[3:3 + nd], t[3 + nd:]
         self._tick('counts to host')
         if kept + H != n:
             raise RuntimeError(f'ghost refresh: {kept} owned + {H} dropped != {n} local agents')

@@ -356,7 +356,8 @@ int die_records_scatter_at(void* const* arrays, const int32_t* elem_bytes, int32
  * and header from the plan's lists / totals in ONE launch.  die_ghost_apply consumes a received buffer: arrival j (sides
  * in order) overwrites holes[j], or is appended behind n_local once the holes are used up; with fewer arrivals than
  * holes the kept entries of the cut tail move into the remaining holes (plan_ws = the workspace die_ghost_plan wrote
- * its membership words to).  All counts are read on the device; *n_new_out = the new number of local agents. */
+ * its membership words to).  All counts are read on the device; n_new_out (3 + 2 * n_dirs words) receives what the host
+ * wants afterwards: [new number of local agents, holes, owned, sent per side…, arrived per side… (raw headers)]. */
 int die_ghost_pack(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs, int32_t* const* lists,
                    const int64_t* totals, const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off, void* send_buf,
                    void* stream);

@@ -200,7 +200,7 @@ def test_ghost_pack_and_apply_against_numpy(lib, counts):
     mask[holes_np] = 1 << 8
     ws = torch.from_numpy(mask.view(np.uint8)).cuda()
     rtot = torch.tensor([0, 0, 0, H, n - H], dtype=torch.int64, device='cuda')
-    n_new = torch.zeros(1, dtype=torch.int64, device='cuda')
+    n_new = torch.zeros(3 + 2 * nd, dtype=torch.int64, device='cuda')
     lib.check(lib.lib.die_ghost_apply(dptr, esz, F, nd, C.c_void_p(rtot.data_ptr()), c64(caps), c64(hdr), c64(rec),
                                       C.c_void_p(buf.data_ptr()), C.c_void_p(holes.data_ptr()), C.c_void_p(ws.data_ptr()), n,
                                       C.c_void_p(n_new.data_ptr()), _sp()), 'die_ghost_apply')
@@ -222,6 +222,6 @@ def test_ghost_pack_and_apply_against_numpy(lib, counts):
         assert len(tail) == len(low)
         for f in range(F):
             want[f][low] = want[f][tail]
-    assert int(n_new) == exp_n
+    assert n_new.cpu().tolist() == [exp_n, H, n - H, 0, 0, 0] + list(counts)
     for f in range(F):
         assert np.array_equal(dst[f].cpu().numpy()[:exp_n], want[f][:exp_n]), f'array {f}'
