@@ -478,10 +478,13 @@ class DistEnv:
         return lib.Dynamics(d.rate_feed, d.rate_decay_chem, d.diffuse_sigma, boundary, cost, 0.02, 0.01,
                             int(d.food_infinite), int(d.agents_die), int(not self._all_alive), 0)
 
-    def _per_agent_tensors(self, action) -> List[torch.Tensor]:
-        """Every per-agent array that must travel with a migrating agent (4-byte views)."""
+    def _per_agent_tensors(self, action, with_action: bool = True) -> List[torch.Tensor]:
+        """Every per-agent array that must travel with a migrating agent (4-byte views).  The action travels only
+        while it still means something (materialised and not yet stepped)."""
         A = self.agents
-        ts = [A.x, A.y, A.slot, A.agent_food, action.data[0], action.data[1], action.data[2]]
+        ts = [A.x, A.y, A.slot, A.agent_food]
+        if with_action:
+            ts += [action.data[0], action.data[1], action.data[2]]
         for obj in A.attached():
             ts += obj._die_state_tensors(A)
         return ts
@@ -605,7 +608,7 @@ class DistEnv:
         self._food_flow()
         self._steps += 1
         if self._steps % self.migrate_every == 0:
-            self._refresh_ghosts(action)
+            self._refresh_ghosts(action, after_step=True)
         if self._sort_every > 0 and self._steps % self._sort_every == 0 and A.N > 1:
             self.sort_agents()
         self.last_result = result
@@ -659,8 +662,11 @@ class DistEnv:
             self._prof[name] = self._prof.get(name, 0.0) + now - self._t_last
         self._t_last = now
 
-    def _refresh_ghosts(self, action):
+    def _refresh_ghosts(self, action, after_step: bool = False):
         """Re-seat owners, ghosts and the chem / food halos (see _step_ghost)."""
+        from .device_array import PendingAction
+        # a consumed action, or one whose forward() has not run yet, holds nothing worth sending
+        self._send_action = not after_step and not (isinstance(action, PendingAction) and action.pending)
         if not self.geo.DIRS:                      # one rank: the tile is the world, nobody to exchange with
             self._owned = self.agents.N
             self._ghosts_fresh = True
@@ -736,12 +742,13 @@ class DistEnv:
         A, g, comm, lib, dev = self.agents, self.geo, self.comm, self._lib, self.device
         n = A.N
         self._tick()
-        tensors = self._per_agent_tensors(action)
+        tensors = self._per_agent_tensors(action, self._send_action)
         arrs, ptrs, esz = self._record_arrays(tensors)
         F = len(arrs)
-        P = getattr(self, '_gplan', None)
-        if P is None or P.F != F:
-            P = self._gplan = self._build_ghost_plan(F)
+        plans = self.__dict__.setdefault('_gplans', {})
+        P = plans.get(F)
+        if P is None:
+            P = plans[F] = self._build_ghost_plan(F)
         nd, sp = P.nd, stream_ptr(dev)
         m, a = self.medium.c_struct(), self._struct(A)
         # everything below is enqueued without looking at a count; the host reads them once, at the end
@@ -814,7 +821,7 @@ class DistEnv:
         if owned_world != self.world_agents:
             raise RuntimeError(f'ghost refresh: {owned_world} agents are owned, the world has {self.world_agents}: an agent moved '
                                f'further than max_step_cells per step or sensed further than probe_reach')
-        tensors = self._per_agent_tensors(action)
+        tensors = self._per_agent_tensors(action, self._send_action)
         arrs, ptrs, esz = self._record_arrays(tensors)
         sp = stream_ptr(self.device)
         sends, recvs, parts = [], [], []
