@@ -196,7 +196,8 @@ def main():
             agent_kw.update(scale=1.53 / (max(gW, gH) - 1), sense_offset=10.2 / (max(gW, gH) - 1))
             denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
                            device=device, seed=args.seed, sort_every=args.sort_every,
-                           migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost')
+                           migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost',
+                           ghost_headroom=1.3)     # the synthetic world stays uniform (measured fill 0.5 of 2x over 1200 steps)
             how = (f'ghost agents, halo ({denv.geo.hx}, {denv.geo.hy}) re-seated every {denv.migrate_every} steps' if denv.ghosts else
                    f'halo {denv.geo.h}, claims merged every step, strays handed over every {denv.migrate_every} steps')
             mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, {how}, '
