@@ -32,7 +32,7 @@ def _wave_dynamics(die_amd, W, H):
 
 
 def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
-            wave=False):
+            wave=False, f16=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -52,7 +52,8 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
         env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H) if wave else None, probe_reach=11,
                                         device='cuda:0', sort_every=sort_every,
-                                        overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts)
+                                        overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
+                                        field_dtype=torch.float16 if f16 else torch.float32)
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
         local = torch.zeros(cap, dtype=torch.float32, device='cuda:0')
@@ -107,10 +108,11 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
     assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
 
 
-def _single_device_run(W, H, N, K, steps, wave=False):
+def _single_device_run(W, H, N, K, steps, wave=False, f16=False):
     import die_amd
     medium, agents, dir0 = _state(W, H, N, K, 5)
-    env = die_amd.Env.from_numpy(medium, agents, _wave_dynamics(die_amd, W, H) if wave else None, sort_every=0)
+    env = die_amd.Env.from_numpy(medium, agents, _wave_dynamics(die_amd, W, H) if wave else None, sort_every=0,
+                                 field_dtype=torch.float16 if f16 else torch.float32)
     agent = die_amd.PhysarumAgent(max_agents=N, seed=9, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
     agent.set_state(dir0)
     obs = env._get_current_obs
@@ -123,7 +125,8 @@ def _single_device_run(W, H, N, K, steps, wave=False):
 
 @pytest.mark.parametrize('grid,sort_every,refresh_every,backend,wave', [
     ((1, 2), 0, 2, 'gloo', False), ((2, 1), 3, 3, 'gloo', False), ((2, 2), 2, 2, 'gloo', False), ((2, 2), 0, 3, 'gloo', True),
-    ((2, 2), 4, 1, 'gloo', False), ((1, 1), 2, 4, 'nccl', True), ((2, 2), 2, 2, 'gloo-torch-refresh', False)])
+    ((2, 2), 4, 1, 'gloo', False), ((1, 1), 2, 4, 'nccl', True), ((2, 2), 2, 2, 'gloo-torch-refresh', False),
+    ((1, 2), 3, 3, 'gloo-f16', False)])
 def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, refresh_every, backend, wave):
     """Communication-avoiding mode: ghosts of the neighbours' border agents are stepped locally, nothing crosses
     ranks for `refresh_every` steps; world state and rewards must equal the single-device run bit for bit
@@ -134,10 +137,12 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
     W, H, N, K, steps = 256, 192, 7000, 6400, 13
     out = str(tmp_path / 'dist.npz')
     size = grid[0] * grid[1]
-    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, False, refresh_every, out, backend, True, wave),
-             nprocs=size, join=True)
+    f16 = backend.endswith('-f16')                                   # fp16 field channels (BASELINE configs[4])
+    backend = backend.replace('-f16', '')
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, K, steps, sort_every, False, refresh_every, out, backend, True, wave,
+                            f16), nprocs=size, join=True)
     got = np.load(out)
-    m, a, r = _single_device_run(W, H, N, K, steps, wave)
+    m, a, r = _single_device_run(W, H, N, K, steps, wave, f16)
     assert np.array_equal(got['agents'], a)
     for c in range(3):
         assert np.array_equal(got['medium'][c], m[c])
