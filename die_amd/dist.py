@@ -667,6 +667,9 @@ class DistEnv:
         from .device_array import PendingAction
         # a consumed action, or one whose forward() has not run yet, holds nothing worth sending
         self._send_action = not after_step and not (isinstance(action, PendingAction) and action.pending)
+        if self._send_action and action.data.shape[1] < self.capacity:
+            raise ValueError(f'the action arrays hold {action.data.shape[1]} slots, the local agent arrays {self.capacity}: arriving '
+                             f'ghosts bring their action with them (build the action for `env.capacity` slots)')
         if not self.geo.DIRS:                      # one rank: the tile is the world, nobody to exchange with
             self._owned = self.agents.N
             self._ghosts_fresh = True
