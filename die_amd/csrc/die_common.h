@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned long long die_claim(int epoch, int64_t slot,
     return ((unsigned long long)die_owner_word(epoch, slot) << 32) | (unsigned long long)__float_as_uint(deposit);
 }
 __device__ __forceinline__ bool die_claim_occupied(unsigned long long k, int epoch) {
-    return (uint32_t)(k >> 61) == (uint32_t)epoch;
+    return (uint32_t)(k >> (32 + DIE_OWNER_EPOCH_SHIFT)) == (uint32_t)epoch;
 }
 __device__ __forceinline__ float die_claim_deposit(unsigned long long k) { return __uint_as_float((uint32_t)k); }
 

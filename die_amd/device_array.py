@@ -80,7 +80,7 @@ class DeviceMedium:
 
     def occupied(self) -> torch.Tensor:
         """Boolean (W, H): the 'agents' channel > 0."""
-        return ((self.owner >> 61) & 7) == self.epoch
+        return ((self.owner >> (32 + _lib.OWNER_EPOCH_SHIFT)) & _lib.OWNER_EPOCH_MAX) == self.epoch
 
     def owner_slots(self) -> torch.Tensor:
         """int64 (W, H): owning slot id, −1 for empty cells."""

@@ -243,7 +243,7 @@ class Env(_EnvBase):
         """`n_steps` × `obs, … = env.step(agent.forward(obs))` (the loop of examples/minimal_run.py:23-25) without reading
         anything back in between.  Returns the (n_steps, 2) float64 device tensor of die_step_result words
         (`read_results` decodes it).  `graph=True` (Gradient / Physarum agents): the loop is captured ONCE as a hipGraph
-        of K = lcm(epochs 7, chem planes 2, two re-sorts) steps and replayed; the launch arguments of a graph are
+        of K = lcm(epochs 31, chem planes 2, two re-sorts) steps and replayed; the launch arguments of a graph are
         frozen, so the Philox step counter comes from a device word (`step_base`).  Same bits as the step-by-step loop
         (tests/test_gpu_parity.py::test_graph_run_equals_step_loop).  Measured on MI355X / ROCm 7 the replay is NOT
         faster than the plain launch loop (256²: 33.8 vs 30.4 µs/step, 1024²: 49.0 vs 42.3, 4096²: 243 vs 224 —

