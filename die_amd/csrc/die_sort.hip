@@ -246,7 +246,10 @@ extern "C" int die_agents_sort(const die_medium* m, const die_agents* in, const 
     char* w = (char*)ws;
     hipStream_t s = (hipStream_t)stream;
     int64_t g = (N + DIE_BLOCK - 1) / DIE_BLOCK;
-    const int grid = (int)(g < 4096 ? g : 4096);
+#ifndef DIE_SORT_GRID_CAP
+#define DIE_SORT_GRID_CAP 4096
+#endif
+    const int grid = (int)(g < DIE_SORT_GRID_CAP ? g : DIE_SORT_GRID_CAP);
     const int nby = (m->H >> DIE_SORT_YSHIFT) + 1;
     for (int i = 0; i < n_extra; ++i)
         DIE_REQUIRE(extra_in[i] && extra_out[i] && extra_in[i] != extra_out[i], "die_agents_sort: bad attached array %d", i);
