@@ -56,7 +56,7 @@ def algorithmic_bytes(C, K):
     }
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v6_pmc_traffic_per_kernel_avg.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v7_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
@@ -317,7 +317,7 @@ def main():
         line['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/r01_v6_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
+            'traffic_source': 'profiles/r01_v7_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},
