@@ -116,7 +116,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_sort_hist(die_geo g, int64_t N, c
 
 // exclusive scan of the bucket counts by ONE workgroup: cursor[b] = first position of bucket b.  A thread owns `per`
 // consecutive buckets (per % 4 == 0: 16-byte loads, all of them in flight before the first use).
+#ifndef SORT_SCAN_MAX_PER
 #define SORT_SCAN_MAX_PER 64
+#endif
 __global__ __launch_bounds__(1024) void k_sort_scan(const uint32_t* hist, uint32_t* cursor, int nb, int per) {
     __shared__ uint32_t s[1024];
     const int lo = threadIdx.x * per;
