@@ -2,7 +2,9 @@
 """bench.py — env steps/sec of the Physarum grid step (agent.forward + env.step) on MI355X.
 
 Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON
-line on rank 0.  A "step" is one PhysarumAgent.forward + one Env.step (action handed over in
+line on rank 0.  With N > 1 and no rank environment the command launches its own N ranks
+(torch.distributed.run) before touching the GPU; a failure of the decomposed path ends the run
+with a non-zero status — there is no fallback to independent replicas.  A "step" is one PhysarumAgent.forward + one Env.step (action handed over in
 HBM, as the Gym API does) over a synthetic 4096x4096 fp32 grid (BASELINE.json configs[2]) with
 the state already resident in HBM.  Next to it: `roofline` for the dominant kernel (HIP-event
 timed here, algorithmic bytes from DESIGN.md §5) and `cpu_baseline` (the float64 numpy oracle,
@@ -19,6 +21,34 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def kernel_source_sha():
+    """sha1 over the kernel sources: stamps which build a committed PMC file belongs to."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'die_amd', 'csrc', '*.h*'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no rank environment: this process becomes the launcher.  It starts N
+    fresh rank processes with torch.distributed.run BEFORE anything here has touched the GPU, relays their output
+    (rank 0 prints the JSON line) and exits with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    return subprocess.run(cmd, env=env).returncode
 
 
 def parse():
@@ -56,22 +86,27 @@ def algorithmic_bytes(C, K):
     }
 
 
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_v7_pmc_traffic_per_kernel_avg.json')
+PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
 
 
 def pmc_traffic(kernel):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same
-    command (profiles/README.md): (FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE under-counts wide coalesced
-    streams by 2x on gfx950 (applied to the diffusion sweep only); None if the file is absent."""
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
+    (profiles/README.md): (FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE under-counts wide coalesced streams by 2x on gfx950
+    (applied to the diffusion sweep only).  The file carries the sha of the kernel sources it was taken from: when the
+    sources have changed since, the figure would be stale and is reported as null."""
     try:
-        c = json.load(open(PMC_FILE))[PMC_NAMES[kernel]]
+        doc = json.load(open(PMC_FILE))
+        if doc.get('kernel_source_sha') != kernel_source_sha():
+            return None, f'{os.path.relpath(PMC_FILE, ROOT)} was taken from another build of the kernels (sha {doc.get("kernel_source_sha")}): not reported'
+        c = doc[PMC_NAMES[kernel]]
         fetch = c['FETCH_SIZE'] * (2 if kernel == 'k_diffuse_rows_fused' else 1)
-        return int((fetch + c['WRITE_SIZE']) * 1024)
-    except Exception:
-        return None
+        return int((fetch + c['WRITE_SIZE']) * 1024), (f'{os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command, '
+                                                      f'kernel sources sha {doc["kernel_source_sha"]})')
+    except Exception as e:
+        return None, f'unavailable: {type(e).__name__}'
 
 
 def time_kernels(env, agent, reps):
@@ -155,26 +190,52 @@ def cpu_baseline(env, agent_kw, n_steps, seed):
     return n_steps / dt, dt
 
 
+def other_cpu_baselines(seed):
+    """BASELINE.md §3's two smaller CPU cases, for the record (not the metric): BASELINE configs[0] Brownian 256x256 x 300
+    steps (examples/minimal_run.py:32-36) and Physarum 1024x1024 x 50 steps, same float64 oracle."""
+    from oracle import cpu_ref as R
+    out = []
+    for name, (W, H), ratio, steps, mk in (
+            ('BrownianAgent 256x256, 300 steps, ratio 0.05', (256, 256), 0.05, 300, lambda N: R.RefBrownianAgent(move_scale=0.01, seed=seed)),
+            ('PhysarumAgent 1024x1024, 50 steps, ratio 0.15', (1024, 1024), 0.15, 50,
+             lambda N: R.RefPhysarumAgent(N, seed=seed, scale=1.53 / 1023, sense_offset=10.2 / 1023))):
+        medium, agents = R.synthetic_init(W, H, ratio, seed=seed)
+        agents = agents[:, :int(agents[2].sum())].copy()              # alive-only slots, like the GPU workload
+        env, agent = R.RefEnv(medium, agents), mk(agents.shape[1])
+        obs = env.obs
+        obs, *_ = env.step(agent.forward(obs))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            obs, *_ = env.step(agent.forward(obs))
+        dt = time.perf_counter() - t0
+        out.append({'workload': name, 'value': round(steps / dt, 3), 'unit': 'env steps/s', 'seconds': round(dt, 2)})
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.force_dist:
+        sys.exit(launch_ranks(args))              # nothing above this line touches the GPU
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dist_on = world > 1 or args.force_dist
+    backend = os.environ.get('DIE_DIST_BACKEND', 'nccl')      # 'gloo': rehearsal with several ranks sharing one GPU
     if dist_on:
         import datetime
         import torch.distributed as dist
-        backend = os.environ.get('DIE_DIST_BACKEND', 'nccl')      # 'gloo': rehearsal with several ranks on one GPU
-        if torch.cuda.device_count() == 1:
+        n_dev = torch.cuda.device_count()
+        if backend == 'nccl' and world > n_dev:
+            sys.exit(f'bench.py: {world} ranks over RCCL need {world} GPUs, this box has {n_dev} '
+                     '(DIE_DIST_BACKEND=gloo rehearses the decomposed path with the ranks sharing one GPU)')
+        if n_dev == 1:
             local_rank = 0
         torch.cuda.set_device(local_rank)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         kw = dict(device_id=torch.device(f'cuda:{local_rank}')) if backend == 'nccl' else {}
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300), **kw)
-    elif args.gpus > 1:
-        sys.exit('launch N>1 with torch.distributed.run (one rank per GPU)')
     device = torch.device(f'cuda:{local_rank}')
     torch.cuda.set_device(device)
 
@@ -184,103 +245,69 @@ def main():
                     turn_tolerance=0.1, deposit=4.0)
     GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
     mode, denv = 'single GPU', None
+    # A failure anywhere in the decomposed path ends the run with a non-zero status (torch.distributed.run then stops the
+    # other ranks): the scaling record shows the failure instead of a replica number under the same metric name.
     if dist_on:
         # weak scaling: every rank owns one W×H tile of a (W·Px)×(H·Py) torus — 2-D domain decomposition with
         # chem-halo exchange and agent migration over RCCL point-to-point (die_amd/dist.py)
         grid = GRIDS.get(world) or (1, world)
-        try:
-            from die_amd.dist import DistEnv
-            gW, gH = W * grid[0], H * grid[1]
-            # same cell-unit parameters as the single-GPU workload (10.2-cell probe, 1.53-cell step)
-            # (a non-square world is anisotropic in cells, offsets being fractions of the unit square: size them on the longer axis)
-            agent_kw.update(scale=1.53 / (max(gW, gH) - 1), sense_offset=10.2 / (max(gW, gH) - 1))
-            denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
-                           device=device, seed=args.seed, sort_every=args.sort_every,
-                           migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost',
-                           ghost_headroom=1.3)     # the synthetic world stays uniform (measured fill 0.5 of 2x over 1200 steps)
-            how = (f'ghost agents, halo ({denv.geo.hx}, {denv.geo.hy}) re-seated every {denv.migrate_every} steps' if denv.ghosts else
-                   f'halo {denv.geo.h}, claims merged every step, strays handed over every {denv.migrate_every} steps')
-            mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, {how}, '
-                    f'{"RCCL" if backend == "nccl" else backend} point-to-point')
-        except Exception as e:           # keep the scaling run alive: independent replicas, and say so
-            denv = None
-            mode = f'{world} independent grid replicas (decomposition unavailable: {type(e).__name__}: {e})'
-    if denv is not None:
-        # trial steps before committing to the decomposed path: a transport that fails at the first exchanges must
-        # not cost the scaling run its line (all ranks agree on the outcome; on failure: replicas, and say so)
-        ok, why = 1, ''
-        try:
-            trial_agent = die_amd.PhysarumAgent(max_agents=denv.capacity, seed=args.seed, **agent_kw)   # one seed: streams are keyed by world slot id
-            o = denv._get_current_obs
-            for _ in range(2 * denv.migrate_every + 1):          # covers two refreshes / hand-overs over the real transport
-                o, res, *_ = denv.step(trial_agent.forward(o))
-            denv.read_result(res)                                # ghost mode: every world agent has exactly one owner
-            torch.cuda.synchronize()
-        except Exception as e:
-            ok, why = 0, f'{type(e).__name__}: {e}'
-        try:
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        except Exception as e:
-            ok, why = 0, why or f'{type(e).__name__}: {e}'
-        if ok:
-            agent = trial_agent
-        else:
-            denv = None
-            agent_kw.update(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
-            mode = f'{world} independent grid replicas (decomposed step failed: {why or "on another rank"})'
+        from die_amd.dist import DistEnv
+        gW, gH = W * grid[0], H * grid[1]
+        # same cell-unit parameters as the single-GPU workload (10.2-cell probe, 1.53-cell step); a non-square world is
+        # anisotropic in cells (offsets are fractions of the unit square): size them on the longer axis
+        agent_kw.update(scale=1.53 / (max(gW, gH) - 1), sense_offset=10.2 / (max(gW, gH) - 1))
+        denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
+                       device=device, seed=args.seed, sort_every=args.sort_every,
+                       migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost',
+                       ghost_headroom=1.3)     # the synthetic world stays uniform (measured fill 0.5 of 2x over 1200 steps)
+        how = (f'ghost agents, halo ({denv.geo.hx}, {denv.geo.hy}) re-seated every {denv.migrate_every} steps' if denv.ghosts else
+               f'halo {denv.geo.h}, claims merged every step, strays handed over every {denv.migrate_every} steps')
+        mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, {how}, '
+                f'{"RCCL" if backend == "nccl" else backend} point-to-point')
+        env = denv
+        agent = die_amd.PhysarumAgent(max_agents=denv.capacity, seed=args.seed, **agent_kw)   # one seed: streams are keyed by world slot id
+    else:
+        env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed,
+                          max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
+                          field_dtype=torch.float16 if args.fields == 'f16' else torch.float32)
+        agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **agent_kw)
+
     def barrier():
         if dist_on:
-            try:
-                dist.barrier()
-            except Exception:
-                if denv is not None:       # the decomposed run needs it; replicas after a transport failure do not
-                    raise
+            dist.barrier()
 
     def timed_run(env, agent):
+        """Pre-warm (not part of the contract's W): at least two full re-sort / refresh periods and >= 50 ms of GPU work, so
+        that lazily created state, first launches and the clock ramp are behind us whatever --warmup says.  Then W warm-up
+        steps, then EXACTLY K timed steps between barrier + synchronize pairs, one HIP event after every step."""
         obs = env._get_current_obs
-        results = []
+        period = max(args.sort_every, 1)
+        if dist_on:
+            period = max(period, env.migrate_every)
+        n_pre, t_pre = 0, time.perf_counter()
+        while n_pre < 2 * period + 1 or time.perf_counter() - t_pre < 0.05:
+            for _ in range(2 * period + 1):
+                obs, res, *_ = env.step(agent.forward(obs))
+            n_pre += 2 * period + 1
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             obs, res, *_ = env.step(agent.forward(obs))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        ev[0].record()
+        for i in range(args.steps):
             obs, res, *_ = env.step(agent.forward(obs))
-            results.append(res)
+            ev[i + 1].record()
         torch.cuda.synchronize()
         barrier()
-        return time.perf_counter() - t0, results
+        dt = time.perf_counter() - t0
+        per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
+        return dt, res, per_step, n_pre
 
-    def replica():
-        e = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + rank,
-                        max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
-                        field_dtype=torch.float16 if args.fields == 'f16' else torch.float32)
-        return e, die_amd.PhysarumAgent(max_agents=e.agents.N, seed=args.seed + rank, **agent_kw)
-
-    if denv is not None:
-        env = denv
-        ok, why = 1, ''
-        try:
-            dt, results = timed_run(env, agent)
-            last_reward, last_alive = env.read_result(results[-1])
-        except Exception as e:                                   # e.g. a ghost refresh that overflows its messages
-            ok, why = 0, f'{type(e).__name__}: {e}'
-        try:
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = int(flag.item())
-        except Exception as e:
-            ok, why = 0, why or f'{type(e).__name__}: {e}'
-        if not ok:
-            denv = None
-            agent_kw.update(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
-            mode = f'{world} independent grid replicas (decomposed run failed: {why or "on another rank"})'
-    if denv is None:
-        env, agent = replica()
-        dt, results = timed_run(env, agent)
-        last_reward, last_alive = env.read_result(results[-1])
+    dt, res, per_step, n_pre = timed_run(env, agent)
+    last_reward, last_alive = env.read_result(res)
     K = env.agents.N
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -288,17 +315,22 @@ def main():
         dt = float(t.item())
     # whole job: the world is `world` tiles of W×H cells, so one world step = `world` 4096²-grid steps
     steps_per_s = args.steps / dt * world
+    med = per_step[len(per_step) // 2]
     line = {
         'metric': 'env steps/sec on 4096^2 Physarum grid', 'value': round(steps_per_s, 2), 'unit': 'env steps/s',
         'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.fields, 'data': 'synthetic',
+        'decomposed': bool(dist_on),
         'config': {'workload': f'PhysarumAgent {W}x{H} {args.fields} fields, agent ratio {args.ratio} (BASELINE configs[2]); '
                                'step = PhysarumAgent.forward + Env.step with the action handed over in HBM',
                    'grid': [W, H], 'alive_agents': K, 'agent_slots': K, 'steps_per_rank': args.steps,
-                   'parallelism': mode,
+                   'parallelism': mode, 'prewarm_steps': n_pre,
                    'last_reward': round(last_reward, 3), 'last_num_agents': last_alive},
+        # one HIP event after every timed step (rank 0's stream): device-side step times, host launch gaps included
+        'step_ms': {'median': round(med, 4), 'mean': round(sum(per_step) / len(per_step), 4), 'min': round(per_step[0], 4),
+                    'max': round(per_step[-1], 4), 'median_steps_per_s': round(1e3 / med * world, 1)},
     }
-    if rank == 0 and denv is not None:
+    if rank == 0 and dist_on:
         Kw = int(getattr(denv, 'world_agents', K * world))
         Bw = (12 * W * H * world + 104 * Kw)
         line['config'].update(alive_agents=Kw, agent_slots=Kw, local_agents_rank0=K)
@@ -314,26 +346,28 @@ def main():
         kt = time_kernels(env, agent, args.kernel_reps)
         dom = max(kt, key=kt.get)
         ach = B[dom] / (kt[dom] * 1e-6) / 1e9
+        traffic, traffic_src = pmc_traffic(dom)
         line['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': pmc_traffic(dom),
-            'traffic_source': 'profiles/r01_v7_pmc_traffic_per_kernel_avg.json (separate --pmc passes of this command)',
+            'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},
             'copy_ceiling_gbs': round(copy_ceiling_gbs(device), 1),
             'step': {'algorithmic_bytes': B['step'],
                      'achieved': round(B['step'] / (dt / args.steps) / 1e9, 1),
-                     'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                     'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     'frac_median_step': round(B['step'] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             v, cpu_dt = cpu_baseline(env, agent_kw, args.cpu_steps, args.seed)
             line['cpu_baseline'] = {
                 'value': round(v, 4), 'unit': 'env steps/s', 'cores': 1, 'kind': 'port',
                 'sample': f'{args.cpu_steps} steps of the same {W}x{H} workload ({K} alive-only slots) after 1 warm-up '
                           f'step, {cpu_dt:.1f} s; float64 numpy/scipy oracle (index arithmetic instead of the '
                           "reference's pandas label lookups, so faster than the reference itself); host has "
-                          f'{os.cpu_count()} cores, numpy/scipy kernels on this path run on 1 thread'}
+                          f'{os.cpu_count()} cores, numpy/scipy kernels on this path run on 1 thread',
+                'other_sizes': other_cpu_baselines(args.seed)}
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class Medium(C.Structure):
@@ -42,7 +42,7 @@ class Dynamics(C.Structure):
     _fields_ = [('rate_feed', C.c_float), ('rate_decay_chem', C.c_float), ('diffuse_sigma', C.c_float),
                 ('boundary', C.c_int32), ('cost', C.c_int32), ('cost_w_deposit', C.c_float),
                 ('cost_w_dist', C.c_float), ('food_infinite', C.c_int32), ('agents_die', C.c_int32),
-                ('has_dead_slots', C.c_int32), ('diffuse_mode', C.c_int32)]
+                ('has_dead_slots', C.c_int32), ('diffuse_mode', C.c_int32), ('staged', C.c_int32)]
 
 
 class GradientAgent(C.Structure):
@@ -129,7 +129,7 @@ _SIGNATURES = {
     'die_ghost_pack': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_void_p, _P(C.c_int64),
                                  _P(C.c_int64), _P(C.c_int64), C.c_void_p, C.c_void_p]),
     'die_ghost_apply': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, _P(C.c_int64), _P(C.c_int64),
-                                  _P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+                                  _P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
                                   C.c_int64, C.c_void_p]),

@@ -13,7 +13,6 @@
 // (pass 1) are separated from the single write per occupied cell (pass 2) by a kernel boundary.
 // "Last writer wins" of the fancy-index assignment at :211 is an atomicMax on the slot id.
 #include "die_forward.h"
-#include <stdlib.h>
 
 #ifndef DIE_MAX_PARTIALS
 #define DIE_MAX_PARTIALS 8192
@@ -46,7 +45,6 @@ struct StepArgs {
     const float* dep;
     float rate_feed, w_dep, w_dist;
     int boundary, cost, food_infinite, agents_die, has_dead;
-    int claim_by_store;    // 1: k_move_claim stores, k_claim_fix repairs; 0: atomicMax in k_move_claim
     int skip_scatter;      // fused step: the winner's chem/food writes are done by k_diffuse_rows
     float* stash;          // N floats, only when has_dead
     long long* part_gain;  // gridDim.x fixed-point sums (die_fix)
@@ -103,25 +101,12 @@ __device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t
     if (a.tile_of) a.tile_of[n] = (cx / a.tile_w) * a.tiles_y + cy / a.tile_h;
     if (!a.do_claim) return 0.f;
     const int64_t c = die_local(g, cx, cy);
-#ifndef DIE_ABL_NOFOODG
     const float consumed = a.rate_feed * die_ld(food, c);
-#else
-    const float consumed = a.rate_feed * (float)c;
-#endif
     if (a.alive[n]) {
-        // Claim: one 64-bit atomicMax (≈ 58 µs per 2.5 M agents).  claim_by_store: plain store now
-        // (≈ 21 µs) and k_claim_fix raises the word to the maximum afterwards (≈ 38 µs) — measured, no gain.
-        const unsigned long long key = die_claim(a.epoch, (int64_t)sid, dep);
-#ifndef DIE_ABL_NOCLAIM
-        if (a.claim_by_store) a.owner[c] = key;
-        else atomicMax(&a.owner[c], key);
-#else
-        if (key == 12345ull) a.owner[c] = key;
-#endif
+        // Claim: one 64-bit atomicMax (a plain store + a repair pass was measured: 70 + 38 µs against 105 µs, no gain)
+        atomicMax(&a.owner[c], die_claim(a.epoch, (int64_t)sid, dep));
         const float gained = consumed - action_cost(a, dx, dy, dep);
-#ifndef DIE_ABL_NOAF
         a.agent_food[n] += gained;
-#endif
         if (EXT) {                                     // ghost-agent tiles (compiled out of the single-tile kernel)
             if (!die_owned(g, cx, cy)) return 0.f;     // a ghost: the rank that owns this cell accounts for it
             ++owned_alive;
@@ -146,11 +131,8 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) void k_move_claim(StepArgs a) {
 
 // Agent.forward fused with the first half of Env.step: the action stays in registers between the two
 // (it is still written out for the caller, but never read back), x / y / slot are loaded once.
-#ifndef DIE_FMC_ATTR
-#define DIE_FMC_ATTR
-#endif
 template <typename T, int KIND, bool EXT = true>
-__global__ __launch_bounds__(DIE_STEP_BLOCK) DIE_FMC_ATTR void k_forward_move_claim(FwdArgs f, StepArgs a) {
+__global__ __launch_bounds__(DIE_STEP_BLOCK) void k_forward_move_claim(FwdArgs f, StepArgs a) {
     long long gsum = 0;
     long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -160,26 +142,10 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) DIE_FMC_ATTR void k_forward_move_cl
         const uint32_t X = a.x[n], Y = a.y[n];
         const FwdOut o = die_forward_agent<T, KIND, EXT>(f, X, Y, f.heading[n], sid, n);
         f.heading[n] = o.heading;
-#ifdef DIE_NT_ACTION
-        if (f.dx) { __builtin_nontemporal_store(o.dx, &f.dx[n]); __builtin_nontemporal_store(o.dy, &f.dy[n]); __builtin_nontemporal_store(o.dep, &f.dep[n]); }
-#elif !defined(DIE_ABL_NOACT)
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
-#endif
         gsum += die_fix(move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt));
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
-}
-
-// Second half of the claim: raise every cell's word to the maximum over its claimants.
-__global__ __launch_bounds__(DIE_STEP_BLOCK) void k_claim_fix(StepArgs a) {
-    const die_geo g = a.g;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
-        if (!a.alive[n]) continue;
-        const int64_t c = die_local(g, die_cell((int64_t)a.x[n], g.gW), die_cell((int64_t)a.y[n], g.gH));
-        const unsigned long long key = die_claim(a.epoch, a.slot ? (int64_t)a.slot[n] : n, a.dep[n]);
-        if (a.owner[c] < key) atomicMax(&a.owner[c], key);
-    }
 }
 
 template <typename T>
@@ -658,7 +624,6 @@ static int fill_args(StepArgs& k, const die_medium* m, const die_agents* a, cons
     k.boundary = d->boundary; k.cost = d->cost; k.food_infinite = d->food_infinite; k.agents_die = d->agents_die;
     k.has_dead = d->has_dead_slots || d->agents_die;
     k.skip_scatter = 0;
-    k.claim_by_store = getenv("DIE_STORE_CLAIM") ? 1 : 0;   // measured: store 70 µs + fix 38 µs vs atomic 105 µs — no gain
     char* w = (char*)ws;
     k.part_gain = nullptr;
     // ghost-agent tiles: num_alive is the number of alive slots on OWNED cells, counted by the claim pass
@@ -677,7 +642,6 @@ extern "C" int die_agent_move_claim(const die_medium* m, const die_agents* a, co
     const int grid = step_grid(a->N);
     if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_STEP_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_move_claim<__half><<<grid, DIE_STEP_BLOCK, 0, (hipStream_t)stream>>>(k);
-    if (k.claim_by_store) k_claim_fix<<<grid, DIE_STEP_BLOCK, 0, (hipStream_t)stream>>>(k);
     DIE_CHECK_LAUNCH("die_agent_move_claim");
     return DIE_OK;
 }
@@ -740,7 +704,6 @@ extern "C" int die_agent_claim_feed(const die_medium* m, const die_agents* a, co
     const int grid = step_grid(a->N);
     if (m->dtype == DIE_F32) k_move_claim<float><<<grid, DIE_STEP_BLOCK, 0, (hipStream_t)stream>>>(k);
     else k_move_claim<__half><<<grid, DIE_STEP_BLOCK, 0, (hipStream_t)stream>>>(k);
-    if (k.claim_by_store) k_claim_fix<<<grid, DIE_STEP_BLOCK, 0, (hipStream_t)stream>>>(k);
     DIE_CHECK_LAUNCH("die_agent_claim_feed");
     return DIE_OK;
 }
@@ -819,8 +782,7 @@ extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, co
 
 static bool fused_step_applies(const die_medium* m, const die_dynamics* d) {
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    return m->gW <= 0 && d->diffuse_mode == DIE_DIFFUSE_WRAP && rows_kernel_applies(m->W, m->H, R) && R >= 1 &&
-           !getenv("DIE_NO_FUSED_STEP");
+    return m->gW <= 0 && d->diffuse_mode == DIE_DIFFUSE_WRAP && rows_kernel_applies(m->W, m->H, R) && R >= 1 && !d->staged;
 }
 
 // everything of die_env_step after the claims are in place (fused path)
@@ -834,13 +796,11 @@ static int env_step_tail(const die_medium* m, const die_agents* a, const die_act
         if (rc != DIE_OK) return rc;
     }
     const int g = step_grid(a->N);
-    if (!second_pass && !getenv("DIE_NO_FUSED_REDUCE"))     // the sweep's first workgroup does the reduction (same summation order)
+    if (!second_pass)                                       // an extra workgroup of the sweep does the reduction (same summation order)
         return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed+reduce)", (const long long*)ws, g,
                                     result, a->N);
     k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const long long*)ws, g, (const long long*)ws + DIE_MAX_PARTIALS,
-                                                  second_pass ? g : 0,
-                                                  (const long long*)ws + 2 * DIE_MAX_PARTIALS,
-                                                  second_pass ? g : 0, result, second_pass ? -1 : a->N);
+                                                  g, (const long long*)ws + 2 * DIE_MAX_PARTIALS, g, result, -1);
     DIE_CHECK_LAUNCH("die_env_step(reduce)");
     return deposit_feed_diffuse(m, d, 0, false, stream, "die_env_step(diffuse+deposit+feed)");
 }
@@ -882,10 +842,7 @@ static int forward_move_claim(const die_medium* m, const die_agents* a, die_grad
     const int grid = step_grid(a->N);
     hipStream_t s = (hipStream_t)stream;
     // the sense-mask and ownership tests are compiled out of the plain single-tile kernel (they cost ≈ 5 % there)
-#ifndef DIE_FORCE_EXT
-#define DIE_FORCE_EXT 0
-#endif
-    const bool ext = DIE_FORCE_EXT || f.mask != nullptr || k.g.own_x1 > 0;
+    const bool ext = f.mask != nullptr || k.g.own_x1 > 0;
 #define DIE_FMC(T, KIND) do { if (ext) k_forward_move_claim<T, KIND, true><<<grid, DIE_STEP_BLOCK, 0, s>>>(f, k); \
                               else k_forward_move_claim<T, KIND, false><<<grid, DIE_STEP_BLOCK, 0, s>>>(f, k); } while (0)
     if (m->dtype == DIE_F32) {
@@ -896,7 +853,6 @@ static int forward_move_claim(const die_medium* m, const die_agents* a, die_grad
         else DIE_FMC(__half, DIE_AGENT_GRADIENT);
     }
 #undef DIE_FMC
-    if (k.claim_by_store) k_claim_fix<<<grid, DIE_STEP_BLOCK, 0, s>>>(k);
     DIE_CHECK_LAUNCH(who);
     return DIE_OK;
 }

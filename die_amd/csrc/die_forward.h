@@ -89,21 +89,13 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
     // np.gradient at the probe cell: central inside, one-sided at the four edges (gradient.py:57)
     const int xm = px > 0 ? px - 1 : 0, xp = px < W - 1 ? px + 1 : W - 1;
     const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;
-#ifdef DIE_ABL_NOGATHER
-    const float cxm = (float)xm, cxp = (float)xp * 1.5f, cym = (float)ym, cyp = (float)(yp + py);
-#else
     // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
     auto seen = [&](const T* p, const int64_t i) { return (EXT && a.mask && !a.mask[i]) ? 0.f : die_ld(p, i); };
     const float cxm = seen(chem, die_local(g, xm, py)), cxp = seen(chem, die_local(g, xp, py));
     const float cym = seen(chem, die_local(g, px, ym)), cyp = seen(chem, die_local(g, px, yp));
-#endif
     // food under the agent (gradient.py:114-116)
     const int cx = die_cell((int64_t)X, W), cy = die_cell((int64_t)Y, H);
-#ifdef DIE_ABL_NOFOOD
-    const float f_own = (float)(cx + cy);
-#else
     const float f_own = seen(food, die_local(g, cx, cy));
-#endif
     const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
     const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
     const float norm = sqrtf(gx * gx + gy * gy);

@@ -257,6 +257,8 @@ struct GhostIO {
     const int32_t* holes;            // apply
     const uint16_t* mask;            // apply: the plan's membership words (bit GH_MAXD = hole)
     int64_t n;                       // apply: local agents before the refresh
+    int64_t capacity;                // apply: entries every per-agent array holds; arrivals beyond it are dropped (the
+                                     // host sees n_new > capacity in the summary and raises)
     int64_t* n_new;                  // apply: device word, local agents afterwards
 };
 
@@ -292,6 +294,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_ghost_arrivals(GhostIO a) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
         const int64_t j = prefix + i;
         const int64_t dst = j < H ? (int64_t)a.holes[j] : a.n + (j - H);
+        if (dst >= a.capacity) continue;          // never write past the arrays: k_ghost_tail reports the unclamped count
         for (int f = 0; f < a.n_arr_arrays; ++f) {
             const int32_t v = rec[(int64_t)f * a.cap[k] + i];
             if (a.esz[f] == 4) ((int32_t*)a.arr[f])[dst] = v; else ((uint8_t*)a.arr[f])[dst] = (uint8_t)v;
@@ -369,7 +372,7 @@ extern "C" int die_ghost_pack(void* const* arrays, const int32_t* elem_bytes, in
     DIE_REQUIRE(lists && totals && send_buf, "die_ghost_pack: null argument");
     int64_t maxcap = 1;
     for (int i = 0; i < n_dirs; ++i) { k.lists[i] = lists[i]; DIE_REQUIRE(lists[i], "die_ghost_pack: null list %d", i); if (caps[i] > maxcap) maxcap = caps[i]; }
-    k.totals = totals; k.buf = (char*)send_buf; k.holes = nullptr; k.mask = nullptr; k.n = 0; k.n_new = nullptr;
+    k.totals = totals; k.buf = (char*)send_buf; k.holes = nullptr; k.mask = nullptr; k.n = 0; k.capacity = 0; k.n_new = nullptr;
     int64_t g = (maxcap + DIE_BLOCK - 1) / DIE_BLOCK;
     dim3 grid((unsigned)(g < 256 ? g : 256), (unsigned)n_dirs);
     k_ghost_pack<<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(k);
@@ -380,12 +383,14 @@ extern "C" int die_ghost_pack(void* const* arrays, const int32_t* elem_bytes, in
 extern "C" int die_ghost_apply(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs,
                                const int64_t* totals, const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off,
                                const void* recv_buf, const int32_t* holes, const void* plan_ws, int64_t n_local,
-                               int64_t* n_new_out, void* stream) {
+                               int64_t capacity, int64_t* n_new_out, void* stream) {
     GhostIO k;
     int rc = fill_io(k, arrays, elem_bytes, n_arrays, n_dirs, caps, hdr_off, rec_off, "die_ghost_apply");
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(totals && holes && plan_ws && n_new_out && (n_dirs == 0 || recv_buf) && n_local >= 0, "die_ghost_apply: null argument");
-    k.totals = totals; k.buf = (char*)recv_buf; k.holes = holes; k.mask = (const uint16_t*)plan_ws; k.n = n_local; k.n_new = n_new_out;
+    DIE_REQUIRE(capacity >= n_local, "die_ghost_apply: capacity %lld < %lld local agents", (long long)capacity, (long long)n_local);
+    k.totals = totals; k.buf = (char*)recv_buf; k.holes = holes; k.mask = (const uint16_t*)plan_ws; k.n = n_local; k.capacity = capacity;
+    k.n_new = n_new_out;
     hipStream_t s = (hipStream_t)stream;
     if (n_dirs > 0) {
         int64_t maxcap = 1;

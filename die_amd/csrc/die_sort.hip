@@ -10,9 +10,8 @@
 // attached in the same sweep: 4 launches, ≈ 60 µs at 2.5 M agents against ≈ 125–157 µs for hipCUB's LSD radix sort
 // of (key, index) pairs (two onesweep passes + five 5-µs memsets) followed by a gather pass.  The order INSIDE a
 // bucket is whatever order the waves reach the cursors in: nothing observable depends on it (results are keyed by
-// slot id, the reward is summed in fixed point).  DIE_SORT_RADIX=1 selects the radix path (cross-check).
+// slot id, the reward is summed in fixed point).
 #include "die_common.h"
-#include <hipcub/hipcub.hpp>
 
 #define DIE_SORT_MAX_EXTRA 4
 #ifndef DIE_SORT_XSHIFT
@@ -21,48 +20,6 @@
 #ifndef DIE_SORT_YSHIFT
 #define DIE_SORT_YSHIFT 5
 #endif
-
-__global__ __launch_bounds__(DIE_BLOCK) void k_sort_keys(die_geo g, int64_t N, const uint32_t* x, const uint32_t* y,
-                                                         int nby, uint32_t* key, uint32_t* val) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
-        // row / column inside the local planes (a decomposed tile: world cell − tile origin)
-        int ix = die_cell((int64_t)x[n], g.gW) - g.ox, iy = die_cell((int64_t)y[n], g.gH) - g.oy;
-        ix = ix < 0 ? 0 : (ix >= g.W ? g.W - 1 : ix);
-        iy = iy < 0 ? 0 : (iy >= g.H ? g.H - 1 : iy);
-        key[n] = (uint32_t)((ix >> DIE_SORT_XSHIFT) * nby + (iy >> DIE_SORT_YSHIFT));
-        val[n] = (uint32_t)n;
-    }
-}
-
-struct PermArgs {
-    int64_t N;
-    const uint32_t* idx;        // new position → old position
-    const uint32_t *x, *y, *slot;
-    const uint8_t* alive;
-    const float* agent_food;
-    uint32_t *ox, *oy, *oslot;
-    uint8_t* oalive;
-    float* oagent_food;
-    int n_extra;
-    const float* ein[DIE_SORT_MAX_EXTRA];
-    float* eout[DIE_SORT_MAX_EXTRA];
-};
-
-__global__ __launch_bounds__(DIE_BLOCK) void k_permute(PermArgs a) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < a.N; j += stride) {
-        const uint32_t s = a.idx[j];
-        a.ox[j] = a.x[s];
-        a.oy[j] = a.y[s];
-        a.oalive[j] = a.alive[s];
-        a.oagent_food[j] = a.agent_food[s];
-        a.oslot[j] = a.slot ? a.slot[s] : s;
-#pragma unroll
-        for (int e = 0; e < DIE_SORT_MAX_EXTRA; ++e)
-            if (e < a.n_extra) a.eout[e][j] = a.ein[e][s];
-    }
-}
 
 __device__ __forceinline__ uint32_t sort_key(const die_geo& g, uint32_t X, uint32_t Y, int nby) {
     int ix = die_cell((int64_t)X, g.gW) - g.ox, iy = die_cell((int64_t)Y, g.gH) - g.oy;
@@ -209,26 +166,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_sort_scatter(ScatterArgs a) {
 
 static int64_t n_buckets(int W, int H) { return (int64_t)((W >> DIE_SORT_XSHIFT) + 1) * ((H >> DIE_SORT_YSHIFT) + 1); }
 
-static int key_bits(int W, int H) {
-    const int64_t nb = (int64_t)((W >> DIE_SORT_XSHIFT) + 1) * ((H >> DIE_SORT_YSHIFT) + 1);
-    int b = 1;
-    while (((int64_t)1 << b) < nb) ++b;
-    return b;
-}
-
-static size_t cub_bytes(int64_t N, int bits) {
-    size_t bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (int)N, 0, bits, (hipStream_t)0);
-    return bytes;
-}
-
 extern "C" int64_t die_sort_workspace_bytes(int32_t W, int32_t H, int64_t N) {
     if (W < 1 || H < 1 || N < 1 || N >= ((int64_t)1 << 31)) return -1;
-    const int64_t arr = ((N * 4 + 255) & ~(int64_t)255);
-    const int64_t radix = 4 * arr + (int64_t)((cub_bytes(N, key_bits(W, H)) + 255) & ~(size_t)255);
-    const int64_t counting = 2 * ((((n_buckets(W, H) + 3) & ~(int64_t)3) * 4 + 255) & ~(int64_t)255);
-    return radix > counting ? radix : counting;
+    return 2 * ((((n_buckets(W, H) + 3) & ~(int64_t)3) * 4 + 255) & ~(int64_t)255);
 }
 
 extern "C" int die_agents_sort(const die_medium* m, const die_agents* in, const die_agents* out, int32_t n_extra,
@@ -244,7 +184,6 @@ extern "C" int die_agents_sort(const die_medium* m, const die_agents* in, const 
     const int64_t need = die_sort_workspace_bytes(m->W, m->H, in->N);
     DIE_REQUIRE(ws_bytes >= need, "die_agents_sort: workspace too small (%lld < %lld)", (long long)ws_bytes, (long long)need);
     const int64_t N = in->N;
-    const int64_t arr = ((N * 4 + 255) & ~(int64_t)255);
     char* w = (char*)ws;
     hipStream_t s = (hipStream_t)stream;
     int64_t g = (N + DIE_BLOCK - 1) / DIE_BLOCK;
@@ -255,51 +194,23 @@ extern "C" int die_agents_sort(const die_medium* m, const die_agents* in, const 
     const int nby = (m->H >> DIE_SORT_YSHIFT) + 1;
     for (int i = 0; i < n_extra; ++i)
         DIE_REQUIRE(extra_in[i] && extra_out[i] && extra_in[i] != extra_out[i], "die_agents_sort: bad attached array %d", i);
-    if (!getenv("DIE_SORT_RADIX")) {
-        const int64_t nb = n_buckets(m->W, m->H);
-        const int64_t nb4 = (nb + 3) & ~(int64_t)3;            // the scan reads 16 bytes at a time
-        uint32_t* hist = (uint32_t*)w;
-        uint32_t* cursor = (uint32_t*)(w + ((nb4 * 4 + 255) & ~(int64_t)255));
-        hipError_t e = hipMemsetAsync(hist, 0, (size_t)nb4 * 4, s);
-        if (e != hipSuccess) { die_set_error("die_agents_sort: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
-        k_sort_hist<<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), N, in->x, in->y, nby, hist);
-        const int per = (int)(((nb4 + 1023) / 1024 + 3) & ~3);
-        if (per <= SORT_SCAN_MAX_PER) k_sort_scan<<<1, 1024, 0, s>>>(hist, cursor, (int)nb4, per);
-        else k_sort_scan_big<<<1, 1024, 0, s>>>(hist, cursor, (int)nb4);
-        ScatterArgs q;
-        q.g = die_geo_of(m); q.N = N; q.nby = nby; q.cursor = cursor;
-        q.x = in->x; q.y = in->y; q.slot = in->slot; q.alive = in->alive; q.agent_food = in->agent_food;
-        q.ox = out->x; q.oy = out->y; q.oslot = out->slot; q.oalive = out->alive; q.oagent_food = out->agent_food;
-        q.n_extra = n_extra;
-        for (int i = 0; i < DIE_SORT_MAX_EXTRA; ++i) { q.ein[i] = i < n_extra ? extra_in[i] : nullptr; q.eout[i] = i < n_extra ? extra_out[i] : nullptr; }
-        k_sort_scatter<<<grid, DIE_BLOCK, 0, s>>>(q);
-        DIE_CHECK_LAUNCH("die_agents_sort");
-        return DIE_OK;
-    }
-    uint32_t* key_in = (uint32_t*)w;
-    uint32_t* key_out = (uint32_t*)(w + arr);
-    uint32_t* val_in = (uint32_t*)(w + 2 * arr);
-    uint32_t* val_out = (uint32_t*)(w + 3 * arr);
-    void* tmp = w + 4 * arr;
-    const int bits = key_bits(m->W, m->H);
-    size_t tmp_bytes = cub_bytes(N, bits);
-    k_sort_keys<<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), N, in->x, in->y, nby, key_in, val_in);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key_in, key_out, val_in, val_out, (int)N, 0, bits, s);
-    if (e != hipSuccess) {
-        die_set_error("die_agents_sort: radix sort failed: %s", hipGetErrorString(e));
-        return DIE_ERR_HIP;
-    }
-    PermArgs p;
-    p.N = N; p.idx = val_out;
-    p.x = in->x; p.y = in->y; p.slot = in->slot; p.alive = in->alive; p.agent_food = in->agent_food;
-    p.ox = out->x; p.oy = out->y; p.oslot = out->slot; p.oalive = out->alive; p.oagent_food = out->agent_food;
-    p.n_extra = n_extra;
-    for (int i = 0; i < DIE_SORT_MAX_EXTRA; ++i) {
-        p.ein[i] = i < n_extra ? extra_in[i] : nullptr;
-        p.eout[i] = i < n_extra ? extra_out[i] : nullptr;
-        DIE_REQUIRE(i >= n_extra || (p.ein[i] && p.eout[i] && p.ein[i] != p.eout[i]), "die_agents_sort: bad attached array %d", i);
-    }
-    k_permute<<<grid, DIE_BLOCK, 0, s>>>(p);
+    const int64_t nb = n_buckets(m->W, m->H);
+    const int64_t nb4 = (nb + 3) & ~(int64_t)3;            // the scan reads 16 bytes at a time
+    uint32_t* hist = (uint32_t*)w;
+    uint32_t* cursor = (uint32_t*)(w + ((nb4 * 4 + 255) & ~(int64_t)255));
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)nb4 * 4, s);
+    if (e != hipSuccess) { die_set_error("die_agents_sort: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
+    k_sort_hist<<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), N, in->x, in->y, nby, hist);
+    const int per = (int)(((nb4 + 1023) / 1024 + 3) & ~3);
+    if (per <= SORT_SCAN_MAX_PER) k_sort_scan<<<1, 1024, 0, s>>>(hist, cursor, (int)nb4, per);
+    else k_sort_scan_big<<<1, 1024, 0, s>>>(hist, cursor, (int)nb4);
+    ScatterArgs q;
+    q.g = die_geo_of(m); q.N = N; q.nby = nby; q.cursor = cursor;
+    q.x = in->x; q.y = in->y; q.slot = in->slot; q.alive = in->alive; q.agent_food = in->agent_food;
+    q.ox = out->x; q.oy = out->y; q.oslot = out->slot; q.oalive = out->alive; q.oagent_food = out->agent_food;
+    q.n_extra = n_extra;
+    for (int i = 0; i < DIE_SORT_MAX_EXTRA; ++i) { q.ein[i] = i < n_extra ? extra_in[i] : nullptr; q.eout[i] = i < n_extra ? extra_out[i] : nullptr; }
+    k_sort_scatter<<<grid, DIE_BLOCK, 0, s>>>(q);
     DIE_CHECK_LAUNCH("die_agents_sort");
     return DIE_OK;
 }

@@ -62,7 +62,7 @@ class DeviceMedium:
                            _ptr(self.sense_mask) if getattr(self, 'sense_mask', None) is not None else None)
 
     def next_epoch(self):
-        """Advance the ownership epoch; zero the plane when the 3-bit tag wraps."""
+        """Advance the ownership epoch; zero the plane when the 5-bit tag (1..31) wraps."""
         self.epoch += 1
         if self.epoch > _lib.OWNER_EPOCH_MAX:
             self.owner.zero_()

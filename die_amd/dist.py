@@ -775,7 +775,7 @@ class DistEnv:
             for arr, cnt in recv_r:
                 lib.check(lib.lib.die_rects_unpack(arr, cnt, rb, sp), 'die_rects_unpack')
         lib.check(lib.lib.die_ghost_apply(ptrs, esz, F, nd, _ptr(P.totals), P.c_caps, P.c_hdr, P.c_rec, _ptr(P.rbuf),
-                                          _ptr(P.lists[nd]), _ptr(P.ws), n, _ptr(P.n_new), sp), 'die_ghost_apply')
+                                          _ptr(P.lists[nd]), _ptr(P.ws), n, self.capacity, _ptr(P.n_new), sp), 'die_ghost_apply')
         self._tick('field unpack + arrivals + compaction')
         t = P.n_new.cpu().tolist()                                   # the one host read
         n_new, H, kept, sent, arrived = t[0], t[1], t[2], t[3:3 + nd], t[3 + nd:]

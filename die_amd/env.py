@@ -75,7 +75,7 @@ class Env(_EnvBase):
     def __init__(self, field_size: Tuple[int, int], dynamics: Optional[Dynamics] = None, *,
                  max_agents: Union[None, int, str] = None, seed: Optional[int] = None,
                  field_dtype: torch.dtype = torch.float32, device: Union[str, torch.device, None] = None,
-                 sync: bool = True, sort_every: int = 4):
+                 sync: bool = True, sort_every: int = 4, staged: bool = False):
         if not torch.cuda.is_available():
             raise RuntimeError('die_amd.Env needs a ROCm GPU (MI355X); there is no CPU path')
         self._field_size = (int(field_size[0]), int(field_size[1]))
@@ -85,6 +85,7 @@ class Env(_EnvBase):
         self._field_dtype = field_dtype
         self._sync = sync
         self._sort_every = int(sort_every)
+        self._staged = bool(staged)       # cross-checks: one kernel per stage of the step instead of the fused sweep
         self._seed = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
         self._renderer = None
         self.last_result = None
@@ -114,6 +115,8 @@ class Env(_EnvBase):
         self._steps = 0
         self._shadow = None
         self._sort_ws = None
+        if self._sort_every > 0:            # the re-sort's shadow arrays and workspace exist before the first step, so that
+            self._alloc_sort_buffers()      # no step of a timed loop pays for allocations
         self._fuse_forward = True           # False once die_forward_env_step reports the shape unsupported
         self.medium.sense_mask = None
         if self.dynamics.apply_sense_mask:
@@ -144,6 +147,7 @@ class Env(_EnvBase):
         env._field_dtype = kw.get('field_dtype', torch.float32)
         env._sync = kw.get('sync', True)
         env._sort_every = int(kw.get('sort_every', 4))
+        env._staged = bool(kw.get('staged', False))
         env._seed = int(kw.get('seed', 0))
         env._renderer = None
         env.last_result = None
@@ -175,7 +179,8 @@ class Env(_EnvBase):
             boundary = _lib.DIE_BOUNDARY_NONE
         cost = _lib.DIE_COST_LINEAR if d.op_action_cost is linear_action_cost else _lib.DIE_COST_ZERO
         return _lib.Dynamics(d.rate_feed, d.rate_decay_chem, d.diffuse_sigma, boundary, cost, 0.02, 0.01,
-                             int(d.food_infinite), int(d.agents_die), int(not self._all_alive), _lib.DIFFUSE_MODES[d.diffuse_mode])
+                             int(d.food_infinite), int(d.agents_die), int(not self._all_alive), _lib.DIFFUSE_MODES[d.diffuse_mode],
+                             int(self._staged))
 
     def _as_action(self, action) -> DeviceAction:
         if isinstance(action, DeviceAction):
@@ -353,16 +358,20 @@ class Env(_EnvBase):
         food = self.medium.food.to(torch.float64).cpu().numpy()
         self.medium.upload_channel('env_food', np.asarray(self.dynamics.op_food_flow(food)))
 
+    def _alloc_sort_buffers(self):
+        A = self.agents
+        self._shadow = [torch.empty_like(t) for t in (A.x, A.y, A.alive, A.agent_food)] + \
+                       [torch.empty(A.N, dtype=torch.int32, device=self.device)]
+        n = _lib.lib.die_sort_workspace_bytes(self.medium.W, self.medium.H, A.N)
+        self._sort_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+
     def sort_agents(self):
         """Re-order the agent arrays so that array neighbours are grid neighbours (die_agents_sort).
         Invisible to callers: slot ids travel with the agents, attached Agent objects have their
         per-slot state permuted alongside."""
         A = self.agents
         if self._shadow is None:
-            self._shadow = [torch.empty_like(t) for t in (A.x, A.y, A.alive, A.agent_food)] + \
-                           [torch.empty(A.N, dtype=torch.int32, device=self.device)]
-            n = _lib.lib.die_sort_workspace_bytes(self.medium.W, self.medium.H, A.N)
-            self._sort_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+            self._alloc_sort_buffers()
         ox, oy, oalive, ofood, oslot = self._shadow
         owners, tensors = [], []
         for obj in A.attached():

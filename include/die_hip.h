@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 12
+#define DIE_ABI_VERSION 13
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -123,6 +123,8 @@ typedef struct die_dynamics {
     int32_t agents_die;
     int32_t has_dead_slots;  /* 0: caller guarantees every slot is alive (skips the dead-slot feed pass) */
     int32_t diffuse_mode;    /* die_diffuse_mode (Dynamics.diffuse_mode, core/env.py:49,142); only WRAP takes the fused sweep */
+    int32_t staged;          /* 1: die_env_step runs its stages one kernel each (move/claim, resolve, reduce, diffuse) even where
+                                the fused field sweep applies — same bits, for cross-checks (tests) */
 } die_dynamics;
 
 /* core/agent/gradient.py:19-28,139-151 constructor arguments + per-agent state. */
@@ -356,14 +358,15 @@ int die_records_scatter_at(void* const* arrays, const int32_t* elem_bytes, int32
  * and header from the plan's lists / totals in ONE launch.  die_ghost_apply consumes a received buffer: arrival j (sides
  * in order) overwrites holes[j], or is appended behind n_local once the holes are used up; with fewer arrivals than
  * holes the kept entries of the cut tail move into the remaining holes (plan_ws = the workspace die_ghost_plan wrote
- * its membership words to).  All counts are read on the device; n_new_out (3 + 2 * n_dirs words) receives what the host
+ * its membership words to).  `capacity` = entries each array holds: an arrival that would land at or beyond it is dropped,
+ * never written (n_new_out[0] still reports the unclamped count, so the caller sees the overflow).  All counts are read on the device; n_new_out (3 + 2 * n_dirs words) receives what the host
  * wants afterwards: [new number of local agents, holes, owned, sent per side…, arrived per side… (raw headers)]. */
 int die_ghost_pack(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs, int32_t* const* lists,
                    const int64_t* totals, const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off, void* send_buf,
                    void* stream);
 int die_ghost_apply(void* const* arrays, const int32_t* elem_bytes, int32_t n_arrays, int32_t n_dirs, const int64_t* totals,
                     const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off, const void* recv_buf,
-                    const int32_t* holes, const void* plan_ws, int64_t n_local, int64_t* n_new_out, void* stream);
+                    const int32_t* holes, const void* plan_ws, int64_t n_local, int64_t capacity, int64_t* n_new_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -105,9 +105,9 @@ def fuzz_paths(n_cases=100, seed=0, verbose=True):
         phys = rs.rand() < 0.7
         turn = np.radians(30); dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn); prev = f32(rs.normal(0, .4, (2, N)))
         outs = []
-        for variant in ('default', 'DIE_NO_FUSED_STEP', 'DIE_STORE_CLAIM', 'eager', 'sorted'):
-            if variant.startswith('DIE_'): os.environ[variant] = '1'
-            env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=1 if variant == 'sorted' else 0)
+        for variant in ('default', 'staged', 'eager', 'sorted'):
+            env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=1 if variant == 'sorted' else 0,
+                                         staged=variant == 'staged')
             if phys: ag = die_amd.PhysarumAgent(max_agents=N, seed=3, scale=2.0 / max(W, H), sense_offset=0.05)
             else: ag = die_amd.GradientAgent(max_agents=N, seed=3, scale=0.01, sense_offset=0.03, inertia=0.8, noise_scale=0.02)
             ag.set_state(dir0, None if phys else prev)
@@ -116,8 +116,7 @@ def fuzz_paths(n_cases=100, seed=0, verbose=True):
             for _ in range(4):
                 obs, *_ = env.step(ag.forward(obs))
             outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy()))
-            if variant.startswith('DIE_'): del os.environ[variant]
-        for v, o in zip(('staged', 'store-claim', 'eager', 'sorted'), outs[1:]):
+        for v, o in zip(('staged', 'eager', 'sorted'), outs[1:]):
             for a, b in zip(outs[0], o):
                 if not np.array_equal(a, b):
                     fails += 1; print(f'CASE {case} variant {v} differs: W={W} H={H} N={N} K={K} phys={phys} dyn={dyn}', flush=True); break

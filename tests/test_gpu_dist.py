@@ -221,3 +221,89 @@ def test_decomposed_regressions(tmp_path, case):
         obs, *_ = env.step(ag.forward(obs))
     assert np.array_equal(got['agents'], env.agents.to_numpy())
     assert np.array_equal(got['medium'], env.medium.to_numpy())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] at FULL size: an 8192² world over 2×2 ranks (sharing the test box's one GPU, gloo), ghost-agent
+# mode with the bench's refresh period.  State travels through files (the in-memory gather of the small cases would
+# pickle gigabytes): the single-device run writes the initial world, every rank writes its interior tile and owned agents.
+def _full_worker(rank, size, port, grid, W, H, steps, sort_every, refresh_every, tmp):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=size)
+    try:
+        import die_amd
+        from die_amd.dist import DistEnv
+        medium = np.load(os.path.join(tmp, 'medium.npy'), mmap_mode='r')
+        agents = np.load(os.path.join(tmp, 'agents.npy'), mmap_mode='r')
+        dir0 = np.load(os.path.join(tmp, 'dir0.npy'))
+        env = DistEnv.from_global_numpy(medium, agents, grid, None, probe_reach=11, device='cuda:0', sort_every=sort_every,
+                                        overlap=False, migrate_every=refresh_every, max_step_cells=1.6, ghosts=True,
+                                        ghost_headroom=1.3)
+        del medium, agents
+        agent = die_amd.PhysarumAgent(max_agents=env.capacity, seed=3, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        local = torch.zeros(env.capacity, dtype=torch.float32, device='cuda:0')
+        local[:env.agents.N] = torch.from_numpy(dir0).cuda()[env.local_slots()]
+        agent.set_state_local(env.agents, local)
+        obs = env._get_current_obs
+        rewards = []
+        for _ in range(steps):
+            obs, res = env.step(agent.forward(obs))
+            rewards.append(env.read_result(res))
+        g, A, n = env.geo, env.agents, env.agents.N
+        ri, ci = g.interior()
+        own = env.owned_mask()
+        np.savez(os.path.join(tmp, f'rank{rank}.npz'), x0=g.x0, y0=g.y0,
+                 occ=env.medium.occupied()[ri, ci].cpu().numpy(), food=env.medium.food[ri, ci].cpu().numpy(),
+                 chem=env.medium.chem[ri, ci].cpu().numpy(), slots=A.slot[:n][own].cpu().numpy(),
+                 x=A.x[:n][own].cpu().numpy(), y=A.y[:n][own].cpu().numpy(), alive=A.alive[:n][own].cpu().numpy(),
+                 agent_food=A.agent_food[:n][own].cpu().numpy(), rewards=np.array(rewards))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_configs3_8192_world_2x2_ranks_equals_single_device(tmp_path):
+    """8192×8192 Physarum world, 2×2 domain decomposition (four ranks on the one GPU, gloo), ghost agents re-seated every
+    8 steps, 10 steps: the gathered world equals the single-device 8192² run bit for bit, and that run satisfies the
+    size-independent invariants of the 4096² test."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    import die_amd
+    from die_amd.device_array import unpermute
+    from tests.test_gpu_parity import check_step_invariants
+    W = H = 8192
+    steps, tmp = 10, str(tmp_path)
+    env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=0.15), seed=77, max_agents='alive', sort_every=8)
+    K = env.agents.N
+    assert abs(K / (W * H) - 0.15) < 0.002
+    agent = die_amd.PhysarumAgent(max_agents=K, seed=3, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    agent._alloc_state('cuda:0')
+    np.save(os.path.join(tmp, 'medium.npy'), env.medium.to_numpy().astype(np.float32))
+    np.save(os.path.join(tmp, 'agents.npy'), env.agents.to_numpy())
+    np.save(os.path.join(tmp, 'dir0.npy'), agent._direction_rads.cpu().numpy())
+    rewards = check_step_invariants(env, agent, steps, W, H, 1.53 / (W - 1))
+    want = dict(occ=env.medium.occupied().cpu().numpy(), food=env.medium.food.cpu().numpy(), chem=env.medium.chem.cpu().numpy(),
+                x=unpermute(env.agents.x, env.agents.slot).cpu().numpy(), y=unpermute(env.agents.y, env.agents.slot).cpu().numpy(),
+                agent_food=unpermute(env.agents.agent_food, env.agents.slot).cpu().numpy())
+    del env, agent
+    torch.cuda.empty_cache()
+
+    grid = (2, 2)
+    mp.spawn(_full_worker, args=(4, _free_port(), grid, W, H, steps, 8, 8, tmp), nprocs=4, join=True)
+    seen = np.zeros(K, dtype=bool)
+    for r in range(4):
+        got = np.load(os.path.join(tmp, f'rank{r}.npz'))
+        x0, y0 = int(got['x0']), int(got['y0'])
+        Wi, Hi = got['chem'].shape
+        for name in ('occ', 'food', 'chem'):
+            assert np.array_equal(got[name], want[name][x0:x0 + Wi, y0:y0 + Hi]), f'rank {r}: {name}'
+        sl = got['slots'].astype(np.int64)
+        assert not seen[sl].any()
+        seen[sl] = True
+        assert got['alive'].all()
+        for name in ('x', 'y', 'agent_food'):
+            assert np.array_equal(got[name], want[name][sl]), f'rank {r}: agents {name}'
+        assert np.array_equal(got['rewards'], np.array(rewards))     # every rank holds the all-reduced world result
+    assert seen.all()                                                # every world agent has exactly one owner

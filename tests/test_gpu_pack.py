@@ -203,7 +203,7 @@ def test_ghost_pack_and_apply_against_numpy(lib, counts):
     n_new = torch.zeros(3 + 2 * nd, dtype=torch.int64, device='cuda')
     lib.check(lib.lib.die_ghost_apply(dptr, esz, F, nd, C.c_void_p(rtot.data_ptr()), c64(caps), c64(hdr), c64(rec),
                                       C.c_void_p(buf.data_ptr()), C.c_void_p(holes.data_ptr()), C.c_void_p(ws.data_ptr()), n,
-                                      C.c_void_p(n_new.data_ptr()), _sp()), 'die_ghost_apply')
+                                      n + 1000, C.c_void_p(n_new.data_ptr()), _sp()), 'die_ghost_apply')
     n_arr = sum(counts)
     arrivals = np.concatenate(sent, axis=1)                        # (F, n_arr) in side order
     want = [b.copy() for b in before]
@@ -225,3 +225,48 @@ def test_ghost_pack_and_apply_against_numpy(lib, counts):
     assert n_new.cpu().tolist() == [exp_n, H, n - H, 0, 0, 0] + list(counts)
     for f in range(F):
         assert np.array_equal(dst[f].cpu().numpy()[:exp_n], want[f][:exp_n]), f'array {f}'
+
+
+def test_ghost_apply_never_writes_past_the_capacity(lib):
+    """More arrivals than holes + free capacity: the surplus is dropped, not written past the arrays, and the summary
+    still carries the unclamped count so that the caller raises (DistEnv._refresh_ghosts_native)."""
+    rs = np.random.RandomState(3)
+    n, nd, caps, F = 500, 2, [400, 400], 3
+    cap_arrays = n + 100                                           # 800 arrivals, 10 holes, room for 100
+    src, sptr, esz = _arrays(1000, rs)
+    lists = [torch.from_numpy(rs.permutation(1000)[:400].astype(np.int32)).cuda() for _ in range(nd)]
+    totals = torch.tensor([400, 400, 0, 0], dtype=torch.int64, device='cuda')
+    off, hdr, rec = 0, [], []
+    for k in range(nd):
+        hdr.append(off); rec.append(off + 16); off += 16 + F * caps[k] * 4
+    buf = torch.zeros(off, dtype=torch.uint8, device='cuda')
+    c64 = lambda v: (C.c_int64 * len(v))(*v)
+    lp = (C.c_void_p * nd)(*[t.data_ptr() for t in lists])
+    lib.check(lib.lib.die_ghost_pack(sptr, esz, F, nd, lp, C.c_void_p(totals.data_ptr()), c64(caps), c64(hdr), c64(rec),
+                                     C.c_void_p(buf.data_ptr()), _sp()), 'die_ghost_pack')
+    # receiver arrays of cap_arrays entries followed by a guard region that must stay untouched
+    guard = 2000
+    dst = [torch.full((cap_arrays + guard,), 0x5A5A5A5A, dtype=torch.int32, device='cuda'),
+           torch.full((cap_arrays + guard,), 0x5A5A5A5A, dtype=torch.int32, device='cuda'),
+           torch.full((cap_arrays + guard,), 0x5A, dtype=torch.uint8, device='cuda')]
+    dptr = (C.c_void_p * F)(*[t.data_ptr() for t in dst])
+    H = 10
+    holes_np = np.arange(0, 10 * H, 10, dtype=np.int32)
+    holes = torch.from_numpy(holes_np).cuda()
+    mask = np.full(n, 1 << 9, dtype=np.uint16); mask[holes_np] = 1 << 8
+    ws = torch.from_numpy(mask.view(np.uint8)).cuda()
+    rtot = torch.tensor([0, 0, H, n - H], dtype=torch.int64, device='cuda')
+    n_new = torch.zeros(3 + 2 * nd, dtype=torch.int64, device='cuda')
+    lib.check(lib.lib.die_ghost_apply(dptr, esz, F, nd, C.c_void_p(rtot.data_ptr()), c64(caps), c64(hdr), c64(rec),
+                                      C.c_void_p(buf.data_ptr()), C.c_void_p(holes.data_ptr()), C.c_void_p(ws.data_ptr()), n,
+                                      cap_arrays, C.c_void_p(n_new.data_ptr()), _sp()), 'die_ghost_apply')
+    torch.cuda.synchronize()
+    assert int(n_new[0]) == n + 800 - H > cap_arrays               # the caller's `n_new > capacity` check fires
+    for t in dst:
+        g = t[cap_arrays:].cpu().numpy()
+        assert (g == (0x5A if t.dtype == torch.uint8 else 0x5A5A5A5A)).all(), 'wrote past the capacity'
+    # a capacity below the current count is refused up front
+    rc = lib.lib.die_ghost_apply(dptr, esz, F, nd, C.c_void_p(rtot.data_ptr()), c64(caps), c64(hdr), c64(rec),
+                                 C.c_void_p(buf.data_ptr()), C.c_void_p(holes.data_ptr()), C.c_void_p(ws.data_ptr()), n,
+                                 n - 1, C.c_void_p(n_new.data_ptr()), _sp())
+    assert rc == -1
