@@ -68,6 +68,9 @@ def parse():
     p.add_argument('--dist-mode', choices=['ghost', 'guard'], default='ghost',
                    help='decomposed runs: ghost = communication-avoiding (ghost agents, nothing crosses ranks for M steps); '
                         'guard = claims merged and halos exchanged every step, strays handed over every M steps')
+    p.add_argument('--no-pic', action='store_true', help='classic step (claim plane + bucket sort) instead of the tile-binned one')
+    p.add_argument('--pic-tile', default='', help='tuning: log2 tile shape of the tile-binned step, e.g. 6,6')
+    p.add_argument('--pic-threads', type=int, default=0, help='tuning: workgroup size of the tile-binned agent kernel')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
@@ -82,6 +85,10 @@ def algorithmic_bytes(C, K):
         'k_gradient_forward': 48 * K,     # stand-alone forward: x,y,heading R 12 + heading W 4 + action W 12 + 5 gathers 20
         'k_move_claim': 44 * K,           # stand-alone: x,y RW 16 + agent_food RW 8 + action R 12 + food gather 4 + claim 4
         'k_diffuse_rows_fused': 8 * C + 20 * K,   # chem R + W per cell; per agent chem RMW 8 + food RMW 8 + mark 4
+        # tile-binned step: the same contract split over its three launches (the claim of the contract is K2's)
+        'k_pic_forward_move': 68 * K,     # state R+W 32, action W 12, 6 gathers 24
+        'k_pic_resolve': 4 * K,           # the ownership claim
+        'k_diffuse_rows_dep': 8 * C + 20 * K,
         'step': 12 * C + 104 * K,
     }
 
@@ -89,20 +96,23 @@ def algorithmic_bytes(C, K):
 PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false>',
-             'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, true, true>'}
+             'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
+             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true>', 'k_pic_resolve': 'void k_pic_resolve<6, 6>',
+             'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
+WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve')
 
 
 def pmc_traffic(kernel):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (profiles/README.md): (FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE under-counts wide coalesced streams by 2x on gfx950
-    (applied to the diffusion sweep only).  The file carries the sha of the kernel sources it was taken from: when the
+    (applied to the kernels whose reads are 16-byte-per-lane streams: the sweep and the tile-binned kernels).  The file carries the sha of the kernel sources it was taken from: when the
     sources have changed since, the figure would be stale and is reported as null."""
     try:
         doc = json.load(open(PMC_FILE))
         if doc.get('kernel_source_sha') != kernel_source_sha():
             return None, f'{os.path.relpath(PMC_FILE, ROOT)} was taken from another build of the kernels (sha {doc.get("kernel_source_sha")}): not reported'
         c = doc[PMC_NAMES[kernel]]
-        fetch = c['FETCH_SIZE'] * (2 if kernel == 'k_diffuse_rows_fused' else 1)
+        fetch = c['FETCH_SIZE'] * (2 if kernel in WIDE_STREAM_KERNELS else 1)
         return int((fetch + c['WRITE_SIZE']) * 1024), (f'{os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command, '
                                                       f'kernel sources sha {doc["kernel_source_sha"]})')
     except Exception as e:
@@ -130,13 +140,28 @@ def time_kernels(env, agent, reps):
             torch.cuda.synchronize()
         return sum(a.elapsed_time(b) for a, b in ev) / reps * 1e3
 
-    env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
-    obs = env._get_current_obs
-    sort_every, env._sort_every = env._sort_every, 0
-
     import ctypes as C
     from die_amd.device_array import _ptr, stream_ptr
 
+    if env._pic is not None and env._pic.held is not None and env._pic.held[0] is env.agents.x:
+        # tile-binned step: REAL steps whose three launches are issued one call each (die_pic.stages) with a HIP event
+        # between them — every kernel meets the cache state it meets in the timed loop
+        names = ('k_pic_forward_move', 'k_pic_resolve', 'k_diffuse_rows_dep')
+        n = max(reps, 20)
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+        o = env._get_current_obs
+        for e in evs:
+            env._pic_events = e
+            o, *_ = env.step(agent.forward(o))
+        env._pic_events = None
+        torch.cuda.synchronize()
+        for k, name in enumerate(names):
+            out[name] = sum(e[k].elapsed_time(e[k + 1]) for e in evs) / n * 1e3
+        return out
+
+    env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
+    obs = env._get_current_obs
+    sort_every, env._sort_every = env._sort_every, 0
     calls = [0]
 
     def front_prep():                     # host work of one fused forward + move/claim launch
@@ -269,8 +294,11 @@ def main():
     else:
         env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed,
                           max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
-                          field_dtype=torch.float16 if args.fields == 'f16' else torch.float32)
+                          field_dtype=torch.float16 if args.fields == 'f16' else torch.float32, pic=not args.no_pic)
         agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **agent_kw)
+        if args.pic_tile:
+            env._pic_tile = tuple(int(v) for v in args.pic_tile.split(','))
+        env._pic_k1_threads = args.pic_threads
 
     def barrier():
         if dist_on:

@@ -54,6 +54,17 @@ class GradientAgent(C.Structure):
                 ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32), ('step_base', C.c_void_p)]
 
 
+class PicLayout(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('agent_food', C.c_void_p), ('slot', C.c_void_p), ('heading', C.c_void_p),
+                ('off', C.c_void_p), ('n', C.c_void_p), ('s', C.c_void_p), ('inc', C.c_void_p)]
+
+
+class Pic(C.Structure):
+    _fields_ = [('tile_xs', C.c_int32), ('tile_ys', C.c_int32), ('N', C.c_int64), ('layout', PicLayout * 2),
+                ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
+                ('k1_threads', C.c_int32), ('stages', C.c_int32)]
+
+
 class Rect(C.Structure):
     _fields_ = [('plane', C.c_void_p), ('pitch', C.c_int32), ('r0', C.c_int32), ('r1', C.c_int32), ('c0', C.c_int32),
                 ('c1', C.c_int32), ('elem_bytes', C.c_int32), ('buf_offset', C.c_int64)]
@@ -130,6 +141,11 @@ _SIGNATURES = {
                                  _P(C.c_int64), _P(C.c_int64), C.c_void_p, C.c_void_p]),
     'die_ghost_apply': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, _P(C.c_int64), _P(C.c_int64),
                                   _P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
+    'die_pic_tiles': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'die_pic_bin': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
+    'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
+                                           C.c_void_p]),
+    'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
                                   C.c_int64, C.c_void_p]),

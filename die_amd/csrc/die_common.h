@@ -50,7 +50,13 @@ __device__ __forceinline__ int die_cell(int64_t P, int n) {
 }
 
 // float displacement (fraction of the unit square) → Q0.32 increment
-__device__ __forceinline__ int64_t die_q32(float v) { return (int64_t)__double2ll_rn((double)v * 4294967296.0); }
+// v·2^32 is exact in fp32 (a power-of-two scaling), so below 2^31 the nearest integer comes from the 32-bit convert;
+// larger displacements take the float64 route.  Same value either way.
+__device__ __forceinline__ int64_t die_q32(float v) {
+    const float t = v * 4294967296.0f;
+    if (fabsf(t) < 2147483520.0f) return (int64_t)__float2int_rn(t);
+    return (int64_t)__double2ll_rn((double)v * 4294967296.0);
+}
 
 __device__ __forceinline__ uint32_t die_owner_word(int epoch, int64_t slot) {
     return ((uint32_t)epoch << DIE_OWNER_EPOCH_SHIFT) | (uint32_t)(slot + 1);
@@ -66,6 +72,19 @@ __device__ __forceinline__ bool die_claim_occupied(unsigned long long k, int epo
     return (uint32_t)(k >> (32 + DIE_OWNER_EPOCH_SHIFT)) == (uint32_t)epoch;
 }
 __device__ __forceinline__ float die_claim_deposit(unsigned long long k) { return __uint_as_float((uint32_t)k); }
+
+// The reward is accumulated in 32.32 fixed point: integer sums are associative, so reward does not depend on the order
+// of the agent arrays, on the grid size or on the decomposition — bit for bit (a slot's gain is rounded to 2^-32 ≈
+// 2.3e-10 once; the float64 sum it replaces differed by rounding noise between orders).
+#define DIE_FIX_ONE 4294967296.0
+__device__ __forceinline__ long long die_fix(float g) {
+    const float t = g * 4294967296.0f;                       // exact (power-of-two scaling)
+    if (fabsf(t) < 2147483520.0f) return (long long)__float2int_rn(t);
+    return __double2ll_rn((double)g * DIE_FIX_ONE);
+}
+
+// "no agent on this cell" in the deposit plane of the tile-binned step (a NaN no deposit can carry)
+#define DIE_DEP_EMPTY 0xFFFFFFFFu
 
 // ---- tile geometry (die_medium.gW/gH/ox/oy) ----------------------------------------------------
 struct die_geo {
@@ -117,3 +136,37 @@ __device__ __forceinline__ long long die_wave_sum(long long v) {
     for (int o = DIE_WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, DIE_WAVE);
     return v;
 }
+
+// Groups the active lanes of the wave by key (no memory traffic), then every group's first lane issues ONE atomicAdd of
+// the group's size — all of a wave's atomics are in flight together — and the lanes get base + rank inside the group
+// (lane order): a unique slot of the bucket's range when `counter` is a cursor.  RETURNING = false: histogram only.
+template <bool RETURNING>
+__device__ __forceinline__ uint32_t wave_grouped_add(uint32_t* counter, uint32_t key, bool active) {
+    const int lane = threadIdx.x & (DIE_WAVE - 1);
+    int my_lead = lane;
+    uint32_t my_rank = 0, my_count = 0;
+    bool todo = active;
+    unsigned long long pending = __ballot(todo);
+    while (pending) {
+        const int lead = __ffsll((long long)pending) - 1;
+        const uint32_t kk = __shfl(key, lead, DIE_WAVE);
+        const bool match = todo && key == kk;
+        const unsigned long long mask = __ballot(match);
+        if (match) {
+            my_lead = lead;
+            my_rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (lane == lead) my_count = (uint32_t)__popcll(mask);
+            todo = false;
+        }
+        pending &= ~mask;
+    }
+    uint32_t base = 0;
+    if (active && lane == my_lead) {
+        if (RETURNING) base = atomicAdd(&counter[key], my_count);
+        else atomicAdd(&counter[key], my_count);
+    }
+    if (!RETURNING) return 0;
+    base = __shfl(base, my_lead, DIE_WAVE);
+    return base + my_rank;
+}
+

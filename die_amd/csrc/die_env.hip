@@ -56,12 +56,6 @@ __device__ __forceinline__ float action_cost(const StepArgs& a, float dx, float 
     return a.cost == DIE_COST_LINEAR ? a.w_dep * fabsf(dep) + a.w_dist * sqrtf(dx * dx + dy * dy) : 0.f;
 }
 
-// The reward is accumulated in 32.32 fixed point: integer sums are associative, so reward does not depend on the order
-// of the agent arrays, on the grid size or on the decomposition — bit for bit (a slot's gain is rounded to 2^-32 ≈
-// 2.3e-10 once; the float64 sum it replaces differed by rounding noise between orders).
-#define DIE_FIX_ONE 4294967296.0
-__device__ __forceinline__ long long die_fix(float g) { return __double2ll_rn((double)g * DIE_FIX_ONE); }
-
 __device__ __forceinline__ void block_sum_store(long long g, long long c, long long* pg, long long* pc) {
     __shared__ long long sg[DIE_STEP_BLOCK / DIE_WAVE];
     __shared__ long long sc[DIE_STEP_BLOCK / DIE_WAVE];
@@ -306,7 +300,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
 struct RowsArgs {
     const void* src;
     void* dst;
-    const unsigned long long* claim;   // FUSED only
+    const unsigned long long* claim;   // FUSED == 1: the 64-bit claim plane
+    const float* dep;                  // FUSED == 2: per cell the winner's deposit, or DIE_DEP_EMPTY (tile-binned step, die_pic.hip)
     void* food;                        // FUSED only
     int W, H, epoch, food_infinite;
     int halo;                          // tile mode: cells within `halo` of the array border belong to neighbours
@@ -340,7 +335,7 @@ template <> struct Vec4<__half> {
     }
 };
 
-template <typename T, int R, bool FUSED, bool WRAP>
+template <typename T, int R, int FUSED, bool WRAP>
 __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     static_assert(R >= 1 && R <= 4, "one halo lane of 4 columns per side");
     if (FUSED && a.result && blockIdx.y == gridDim.y - 1) {
@@ -413,15 +408,26 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
         const int64_t off = (int64_t)r * H + col;
         Vec4<T>::ld(src + off, v);
         if (FUSED) {
-            const ulonglong2 c01 = *(const ulonglong2*)(a.claim + off), c23 = *(const ulonglong2*)(a.claim + off + 2);
-            const unsigned long long c[4] = {c01.x, c01.y, c23.x, c23.y};
             bool occ[4];
             bool any = false;
+            if (FUSED == 1) {
+                const ulonglong2 c01 = *(const ulonglong2*)(a.claim + off), c23 = *(const ulonglong2*)(a.claim + off + 2);
+                const unsigned long long c[4] = {c01.x, c01.y, c23.x, c23.y};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                occ[j] = die_claim_occupied(c[j], a.epoch);
-                if (occ[j]) v[j] += die_claim_deposit(c[j]);     // chem[cell] + deposit of the last writer
-                any |= occ[j];
+                for (int j = 0; j < 4; ++j) {
+                    occ[j] = die_claim_occupied(c[j], a.epoch);
+                    if (occ[j]) v[j] += die_claim_deposit(c[j]);     // chem[cell] + deposit of the last writer
+                    any |= occ[j];
+                }
+            } else {
+                const uint4 d4 = *(const uint4*)(a.dep + off);
+                const uint32_t d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    occ[j] = d[j] != DIE_DEP_EMPTY;
+                    if (occ[j]) v[j] += __uint_as_float(d[j]);
+                    any |= occ[j];
+                }
             }
             // feeding: this wave owns rows [x0, x0+rows) × its output lanes (tile mode: interior cells only)
             const bool own_row = i >= 0 && i < rows && r >= hx && r < W - hx;
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     }
 }
 
-template <typename T, bool FUSED, bool WRAP = true>
+template <typename T, int FUSED, bool WRAP = true>
 static int launch_rows(const RowsArgs& a, int R, hipStream_t s) {
     const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
     constexpr int WPB = DIF_BLOCK / DIE_WAVE;
@@ -540,12 +546,12 @@ static int diffuse_decay_mode(const void* src, void* dst, int32_t W, int32_t H, 
         RowsArgs ra;
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
-        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.dep = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
         ra.wrapx = ra.wrapy = 1; ra.part_gain = nullptr; ra.part_alive = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
         ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
         for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
-        int rc2 = dtype == DIE_F32 ? launch_rows<float, false>(ra, R, (hipStream_t)stream)
-                                   : launch_rows<__half, false>(ra, R, (hipStream_t)stream);
+        int rc2 = dtype == DIE_F32 ? launch_rows<float, 0>(ra, R, (hipStream_t)stream)
+                                   : launch_rows<__half, 0>(ra, R, (hipStream_t)stream);
         if (rc2 != DIE_OK) return rc2;
         DIE_CHECK_LAUNCH("die_diffuse_decay");
         return DIE_OK;
@@ -721,12 +727,12 @@ extern "C" int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int
     RowsArgs ra;
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(sigma, wd);
-    ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+    ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.dep = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
     ra.wrapx = ra.wrapy = 0; ra.part_gain = nullptr; ra.part_alive = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
     ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
-    int rc = dtype == DIE_F32 ? launch_rows<float, false, false>(ra, R, (hipStream_t)stream)
-                              : launch_rows<__half, false, false>(ra, R, (hipStream_t)stream);
+    int rc = dtype == DIE_F32 ? launch_rows<float, 0, false>(ra, R, (hipStream_t)stream)
+                              : launch_rows<__half, 0, false>(ra, R, (hipStream_t)stream);
     if (rc != DIE_OK) return rc;
     DIE_CHECK_LAUNCH("die_diffuse_decay_tile");
     return DIE_OK;
@@ -776,7 +782,7 @@ extern "C" int die_step_reduce(const die_agents* a, const die_dynamics* d, die_s
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream, const char* who,
                                 const long long* part_gain = nullptr, int n_part = 0, die_step_result* result = nullptr,
-                                long long alive_const = 0, const long long* part_alive = nullptr);
+                                long long alive_const = 0, const long long* part_alive = nullptr, const float* dep_plane = nullptr);
 extern "C" int die_agent_dead_slots(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                                     void* ws, int64_t ws_bytes, void* stream);
 
@@ -894,11 +900,11 @@ extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, di
 
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream,
                                 const char* who, const long long* part_gain, int n_part, die_step_result* result,
-                                long long alive_const, const long long* part_alive) {
+                                long long alive_const, const long long* part_alive, const float* dep_plane) {
     DIE_REQUIRE(m && d, "%s: null argument", who);
-    DIE_REQUIRE(m->owner && m->food && m->chem && m->chem_next && m->chem_next != m->chem, "%s: null or aliased plane", who);
+    DIE_REQUIRE((m->owner || dep_plane) && m->food && m->chem && m->chem_next && m->chem_next != m->chem, "%s: null or aliased plane", who);
     DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad dtype %d", who, m->dtype);
-    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "%s: bad epoch %d", who, m->epoch);
+    DIE_REQUIRE(dep_plane || (m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX), "%s: bad epoch %d", who, m->epoch);
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
     if (!(rows_kernel_applies(m->W, m->H, R) && R >= 1 && (!tile || (m->H >= 8 && m->W >= 2 * R + 1 && halo >= 0)))) {
         die_set_error("%s: needs H %% 4 == 0 and radius 1..4 (W=%d H=%d sigma=%g halo=%d)", who, m->W, m->H,
@@ -908,20 +914,37 @@ static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int 
     RowsArgs ra;
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(d->diffuse_sigma, wd);
-    ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.food = m->food;
+    ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.dep = dep_plane; ra.food = m->food;
     ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo;
     ra.wrapx = tile && m->gW > 0 && m->W == m->gW; ra.wrapy = tile && m->gW > 0 && m->H == m->gH;
     ra.part_gain = part_gain; ra.part_alive = part_alive; ra.n_part = n_part; ra.result = result; ra.alive_const = alive_const;
     ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
     int rc;
-    if (tile) rc = m->dtype == DIE_F32 ? launch_rows<float, true, false>(ra, R, (hipStream_t)stream)
-                                       : launch_rows<__half, true, false>(ra, R, (hipStream_t)stream);
-    else rc = m->dtype == DIE_F32 ? launch_rows<float, true, true>(ra, R, (hipStream_t)stream)
-                                  : launch_rows<__half, true, true>(ra, R, (hipStream_t)stream);
+    if (dep_plane) {
+        DIE_REQUIRE(!tile, "%s: the deposit-plane sweep is for periodic single-tile planes", who);
+        rc = m->dtype == DIE_F32 ? launch_rows<float, 2, true>(ra, R, (hipStream_t)stream)
+                                 : launch_rows<__half, 2, true>(ra, R, (hipStream_t)stream);
+    }
+    else if (tile) rc = m->dtype == DIE_F32 ? launch_rows<float, 1, false>(ra, R, (hipStream_t)stream)
+                                            : launch_rows<__half, 1, false>(ra, R, (hipStream_t)stream);
+    else rc = m->dtype == DIE_F32 ? launch_rows<float, 1, true>(ra, R, (hipStream_t)stream)
+                                  : launch_rows<__half, 1, true>(ra, R, (hipStream_t)stream);
     if (rc != DIE_OK) return rc;
     DIE_CHECK_LAUNCH(who);
     return DIE_OK;
+}
+
+// the field half of the tile-binned step (die_pic.hip): the sweep reads the winners' deposits from a float plane
+int die_sweep_dep_plane(const die_medium* m, const die_dynamics* d, const float* dep_plane, const long long* part_gain, int n_part,
+                        die_step_result* result, long long alive_const, void* stream) {
+    DIE_REQUIRE(dep_plane, "die_pic_step: null deposit plane");
+    if (!fused_step_applies(m, d)) {
+        die_set_error("die_pic_step: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+        return DIE_ERR_UNSUPPORTED;
+    }
+    return deposit_feed_diffuse(m, d, 0, false, stream, "die_pic_step(diffuse+deposit+feed+reduce)", part_gain, n_part, result,
+                                alive_const, nullptr, dep_plane);
 }
 
 extern "C" int die_medium_deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, void* stream) {

@@ -74,11 +74,32 @@ struct FwdOut {
 // Reads the 4 chem taps around the probe cell and the food under the agent, decides the turn,
 // applies momentum, updates _prev_grad in place (when kept) and returns heading' and the action.
 // EXT = false compiles the sense-mask test out (the benchmark path; chosen at launch when mask == NULL).
-template <typename T, int KIND, bool EXT = true>
-__device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint32_t X, const uint32_t Y, const float d,
-                                                   const uint32_t sid, const int64_t n) {
-    const T* chem = (const T*)a.chem;
-    const T* food = (const T*)a.food;
+// Where the taps come from: global memory (the planes of FwdArgs) …
+template <typename T, bool EXT>
+struct FwdGlobalMem {
+    const T* chem;
+    const T* food;
+    const uint8_t* mask;
+    die_geo g;
+    __device__ __forceinline__ explicit FwdGlobalMem(const FwdArgs& a) : chem((const T*)a.chem), food((const T*)a.food), mask(a.mask), g(a.g) {}
+    // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
+    __device__ __forceinline__ float seen(const T* p, const int64_t i) const { return (EXT && mask && !mask[i]) ? 0.f : die_ld(p, i); }
+    __device__ __forceinline__ float chem_at(int gx, int gy) const { return seen(chem, die_local(g, gx, gy)); }
+    __device__ __forceinline__ float food_at(int gx, int gy) const { return seen(food, die_local(g, gx, gy)); }
+};
+// … or a tile staged in LDS (die_pic.hip): chem with a margin of the probe reach around the tile, food of the tile itself
+template <typename T>
+struct FwdTileMem {
+    const T* chem;          // element (gx, gy) at (gx − cx0)·pitch + (gy − cy0)
+    const T* food;          // element (gx, gy) at (gx − fx0)·fpitch + (gy − fy0)
+    int cx0, cy0, pitch, fx0, fy0, fpitch;
+    __device__ __forceinline__ float chem_at(int gx, int gy) const { return die_ld(chem, (int64_t)((gx - cx0) * pitch + (gy - cy0))); }
+    __device__ __forceinline__ float food_at(int gx, int gy) const { return die_ld(food, (int64_t)((gx - fx0) * fpitch + (gy - fy0))); }
+};
+
+template <typename T, int KIND, bool EXT, class MEM>
+__device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const MEM& mem, const uint32_t X, const uint32_t Y, const float d,
+                                                       const uint32_t sid, const int64_t n) {
     const die_geo g = a.g;
     const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
     float sd, cd;
@@ -89,13 +110,11 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
     // np.gradient at the probe cell: central inside, one-sided at the four edges (gradient.py:57)
     const int xm = px > 0 ? px - 1 : 0, xp = px < W - 1 ? px + 1 : W - 1;
     const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;
-    // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
-    auto seen = [&](const T* p, const int64_t i) { return (EXT && a.mask && !a.mask[i]) ? 0.f : die_ld(p, i); };
-    const float cxm = seen(chem, die_local(g, xm, py)), cxp = seen(chem, die_local(g, xp, py));
-    const float cym = seen(chem, die_local(g, px, ym)), cyp = seen(chem, die_local(g, px, yp));
+    const float cxm = mem.chem_at(xm, py), cxp = mem.chem_at(xp, py);
+    const float cym = mem.chem_at(px, ym), cyp = mem.chem_at(px, yp);
     // food under the agent (gradient.py:114-116)
     const int cx = die_cell((int64_t)X, W), cy = die_cell((int64_t)Y, H);
-    const float f_own = seen(food, die_local(g, cx, cy));
+    const float f_own = mem.food_at(cx, cy);
     const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
     const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
     const float norm = sqrtf(gx * gx + gy * gy);
@@ -169,6 +188,12 @@ __device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint
     o.dy = uy * a.scale;
     o.dep = a.deposit * f_own * dep_mask;
     return o;
+}
+
+template <typename T, int KIND, bool EXT = true>
+__device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint32_t X, const uint32_t Y, const float d,
+                                                   const uint32_t sid, const int64_t n) {
+    return die_forward_agent_mem<T, KIND, EXT>(a, FwdGlobalMem<T, EXT>(a), X, Y, d, sid, n);
 }
 
 // host side: validate and fill FwdArgs (shared by die_gradient_forward and die_forward_env_step)

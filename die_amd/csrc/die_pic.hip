@@ -1,0 +1,627 @@
+// Tile-binned step (gfx950): Agent.forward + Env.step of core/env.py:101-131 / core/agent/gradient.py:96-124 with the
+// agents held in EXACT tile order, so that "last writer wins" (core/env.py:211) is resolved in LDS and no claim plane
+// exists in HBM.  No reference counterpart for the data structure; the arithmetic per agent and per cell is the same
+// code as the classic path (die_forward.h, the field sweep of die_env.hip) and gives the same bits.
+//
+// Why: in the classic step the 8-byte claim plane is 46 % of the HBM traffic (2.5 M scattered 64-bit atomics fetch and
+// write back nearly every line of a 134 MB plane, the sweep reads it again with its halo rows) and the agent kernel is
+// bound by the number of L1 misses in flight, not by bytes.  Binning removes both:
+//
+//   layout    the world is cut into tiles of 2^XS × 2^YS cells.  A layout is a permutation of the agent arrays made of one
+//             segment per tile, [off[t], off[t] + n[t]): first the s[t] agents that stand on tile t ("stayers"), then the
+//             n[t] − s[t] agents that stood on it one step ago and have walked onto a neighbouring tile ("leavers").  The
+//             agents standing on t NOW are its stayers plus those leavers of its 8 neighbours whose cell lies in t.
+//   K1        k_pic_forward_move, one workgroup per tile over exactly that set: forward (4 chem taps, food under the
+//             agent: all inside the tile's neighbourhood, i.e. L1/L2 hits), move, feeding of the agent, reward partial;
+//             the agent is written to the OTHER layout as a stayer (front of the segment) or a leaver (back) — positions
+//             from two LDS counters, one arrival counted per leaver in inc[destination].  Because an agent moves less
+//             than a tile per step, a segment of size |set| always fits: no capacity, no overflow.
+//   K2        k_pic_resolve, one workgroup per tile over the same kind of set in the new layout: 64-bit LDS atomicMax of
+//             (slot + 1) << 32 | deposit bits per cell, then the tile of the deposit plane is written with coalesced
+//             16-byte stores: the winner's deposit, or DIE_DEP_EMPTY.  An extra workgroup turns (s, inc) into the segment
+//             sizes and offsets of the next step (exclusive scan over the tiles).
+//   sweep     k_diffuse_rows<T, R, 2, true> (die_env.hip): deposit + feeding + gaussian + decay, reading 4 bytes per cell
+//             of deposit plane instead of 8 bytes of claims; an extra workgroup reduces the reward partials.
+//
+// Per step the agent arrays are streamed once in and once out by K1 and (x, y, slot, deposit) once by K2; the planes are
+// read through the caches by K1 and streamed by the sweep.  The 'agents' channel (claim plane) is not maintained on this
+// path: die_agents_mark_owner materialises it when somebody asks (DeviceMedium.occupied / owner_slots / render).
+#include "die_forward.h"
+
+#ifndef PIC_K1_BLOCK
+#define PIC_K1_BLOCK 512       // ≈ 614 agents stand on a 64×64 tile at ratio 0.15: one or two trips of the loop
+#endif
+#ifndef PIC_K2_BLOCK
+#define PIC_K2_BLOCK 512
+#endif
+#define PIC_MAX_MARGIN 24      // probe reach (cells) up to which K1 stages the chem tile in LDS
+#ifndef PIC_STAGE_FOOD
+#define PIC_STAGE_FOOD 1
+#endif
+
+struct PicLayout {
+    uint32_t *x, *y;
+    float* agent_food;
+    uint32_t* slot;
+    float* heading;
+    uint32_t *off, *n, *s, *inc;    // per tile
+};
+
+struct PicArgs {
+    die_geo g;
+    int ntx, nty, xs, ys;           // tiles per axis, log2 of the tile shape
+    int margin;                     // K1 stages chem of the tile ± margin cells (a multiple of the 16-byte vector width)
+    PicLayout in, out;
+    float* dep;                     // N: deposit of every agent, `out` order (K1 → K2)
+    float *adx, *ady, *adep;        // the action handed back to the caller, `in` order
+    const void* food;
+    float rate_feed, w_dep, w_dist;
+    int boundary, cost;
+    long long* part_gain;           // one fixed-point partial per tile
+    uint32_t* error;                // device word, sticky: bit 0 segment bookkeeping broken, bit 1 an agent jumped further than a
+                                    // tile
+};
+
+__device__ __forceinline__ int pic_tile_of(const PicArgs& p, uint32_t X, uint32_t Y) {
+    return (die_cell((int64_t)X, p.g.gW) >> p.xs) * p.nty + (die_cell((int64_t)Y, p.g.gH) >> p.ys);
+}
+
+// The 9 index ranges that hold the agents standing on `tile` in layout L: [0] its own stayers, [1..8] the leavers of the
+// neighbours (periodic neighbourhood; under the 'limit' boundary nothing crosses the seam and those ranges simply fail
+// the tile test).  base[r] = first array index, pre[r] = exclusive prefix of the lengths, pre[9] = total candidates.
+// Two halves, so that the (dependent) loads of the per-tile words are in flight while the caller stages its tile.
+struct PicMeta { uint32_t base, len; };
+
+__device__ __forceinline__ PicMeta pic_meta_load(const PicLayout& L, int tile, int ntx, int nty) {
+    PicMeta mt = {0u, 0u};
+    if (threadIdx.x < 9) {
+        const int tx = tile / nty, ty = tile - tx * nty;
+        const int q = threadIdx.x;            // 0: (0, 0); 1..8: the ring
+        const int k = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
+        const int dx = k / 3 - 1, dy = k % 3 - 1;
+        const int nx = (tx + dx + ntx) % ntx, ny = (ty + dy + nty) % nty;
+        const int t = nx * nty + ny;
+        const uint32_t o = L.off[t], s = L.s[t], n = L.n[t];
+        mt.base = q == 0 ? o : o + s;
+        mt.len = s > n ? 0u : (q == 0 ? s : n - s);     // (s > n: broken bookkeeping — never loop over garbage)
+    }
+    return mt;
+}
+
+__device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* base, uint32_t* pre) {
+    __shared__ uint32_t s_len[9];
+    if (threadIdx.x < 9) { base[threadIdx.x] = mt.base; s_len[threadIdx.x] = mt.len; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int q = 0; q < 9; ++q) { pre[q] = run; run += s_len[q]; }
+        pre[9] = run;
+    }
+    __syncthreads();
+}
+
+// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses, four loads in flight per thread;
+// rows / columns outside the world are skipped (nothing ever reads them: probes clamp at the world's edge)
+template <typename T>
+__device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int gy0, int rows, int vpr, int W, int H) {
+    constexpr int V = 16 / (int)sizeof(T);
+    const int BLOCK = blockDim.x;
+    const int nvec = rows * vpr;
+    for (int i0 = threadIdx.x; i0 < nvec; i0 += BLOCK * 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * BLOCK;
+            v[q] = make_uint4(0, 0, 0, 0);
+            if (i < nvec) {
+                const int row = i / vpr, cv = i - row * vpr;
+                const int gx = gx0 + row, gy = gy0 + cv * V;
+                if (gx >= 0 && gx < W && gy >= 0 && gy < H) v[q] = *(const uint4*)(plane + (int64_t)gx * H + gy);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = i0 + q * BLOCK;
+            if (i < nvec) ((uint4*)dst)[i] = v[q];
+        }
+    }
+}
+
+#define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
+
+// Diagnostic build only (-DPIC_STAMPS; scratch/pic_stamps.py): s_memtime at the phase boundaries of K1, written by lane 0
+// of wave 0 behind the error word (the caller allocates 1 + 8·tiles words).  No stamp executes in the shipped kernel.
+#ifdef PIC_STAMPS
+#define PIC_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                          ((unsigned long long*)(p.error + 2))[(size_t)tile * 8 + (k)] = t_; } } while (0)
+#else
+#define PIC_STAMP(k) do { } while (0)
+#endif
+
+template <typename T, int KIND, bool STAGE>
+__global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f, PicArgs p) {
+    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
+    __shared__ uint32_t s_base[9], s_pre[10];
+    __shared__ uint32_t s_front, s_back, s_next, s_nlist;
+    __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
+    __shared__ uint32_t s_list[PIC_LIST_CAP];
+    __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
+    const int tile = blockIdx.x;
+    const int tx = tile / p.nty, ty = tile - tx * p.nty;
+    const int TX = 1 << p.xs, TY = 1 << p.ys, x0 = tx << p.xs, y0 = ty << p.ys;
+    const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE, nwaves = blockDim.x / DIE_WAVE;
+    if (threadIdx.x == 0) { s_front = 0; s_back = 0; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
+    if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
+    PIC_STAMP(0);
+    // 1st round trip: the per-tile words (small arrays, L2-resident)
+    const PicMeta mt = pic_meta_load(p.in, tile, p.ntx, p.nty);
+    const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
+    pic_ranges_finish(mt, s_base, s_pre);
+    PIC_STAMP(1);
+    const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    // 2nd round trip, everything at once: this thread's first candidate arrival, the agent streams of this wave's first
+    // chunk of stayers, and the tiles to stage
+    uint32_t cj = 0, cX = 0, cY = 0;
+    const bool chas = threadIdx.x < ncand;
+    if (chas) {
+        const uint32_t idx = own + threadIdx.x;
+        int r = 1;
+        while (idx >= s_pre[r + 1]) ++r;
+        cj = s_base[r] + (idx - s_pre[r]);
+        cX = p.in.x[cj];
+        cY = p.in.y[cj];
+    }
+    const uint32_t pidx = (uint32_t)(wave * DIE_WAVE + lane);
+    const bool phas = pidx < own;
+    uint32_t pX = 0, pY = 0, pS = 0;
+    float pH = 0.f, pA = 0.f;
+    if (phas) {
+        const uint32_t j = base0 + pidx;
+        pX = p.in.x[j]; pY = p.in.y[j]; pS = p.in.slot[j]; pH = p.in.heading[j]; pA = p.in.agent_food[j];
+    }
+    const T* food = (const T*)p.food;
+    FwdTileMem<T> tm;
+    if (STAGE) {
+        constexpr int V = 16 / (int)sizeof(T);
+        const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
+        T* s_chem = (T*)pic_smem;
+        T* s_food = s_chem + rows * pitch;
+        pic_stage<T>(s_chem, (const T*)f.chem, x0 - P, y0 - P, rows, pitch / V, p.g.W, p.g.H);
+        if (PIC_STAGE_FOOD) {
+            pic_stage<T>(s_food, food, x0, y0, TX, TY / V, p.g.W, p.g.H);
+            tm.food = s_food; tm.fx0 = x0; tm.fy0 = y0; tm.fpitch = TY;
+        } else {
+            tm.food = food; tm.fx0 = 0; tm.fy0 = 0; tm.fpitch = p.g.H;
+        }
+        tm.chem = s_chem; tm.cx0 = x0 - P; tm.cy0 = y0 - P; tm.pitch = pitch;
+    }
+    PIC_STAMP(2);
+    long long gsum = 0;
+    // Rounds: the tile's own stayers plus (at most PIC_LIST_CAP per round) the neighbours' leavers that landed here,
+    // compacted into s_list first so that the heavy part below runs on full waves.  One round unless a crowd arrives.
+    for (uint32_t cb = 0; cb == 0 || cb < ncand; cb += PIC_LIST_CAP) {
+        const uint32_t cend = min(cb + (uint32_t)PIC_LIST_CAP, ncand);
+        for (uint32_t c0 = cb; c0 < cend; c0 += blockDim.x) {      // wave-uniform trip count
+            const uint32_t c = c0 + threadIdx.x;
+            bool hit = false;
+            uint32_t j = 0;
+            if (c0 == 0) {                                         // loaded above
+                j = cj;
+                hit = chas && pic_tile_of(p, cX, cY) == tile;
+            } else if (c < cend) {
+                const uint32_t idx = own + c;
+                int r = 1;
+                while (idx >= s_pre[r + 1]) ++r;
+                j = s_base[r] + (idx - s_pre[r]);
+                hit = pic_tile_of(p, p.in.x[j], p.in.y[j]) == tile;
+            }
+            const unsigned long long m = __ballot(hit);
+            uint32_t at = 0;
+            if (lane == 0 && m) at = atomicAdd(&s_nlist, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, DIE_WAVE);
+            if (hit) s_list[at + (uint32_t)__popcll(m & below)] = j;
+        }
+        __syncthreads();                                           // publishes the staged tiles and the list
+        PIC_STAMP(3);
+        const uint32_t n_own = cb == 0 ? own : 0u, count = n_own + s_nlist;
+        bool first = cb == 0;
+        for (;;) {                         // a wave's first chunk is fixed (its streams are already here), then it takes
+            uint32_t c = 0;                // chunks of 64 items from the counter until none are left
+            if (first) {
+                c = (uint32_t)(wave * DIE_WAVE);
+            } else {
+                if (lane == 0) c = atomicAdd(&s_next, (uint32_t)DIE_WAVE);
+                c = __shfl(c, 0, DIE_WAVE);
+            }
+            if (c >= count) break;
+            const uint32_t idx = c + lane;
+            const bool act = idx < count;
+            bool stay = false;
+            uint32_t X = 0, Y = 0, sid = 0;
+            float hd = 0.f, af = 0.f, dep = 0.f;
+            if (act) {
+                const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
+                if (first && idx < n_own) {
+                    X = pX; Y = pY; sid = pS; hd = pH; af = pA;
+                } else {
+                    X = p.in.x[j];                                 // all five streams in flight together
+                    Y = p.in.y[j];
+                    sid = p.in.slot[j];
+                    hd = p.in.heading[j];
+                    af = p.in.agent_food[j];
+                }
+                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
+                                       : die_forward_agent<T, KIND, false>(f, X, Y, hd, sid, (int64_t)j);
+                if (p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }
+                // _agent_move (core/env.py:163-172)
+                if (p.boundary == DIE_BOUNDARY_WRAP) {
+                    X += (uint32_t)die_q32(o.dx);
+                    Y += (uint32_t)die_q32(o.dy);
+                } else {
+                    const int64_t qx = (int64_t)X + die_q32(o.dx), qy = (int64_t)Y + die_q32(o.dy);
+                    X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
+                    Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
+                }
+                const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
+                const int ntx_ = cx >> p.xs, nty_ = cy >> p.ys;
+                stay = ntx_ == tx && nty_ == ty;
+                // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption
+                const float fnew = (STAGE && stay) ? tm.food_at(cx, cy) : die_ld(food, (int64_t)cx * p.g.H + cy);
+                const float consumed = p.rate_feed * fnew;
+                const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * sqrtf(o.dx * o.dx + o.dy * o.dy) : 0.f;
+                const float gained = consumed - cost;
+                af += gained;
+                gsum += die_fix(gained);
+                hd = o.heading;
+                dep = o.dep;
+                if (!stay) {
+                    int ddx = ntx_ - tx, ddy = nty_ - ty;
+                    ddx = ddx > 1 ? ddx - p.ntx : (ddx < -1 ? ddx + p.ntx : ddx);
+                    ddy = ddy > 1 ? ddy - p.nty : (ddy < -1 ? ddy + p.nty : ddy);
+                    if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) atomicOr(p.error, 2u);
+                    else atomicAdd(&s_inc[(ddx + 1) * 3 + ddy + 1], 1u);   // one global atomic per neighbour at the end (2.5 M
+                }                                                          // agents: 11 µs of contended global atomics otherwise)
+            }
+            // positions: stayers fill the segment from the front, leavers from the back; one LDS atomic per wave and class
+            const unsigned long long m_stay = __ballot(act && stay), m_leave = __ballot(act && !stay);
+            uint32_t bf = 0, bb = 0;
+            if (lane == 0) {
+                if (m_stay) bf = atomicAdd(&s_front, (uint32_t)__popcll(m_stay));
+                if (m_leave) bb = atomicAdd(&s_back, (uint32_t)__popcll(m_leave));
+            }
+            bf = __shfl(bf, 0, DIE_WAVE);
+            bb = __shfl(bb, 0, DIE_WAVE);
+            if (act) {
+                const uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
+                if (k < on) {
+                    const uint32_t q = obase + k;
+                    p.out.x[q] = X;
+                    p.out.y[q] = Y;
+                    p.out.agent_food[q] = af;
+                    p.out.slot[q] = sid;
+                    p.out.heading[q] = hd;
+                    p.dep[q] = dep;
+                } else {
+                    atomicOr(p.error, 1u);
+                }
+            }
+            first = false;
+        }
+        if (cb + PIC_LIST_CAP < ncand) {                           // another round (rare): reset the work counters
+            __syncthreads();
+            if (threadIdx.x == 0) { s_next = 0; s_nlist = 0; }
+            __syncthreads();
+        }
+    }
+    PIC_STAMP(4);
+    gsum = die_wave_sum(gsum);
+    if (lane == 0) s_gain[threadIdx.x / DIE_WAVE] = gsum;
+    __syncthreads();
+    PIC_STAMP(5);
+    if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
+        const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
+        atomicAdd(&p.out.inc[((tx + ddx + p.ntx) % p.ntx) * p.nty + (ty + ddy + p.nty) % p.nty], s_inc[threadIdx.x]);
+    }
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) t += s_gain[i];
+        p.part_gain[tile] = t;
+        p.out.s[tile] = s_front;
+        if (s_front + s_back != on) atomicOr(p.error, 1u);
+    }
+}
+
+// K2.  blockIdx.x == number of tiles: the scan workgroup (sizes and offsets of the layout the NEXT step writes:
+// n = s + inc of the layout just written, exclusive scan; its arrival counters are cleared for that step).
+template <int XS, int YS>
+__global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* dep_plane) {
+    constexpr int TX = 1 << XS, TY = 1 << YS;
+    __shared__ __align__(16) unsigned long long s_claim[TX * TY];
+    __shared__ uint32_t s_base[9], s_pre[10];
+    const int NT = p.ntx * p.nty;
+    if ((int)blockIdx.x == NT) {
+        __shared__ uint32_t s_sum[PIC_K2_BLOCK];
+        const int per = (NT + PIC_K2_BLOCK - 1) / PIC_K2_BLOCK;
+        const int lo = threadIdx.x * per, hi = min(lo + per, NT);
+        uint32_t sum = 0;
+        for (int t = lo; t < hi; ++t) sum += p.out.s[t] + p.out.inc[t];
+        s_sum[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 1; o < PIC_K2_BLOCK; o <<= 1) {
+            const uint32_t v = (int)threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s_sum[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = s_sum[threadIdx.x] - sum;
+        for (int t = lo; t < hi; ++t) {
+            const uint32_t c = p.out.s[t] + p.out.inc[t];
+            p.in.off[t] = run;
+            p.in.n[t] = c;
+            p.in.inc[t] = 0;
+            run += c;
+        }
+        return;
+    }
+    const int tile = blockIdx.x;
+    const PicMeta mt = pic_meta_load(p.out, tile, p.ntx, p.nty);
+    for (int i = threadIdx.x; i < TX * TY / 2; i += PIC_K2_BLOCK) ((ulonglong2*)s_claim)[i] = make_ulonglong2(0ull, 0ull);
+    pic_ranges_finish(mt, s_base, s_pre);                          // (its barriers also cover the zeroing)
+    const uint32_t total = s_pre[9], own = s_pre[1];
+    const int tx = tile / p.nty, ty = tile - tx * p.nty;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += PIC_K2_BLOCK) {
+        int r = 0;
+        while (idx >= s_pre[r + 1]) ++r;
+        const uint32_t j = s_base[r] + (idx - s_pre[r]);
+        const uint32_t X = p.out.x[j], Y = p.out.y[j], sid = p.out.slot[j], db = __float_as_uint(p.dep[j]);
+        const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
+        if (idx >= own && ((cx >> XS) != tx || (cy >> YS) != ty)) continue;
+        // highest slot on the cell wins (core/env.py:211), its deposit rides in the low word
+        atomicMax(&s_claim[(cx & (TX - 1)) * TY + (cy & (TY - 1))], ((unsigned long long)(sid + 1u) << 32) | (unsigned long long)db);
+    }
+    __syncthreads();
+    static_assert(TY % 4 == 0, "16-byte stores");
+    for (int i = threadIdx.x * 4; i < TX * TY; i += PIC_K2_BLOCK * 4) {
+        const int row = i / TY, col = i - row * TY;
+        const ulonglong2 c01 = *(const ulonglong2*)&s_claim[i], c23 = *(const ulonglong2*)&s_claim[i + 2];
+        const unsigned long long c[4] = {c01.x, c01.y, c23.x, c23.y};
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = c[q] ? (uint32_t)c[q] : DIE_DEP_EMPTY;
+        *(uint4*)(dep_plane + (int64_t)(tx * TX + row) * p.g.H + ty * TY + col) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- (re)binning: any order of the agent arrays → a layout with every agent a stayer ---------------------------
+struct PicBinArgs {
+    die_geo g;
+    int64_t N;
+    int nty, xs, ys;
+    const uint32_t *x, *y, *slot;
+    const float *agent_food, *heading;
+    PicLayout out;
+    uint32_t* cursor;
+};
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_hist(PicBinArgs a, uint32_t* hist) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < a.N; b += stride) {
+        const int64_t n = b + threadIdx.x;
+        const bool active = n < a.N;
+        uint32_t key = 0;
+        if (active) key = (uint32_t)((die_cell((int64_t)a.x[n], a.g.gW) >> a.xs) * a.nty + (die_cell((int64_t)a.y[n], a.g.gH) >> a.ys));
+        wave_grouped_add<false>(hist, key, active);
+    }
+}
+
+// one workgroup: off = exclusive scan of the tile counts; both layouts start with the same segments, all stayers
+__global__ __launch_bounds__(1024) void k_pic_bin_scan(const uint32_t* hist, int NT, PicLayout a, PicLayout b, uint32_t* cursor,
+                                                       uint32_t* error) {
+    __shared__ uint32_t s[1024];
+    const int per = (NT + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, NT);
+    uint32_t sum = 0;
+    for (int t = lo; t < hi; ++t) sum += hist[t];
+    s[threadIdx.x] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s[threadIdx.x] - sum;
+    for (int t = lo; t < hi; ++t) {
+        const uint32_t c = hist[t];
+        cursor[t] = run;
+        a.off[t] = run; a.n[t] = c; a.s[t] = c; a.inc[t] = 0;
+        b.off[t] = run; b.n[t] = c; b.s[t] = c; b.inc[t] = 0;
+        run += c;
+    }
+    if (threadIdx.x == 0) *error = 0;
+}
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < a.N; b += stride) {
+        const int64_t n = b + threadIdx.x;
+        const bool active = n < a.N;
+        const uint32_t X = active ? a.x[n] : 0u, Y = active ? a.y[n] : 0u;
+        uint32_t key = 0;
+        if (active) key = (uint32_t)((die_cell((int64_t)X, a.g.gW) >> a.xs) * a.nty + (die_cell((int64_t)Y, a.g.gH) >> a.ys));
+        const uint32_t j = wave_grouped_add<true>(a.cursor, key, active);
+        if (!active) continue;
+        a.out.x[j] = X;
+        a.out.y[j] = Y;
+        a.out.agent_food[j] = a.agent_food[n];
+        a.out.slot[j] = a.slot ? a.slot[n] : (uint32_t)n;
+        a.out.heading[j] = a.heading[n];
+    }
+}
+
+// the 'agents' channel on demand: highest alive slot per cell, as the claim pass of the classic step leaves it
+__global__ __launch_bounds__(DIE_BLOCK) void k_mark_owner(die_geo g, int64_t N, int epoch, const uint32_t* x, const uint32_t* y,
+                                                          const uint32_t* slot, const uint8_t* alive, unsigned long long* owner) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        if (!alive[n]) continue;
+        const int64_t c = die_local(g, die_cell((int64_t)x[n], g.gW), die_cell((int64_t)y[n], g.gH));
+        atomicMax(&owner[c], die_claim(epoch, slot ? (int64_t)slot[n] : n, 0.f));
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+int die_sweep_dep_plane(const die_medium* m, const die_dynamics* d, const float* dep_plane, const long long* part_gain, int n_part,
+                        die_step_result* result, long long alive_const, void* stream);   // die_env.hip
+
+static bool pic_shape_ok(int xs, int ys) { return (xs == 6 && ys == 6) || (xs == 5 && ys == 7) || (xs == 5 && ys == 6) || (xs == 4 && ys == 5); }
+
+static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
+    DIE_REQUIRE(m && p, "%s: null argument", who);
+    DIE_REQUIRE(m->gW <= 0, "%s: periodic single-tile planes only", who);
+    DIE_REQUIRE(pic_shape_ok(p->tile_xs, p->tile_ys), "%s: tile shape 2^%d x 2^%d is not compiled in (64x64, 32x128, 32x64, 16x32)", who,
+                p->tile_xs, p->tile_ys);
+    const int TX = 1 << p->tile_xs, TY = 1 << p->tile_ys;
+    if (m->W % TX || m->H % TY || m->W / TX < 3 || m->H / TY < 3) {
+        die_set_error("%s: a %dx%d world does not split into at least 3x3 whole tiles of %dx%d cells", who, m->W, m->H, TX, TY);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    DIE_REQUIRE(p->N > 0 && p->N < ((int64_t)1 << 31), "%s: bad agent count", who);
+    for (int l = 0; l < 2; ++l) {
+        const die_pic_layout& L = p->layout[l];
+        DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
+    }
+    DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
+    DIE_REQUIRE(p->dep && p->dep_plane && p->part_gain && p->error, "%s: null workspace pointer", who);
+    return DIE_OK;
+}
+
+static PicLayout pic_layout(const die_pic_layout& L) {
+    PicLayout o;
+    o.x = L.x; o.y = L.y; o.agent_food = L.agent_food; o.slot = L.slot; o.heading = L.heading;
+    o.off = L.off; o.n = L.n; o.s = L.s; o.inc = L.inc;
+    return o;
+}
+
+extern "C" int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys) {
+    if (W < 1 || H < 1 || !pic_shape_ok(tile_xs, tile_ys)) return -1;
+    return (int64_t)(W >> tile_xs) * (H >> tile_ys);
+}
+
+extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const float* heading, const die_pic* p, int32_t into,
+                           void* stream) {
+    int rc = pic_check(m, p, "die_pic_bin");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(a && a->N == p->N && a->x && a->y && a->agent_food && heading, "die_pic_bin: bad agent arrays");
+    DIE_REQUIRE(into == 0 || into == 1, "die_pic_bin: layout index %d", into);
+    DIE_REQUIRE(a->x != p->layout[into].x, "die_pic_bin: the agents are already held in layout %d: bin into the other one", into);
+    const int NT = (int)die_pic_tiles(m->W, m->H, p->tile_xs, p->tile_ys);
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t* hist = (uint32_t*)p->part_gain;                 // NT 64-bit words of scratch: histogram + cursors
+    uint32_t* cursor = hist + NT;
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)NT * 4, s);
+    if (e != hipSuccess) { die_set_error("die_pic_bin: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
+    PicBinArgs b;
+    b.g = die_geo_of(m); b.N = a->N; b.nty = m->H >> p->tile_ys; b.xs = p->tile_xs; b.ys = p->tile_ys;
+    b.x = a->x; b.y = a->y; b.slot = a->slot; b.agent_food = a->agent_food; b.heading = heading;
+    b.out = pic_layout(p->layout[into]); b.cursor = cursor;
+    int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
+    const int grid = (int)(g < 4096 ? g : 4096);
+    k_pic_hist<<<grid, DIE_BLOCK, 0, s>>>(b, hist);
+    k_pic_bin_scan<<<1, 1024, 0, s>>>(hist, NT, pic_layout(p->layout[0]), pic_layout(p->layout[1]), cursor, p->error);
+    k_pic_scatter<<<grid, DIE_BLOCK, 0, s>>>(b);
+    DIE_CHECK_LAUNCH("die_pic_bin");
+    return DIE_OK;
+}
+
+template <int XS, int YS>
+static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, hipStream_t s) {
+    k_pic_resolve<XS, YS><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+}
+
+template <typename T, bool STAGE>
+static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
+    if (kind == DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE><<<NT, block, lds, s>>>(f, k);
+    else k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE><<<NT, block, lds, s>>>(f, k);
+}
+
+extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
+                                        const die_action* act, const die_dynamics* d, die_step_result* result, void* stream) {
+    int rc = pic_check(m, p, "die_pic_forward_env_step");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(g && d && result && (from == 0 || from == 1), "die_pic_forward_env_step: null argument");
+    DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_pic_forward_env_step: chem_next must be a second plane");
+    DIE_REQUIRE(!d->has_dead_slots && !d->agents_die && !m->sense_mask && !d->staged,
+                "die_pic_forward_env_step: every slot must be alive (no agents_die), no sense mask");
+    DIE_REQUIRE(g->inertia == 0.f && g->noise_scale == 0.f && g->normalized_grad,
+                "die_pic_forward_env_step: the step length must be bounded by `scale` (normalised gradient, no inertia, no noise)");
+    if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
+        die_set_error("die_pic_forward_env_step: boundary %d is not representable in Q0.32", d->boundary);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    DIE_REQUIRE(d->cost == DIE_COST_LINEAR || d->cost == DIE_COST_ZERO, "die_pic_forward_env_step: bad cost operator %d", d->cost);
+    const int TX = 1 << p->tile_xs, TY = 1 << p->tile_ys;
+    const float reach = fabsf(g->scale) * (float)((m->W > m->H ? m->W : m->H) - 1);     // cells per step, at most
+    if (!(reach <= (float)((TX < TY ? TX : TY) - 1))) {
+        die_set_error("die_pic_forward_env_step: a step of %.1f cells does not stay within the neighbouring %dx%d tiles", (double)reach, TX, TY);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    const die_pic_layout& Lin = p->layout[from];
+    die_agents a;
+    a.N = p->N; a.x = Lin.x; a.y = Lin.y; a.alive = nullptr; a.agent_food = Lin.agent_food; a.slot = Lin.slot;
+    die_gradient_agent gg = *g;
+    gg.heading = Lin.heading;
+    FwdArgs f;
+    rc = die_fill_fwd_args(f, m, &a, &gg, act, "die_pic_forward_env_step");
+    if (rc != DIE_OK) return rc;
+    PicArgs k;
+    k.g = die_geo_of(m); k.ntx = m->W >> p->tile_xs; k.nty = m->H >> p->tile_ys; k.xs = p->tile_xs; k.ys = p->tile_ys;
+    k.in = pic_layout(Lin); k.out = pic_layout(p->layout[1 - from]);
+    k.dep = p->dep;
+    k.adx = act ? act->dx : nullptr; k.ady = act ? act->dy : nullptr; k.adep = act ? act->deposit : nullptr;
+    k.food = m->food; k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
+    k.boundary = d->boundary; k.cost = d->cost;
+    k.part_gain = (long long*)p->part_gain; k.error = p->error;
+    const int NT = k.ntx * k.nty;
+    hipStream_t s = (hipStream_t)stream;
+    // K1 stages chem of the tile ± the probe reach in LDS when that fits: an agent's probe cell lies at most
+    // floor(|sense_offset|·(size − 1)) + 1 cells from its own cell, the gradient taps one further
+    const int esz = m->dtype == DIE_F32 ? 4 : 2, V = 16 / esz;
+    int P = (int)floorf(fabsf(g->sense_offset) * (float)((m->W > m->H ? m->W : m->H) - 1)) + 2;
+    P = (P + V - 1) / V * V;
+    const bool stage = P <= PIC_MAX_MARGIN;
+    k.margin = stage ? P : 0;
+    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
+    const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
+    int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
+    DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK, "die_pic_forward_env_step: k1_threads %d", block);
+    if (stages & 1) {
+        if (m->dtype == DIE_F32) {
+            if (stage) launch_forward_move<float, true>(g->kind, f, k, NT, block, lds, s);
+            else launch_forward_move<float, false>(g->kind, f, k, NT, block, 0, s);
+        } else {
+            if (stage) launch_forward_move<__half, true>(g->kind, f, k, NT, block, lds, s);
+            else launch_forward_move<__half, false>(g->kind, f, k, NT, block, 0, s);
+        }
+    }
+    if (stages & 2) {
+        if (p->tile_xs == 6 && p->tile_ys == 6) launch_resolve<6, 6>(k, p->dep_plane, NT, s);
+        else if (p->tile_xs == 5 && p->tile_ys == 7) launch_resolve<5, 7>(k, p->dep_plane, NT, s);
+        else if (p->tile_xs == 5 && p->tile_ys == 6) launch_resolve<5, 6>(k, p->dep_plane, NT, s);
+        else launch_resolve<4, 5>(k, p->dep_plane, NT, s);
+    }
+    DIE_CHECK_LAUNCH("die_pic_forward_env_step");
+    if (!(stages & 4)) return DIE_OK;
+    return die_sweep_dep_plane(m, d, p->dep_plane, (const long long*)p->part_gain, NT, result, p->N, stream);
+}
+
+extern "C" int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream) {
+    DIE_REQUIRE(m && a && m->owner && a->x && a->y && a->alive && a->N > 0, "die_agents_mark_owner: null argument");
+    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX, "die_agents_mark_owner: bad epoch %d", m->epoch);
+    int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
+    k_mark_owner<<<(int)(g < 8192 ? g : 8192), DIE_BLOCK, 0, (hipStream_t)stream>>>(die_geo_of(m), a->N, m->epoch, a->x, a->y, a->slot,
+                                                                                    a->alive, (unsigned long long*)m->owner);
+    DIE_CHECK_LAUNCH("die_agents_mark_owner");
+    return DIE_OK;
+}

@@ -28,39 +28,6 @@ __device__ __forceinline__ uint32_t sort_key(const die_geo& g, uint32_t X, uint3
     return (uint32_t)((ix >> DIE_SORT_XSHIFT) * nby + (iy >> DIE_SORT_YSHIFT));
 }
 
-// Groups the active lanes of the wave by key (no memory traffic), then every group's first lane issues ONE atomicAdd of
-// the group's size — all of a wave's atomics are in flight together — and the lanes get base + rank inside the group
-// (lane order): a unique slot of the bucket's range when `counter` is a cursor.  RETURNING = false: histogram only.
-template <bool RETURNING>
-__device__ __forceinline__ uint32_t wave_grouped_add(uint32_t* counter, uint32_t key, bool active) {
-    const int lane = threadIdx.x & (DIE_WAVE - 1);
-    int my_lead = lane;
-    uint32_t my_rank = 0, my_count = 0;
-    bool todo = active;
-    unsigned long long pending = __ballot(todo);
-    while (pending) {
-        const int lead = __ffsll((long long)pending) - 1;
-        const uint32_t kk = __shfl(key, lead, DIE_WAVE);
-        const bool match = todo && key == kk;
-        const unsigned long long mask = __ballot(match);
-        if (match) {
-            my_lead = lead;
-            my_rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (lane == lead) my_count = (uint32_t)__popcll(mask);
-            todo = false;
-        }
-        pending &= ~mask;
-    }
-    uint32_t base = 0;
-    if (active && lane == my_lead) {
-        if (RETURNING) base = atomicAdd(&counter[key], my_count);
-        else atomicAdd(&counter[key], my_count);
-    }
-    if (!RETURNING) return 0;
-    base = __shfl(base, my_lead, DIE_WAVE);
-    return base + my_rank;
-}
-
 __global__ __launch_bounds__(DIE_BLOCK) void k_sort_hist(die_geo g, int64_t N, const uint32_t* x, const uint32_t* y, int nby,
                                                          uint32_t* hist) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;

@@ -50,12 +50,21 @@ class DeviceMedium:
         self.chem_next = torch.empty((W, H), dtype=dtype, device=device)
         self.epoch = 1
         self.world = None        # (gW, gH, ox, oy) when these planes are one tile of a decomposed world
+        self.owner_stale = None  # callable that rebuilds `owner` (the tile-binned step does not maintain the claim plane)
 
     @property
     def shape(self):
         return (3, self.W, self.H)
 
-    def c_struct(self) -> _lib.Medium:
+    def _ensure_owner(self):
+        if self.owner_stale is not None:
+            rebuild, self.owner_stale = self.owner_stale, None
+            rebuild()
+
+    def c_struct(self, need_owner: bool = True) -> _lib.Medium:
+        """`need_owner=False`: the callee does not read the claim plane (or overwrites it with a new epoch)."""
+        if need_owner:
+            self._ensure_owner()
         return _lib.Medium(self.W, self.H, _lib.DIE_F32 if self.dtype == torch.float32 else _lib.DIE_F16, self.epoch,
                            _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next),
                            *(self.world or (0, 0, 0, 0)), *(getattr(self, 'own', None) or (0, 0, 0, 0)),
@@ -63,6 +72,7 @@ class DeviceMedium:
 
     def next_epoch(self):
         """Advance the ownership epoch; zero the plane when the 5-bit tag (1..31) wraps."""
+        self.owner_stale = None          # whoever advances the epoch re-claims every occupied cell
         self.epoch += 1
         if self.epoch > _lib.OWNER_EPOCH_MAX:
             self.owner.zero_()
@@ -80,10 +90,12 @@ class DeviceMedium:
 
     def occupied(self) -> torch.Tensor:
         """Boolean (W, H): the 'agents' channel > 0."""
+        self._ensure_owner()
         return ((self.owner >> (32 + _lib.OWNER_EPOCH_SHIFT)) & _lib.OWNER_EPOCH_MAX) == self.epoch
 
     def owner_slots(self) -> torch.Tensor:
         """int64 (W, H): owning slot id, −1 for empty cells."""
+        self._ensure_owner()
         w = (self.owner >> 32) & 0xFFFFFFFF
         return torch.where((w >> _lib.OWNER_EPOCH_SHIFT) == self.epoch, (w & _lib.OWNER_SLOT_MASK) - 1,
                            torch.full_like(w, -1))
@@ -104,6 +116,7 @@ class DeviceMedium:
         """Load a (3, W, H) array; occupied cells get an ownership word of the current epoch."""
         medium = np.asarray(medium)
         assert medium.shape == self.shape, (medium.shape, self.shape)
+        self.owner_stale = None
         occ = medium[0] > 0
         words = np.where(occ, np.uint64(((self.epoch << _lib.OWNER_EPOCH_SHIFT) | 1) << 32), np.uint64(0)).astype(np.uint64)
         self.owner.copy_(torch.from_numpy(words.view(np.int64)))
@@ -270,6 +283,13 @@ class PendingAction(DeviceAction):
         """Pointers of the (possibly still unfilled) arrays, without forcing the forward kernel."""
         d = self._data
         return _lib.Action(self.N, _ptr(d[0]), _ptr(d[1]), _ptr(d[2]))
+
+    def rebind(self, agents):
+        """The agents (and the agent object's state) were re-ordered between forward() and the fused step."""
+        self.slot = agents.slot
+        hd = self.agent._direction_rads
+        self.g_struct.heading = hd.data_ptr()
+        self._keepalive = (hd,) + tuple(self._keepalive[1:])
 
     def ensure(self):
         if self.pending:

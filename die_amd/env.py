@@ -75,7 +75,7 @@ class Env(_EnvBase):
     def __init__(self, field_size: Tuple[int, int], dynamics: Optional[Dynamics] = None, *,
                  max_agents: Union[None, int, str] = None, seed: Optional[int] = None,
                  field_dtype: torch.dtype = torch.float32, device: Union[str, torch.device, None] = None,
-                 sync: bool = True, sort_every: int = 4, staged: bool = False):
+                 sync: bool = True, sort_every: int = 4, staged: bool = False, pic: bool = True):
         if not torch.cuda.is_available():
             raise RuntimeError('die_amd.Env needs a ROCm GPU (MI355X); there is no CPU path')
         self._field_size = (int(field_size[0]), int(field_size[1]))
@@ -86,6 +86,7 @@ class Env(_EnvBase):
         self._sync = sync
         self._sort_every = int(sort_every)
         self._staged = bool(staged)       # cross-checks: one kernel per stage of the step instead of the fused sweep
+        self._pic_enabled = bool(pic)     # tile-binned step (die_amd/pic.py) whenever it applies
         self._seed = int.from_bytes(os.urandom(8), 'little') if seed is None else int(seed)
         self._renderer = None
         self.last_result = None
@@ -118,6 +119,8 @@ class Env(_EnvBase):
         if self._sort_every > 0:            # the re-sort's shadow arrays and workspace exist before the first step, so that
             self._alloc_sort_buffers()      # no step of a timed loop pays for allocations
         self._fuse_forward = True           # False once die_forward_env_step reports the shape unsupported
+        self._pic = None                    # PicState, built at the first eligible step
+        self._pic_tile = None
         self.medium.sense_mask = None
         if self.dynamics.apply_sense_mask:
             W, H = self._field_size
@@ -148,6 +151,7 @@ class Env(_EnvBase):
         env._sync = kw.get('sync', True)
         env._sort_every = int(kw.get('sort_every', 4))
         env._staged = bool(kw.get('staged', False))
+        env._pic_enabled = bool(kw.get('pic', True))
         env._seed = int(kw.get('seed', 0))
         env._renderer = None
         env.last_result = None
@@ -194,8 +198,11 @@ class Env(_EnvBase):
     def step(self, action):
         """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
         result = torch.empty(2, dtype=torch.float64, device=self.device)
-        fused = False
+        fused = binned = False
         if isinstance(action, PendingAction) and action.pending and action.agents is self.agents \
+                and action.medium is self.medium and action.slot is self.agents.slot and self._fuse_forward:
+            fused = binned = self._pic_step(action, result)
+        if not fused and isinstance(action, PendingAction) and action.pending and action.agents is self.agents \
                 and action.medium is self.medium and action.slot is self.agents.slot and self._fuse_forward:
             # `env.step(agent.forward(obs))`: forward runs fused with the move / claim pass
             self.medium.next_epoch()
@@ -225,8 +232,8 @@ class Env(_EnvBase):
         if self.dynamics.apply_sense_mask:
             self._update_sense_mask()
         self._steps += 1
-        if self._sort_every > 0 and self._steps % self._sort_every == 0:
-            self.sort_agents()
+        if self._sort_every > 0 and self._steps % self._sort_every == 0 and not binned:
+            self.sort_agents()              # (the tile-binned step keeps the arrays exactly sorted by itself)
         self.last_result = result
         if not self._sync:
             return self._get_current_obs, result, False, False, {}
@@ -237,11 +244,54 @@ class Env(_EnvBase):
         info = {'num_agents': num_agents, 'reward': np.round(reward, 3), 'mean_reward': np.round(mean_gain, 5)}
         return self._get_current_obs, reward, num_agents == 0, False, info
 
-    @staticmethod
-    def read_result(result: torch.Tensor) -> Tuple[float, int]:
+    def read_result(self, result: torch.Tensor) -> Tuple[float, int]:
         """(reward, num_agents) of a die_step_result buffer (synchronises)."""
         host = result.cpu()
+        if self._pic is not None:
+            self._pic.check()
         return float(host[0]), int(host.view(torch.int64)[1])
+
+    # ------------------------------------------------------------------ tile-binned step (die_amd/pic.py)
+    def _pic_applies(self, action) -> bool:
+        d, ag = self.dynamics, action.agent
+        if not (self._pic_enabled and self._all_alive and not d.agents_die and not d.apply_sense_mask and not self._staged
+                and self.medium.world is None and isinstance(d.boundary, BoundaryCondition) and d.diffuse_mode == 'wrap'
+                and 1 <= int(4.0 * float(d.diffuse_sigma) + 0.5) <= 4):
+            return False
+        if not (ag._normalized and ag._inertia == 0 and ag._noise_scale == 0 and ag._step_base is None and ag._prev_grad is None):
+            return False
+        W, H = self._field_size
+        reach = abs(ag._scale) * (max(W, H) - 1)                 # cells per step, at most
+        if self._pic_tile is None:
+            from .pic import pick_tile
+            self._pic_tile = pick_tile(W, H, reach) or False
+        return bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1
+
+    def _pic_step(self, action, result) -> bool:
+        """`env.step(agent.forward(obs))` on tile-binned agents: die_pic_forward_env_step.  False: not applicable, the
+        caller takes the classic path (nothing has been touched)."""
+        if not self._pic_applies(action):
+            return False
+        from .pic import PicState
+        ag = action.agent
+        if self._pic is None:
+            self._pic = PicState(self, self._pic_tile)
+            self._pic.k1_threads = int(getattr(self, '_pic_k1_threads', 0))
+        if not self._pic.is_current(self, ag):
+            self._pic.bin(self, ag)
+            action.rebind(self.agents)
+        _lib.check(self._pic.step(self, ag, action, self._c_dynamics(), result, getattr(self, '_pic_events', None)),
+                   'die_pic_forward_env_step')
+        ag._forward_consumed(action)
+        self.medium.owner_stale = self._mark_owner
+        return True
+
+    def _mark_owner(self):
+        """Rebuild the 'agents' channel (claim plane) from the agent arrays after tile-binned steps."""
+        M = self.medium
+        M.next_epoch()
+        m, a = M.c_struct(need_owner=False), self.agents.c_struct()
+        _lib.check(_lib.lib.die_agents_mark_owner(C.byref(m), C.byref(a), stream_ptr(self.device)), 'die_agents_mark_owner')
 
     # ------------------------------------------------------------------ many steps without the host in the loop
     def run(self, agent, n_steps: int, graph: Optional[bool] = None) -> torch.Tensor:

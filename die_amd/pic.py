@@ -1,0 +1,112 @@
+"""Host side of the tile-binned step (csrc/die_pic.hip, include/die_hip.h `die_pic`): buffers of the two agent layouts,
+(re)binning, and the per-step swap of the array handles.  No reference counterpart: the reference keeps agents in slot
+order (core/data_init.py:133-150); here the order of the arrays is free (results are keyed by slot id) and this path
+keeps it exactly tile-sorted so that `Env.step` needs no claim plane."""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from .device_array import _ptr, stream_ptr
+
+TILE_SHAPES = ((6, 6), (5, 6), (4, 5))        # log2 (rows, columns), in order of preference; (5, 7) by request only
+
+
+def pick_tile(W: int, H: int, reach_cells: float) -> Optional[Tuple[int, int]]:
+    """Largest compiled tile shape that cuts the world into at least 3×3 whole tiles and is wider than a step."""
+    for xs, ys in TILE_SHAPES:
+        TX, TY = 1 << xs, 1 << ys
+        if W % TX == 0 and H % TY == 0 and W // TX >= 3 and H // TY >= 3 and reach_cells <= min(TX, TY) - 1:
+            return xs, ys
+    return None
+
+
+class PicState:
+    def __init__(self, env, tile: Tuple[int, int]):
+        self.xs, self.ys = tile
+        W, H = env._field_size
+        self.NT = int(_lib.lib.die_pic_tiles(W, H, self.xs, self.ys))
+        if self.NT <= 0:
+            raise ValueError(f'tile shape 2^{tile} is not available')
+        dev, N = env.device, env.agents.N
+        self.N = N
+        self.meta = [torch.zeros((4, self.NT), dtype=torch.int32, device=dev) for _ in range(2)]     # off, n, s, inc
+        self.dep = torch.empty(N, dtype=torch.float32, device=dev)
+        self.dep_plane = torch.empty((W, H), dtype=torch.float32, device=dev)
+        self.part = torch.zeros(self.NT, dtype=torch.int64, device=dev)
+        self.error = torch.zeros(2 + 16 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
+        self.spare = [torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev),
+                      torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)]
+        self.k1_threads = 0          # tuning knob of die_pic (0 = library default)
+        self.cur = 0                 # layout index that holds the agents
+        self.held = None             # (x, y, agent_food, slot, heading) tensors of layout[cur] — identity = validity
+        self.agent = None
+
+    # ------------------------------------------------------------------
+    def _layout(self, tensors, meta) -> _lib.PicLayout:
+        x, y, af, slot, hd = tensors
+        return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hd), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
+
+    def _struct(self, cur_tensors, other_tensors, stages: int = 0) -> _lib.Pic:
+        lay = [None, None]
+        lay[self.cur] = self._layout(cur_tensors, self.meta[self.cur])
+        lay[1 - self.cur] = self._layout(other_tensors, self.meta[1 - self.cur])
+        return _lib.Pic(self.xs, self.ys, self.N, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self.dep_plane), _ptr(self.part),
+                        _ptr(self.error), self.k1_threads, stages)
+
+    def is_current(self, env, agent) -> bool:
+        A, h = env.agents, self.held
+        return h is not None and self.agent is agent and A.x is h[0] and A.y is h[1] and A.agent_food is h[2] and A.slot is h[3] and \
+            agent._direction_rads is h[4] and agent._order is A.slot
+
+    def _adopt(self, env, agent, new):
+        """The agents now live in `new` = (x, y, agent_food, slot, heading): hand the arrays to their owners and keep the
+        old ones as the next step's output buffers (the slot array is never reused: actions may still refer to it)."""
+        A = env.agents
+        self.spare = [A.x, A.y, A.agent_food, agent._direction_rads]
+        A.x, A.y, A.agent_food, A.slot = new[0], new[1], new[2], new[3]
+        agent._direction_rads = new[4]
+        agent._order = A.slot
+        self.held, self.agent = tuple(new), agent
+
+    def _out_tensors(self, env):
+        slot = torch.empty(self.N, dtype=torch.int32, device=env.device)
+        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3])
+
+    def bin(self, env, agent):
+        """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset."""
+        A = env.agents
+        out = self._out_tensors(env)
+        cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._direction_rads)
+        p = self._struct(cur_t, out)
+        m, a = env.medium.c_struct(need_owner=False), A.c_struct()
+        _lib.check(_lib.lib.die_pic_bin(C.byref(m), C.byref(a), _ptr(agent._direction_rads), C.byref(p), 1 - self.cur,
+                                        stream_ptr(env.device)), 'die_pic_bin')
+        self.cur = 1 - self.cur
+        self._adopt(env, agent, out)
+
+    def step(self, env, agent, action, dyn, result, events=None):
+        """One step.  `events`: four torch.cuda.Event objects — the three launches are then issued by three calls
+        (die_pic.stages) with an event between them, so that bench.py times each kernel inside real steps."""
+        out = self._out_tensors(env)
+        m, u = env.medium.c_struct(need_owner=False), action.raw_struct()
+        for i, stages in enumerate((0,) if events is None else (1, 2, 4)):
+            p = self._struct(self.held, out, stages)
+            if events is not None:
+                events[i].record()
+            rc = _lib.lib.die_pic_forward_env_step(C.byref(m), C.byref(p), self.cur, C.byref(action.g_struct), C.byref(u), C.byref(dyn),
+                                                   _ptr(result), stream_ptr(env.device))
+            if rc != 0:
+                return rc
+        if events is not None:
+            events[3].record()
+        self.cur = 1 - self.cur
+        self._adopt(env, agent, out)
+        return 0
+
+    def check(self):
+        """After a synchronisation: did every agent stay within its tile's neighbourhood?"""
+        e = int(self.error[0].item())
+        if e:
+            raise RuntimeError(f'tile-binned step: bookkeeping error {e} (an agent moved further than one tile in a step)')

@@ -314,6 +314,54 @@ int die_agents_sort(const die_medium* m, const die_agents* in, const die_agents*
                     const float* const* extra_in, float* const* extra_out, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* ---- tile-binned step (die_pic.hip; no reference counterpart for the data structure) --------------------------------
+ * The fast path of `env.step(agent.forward(obs))` (examples/minimal_run.py:24-25) for worlds in which every slot is alive
+ * and an agent moves less than a tile per step: the agent arrays are kept in EXACT tile order (tiles of 2^tile_xs ×
+ * 2^tile_ys cells; 64×64, 32×128, 32×64 and 16×32 are compiled in), "last writer wins" of core/env.py:211 is resolved in LDS
+ * and the field sweep reads a 4-byte deposit plane — no claim plane, no global atomics on cells.  Same bits as
+ * die_forward_env_step.  A layout = the per-agent arrays plus per-tile words: segment offset / size, number of stayers
+ * (agents of the segment that stand on the tile; the rest have walked onto a neighbouring tile), arrivals.  The step reads
+ * layout[from] and writes layout[1 - from]; the caller alternates.  The 'agents' channel (m->owner) is NOT maintained by this
+ * path: die_agents_mark_owner rebuilds it on demand. */
+typedef struct die_pic_layout {
+    uint32_t* x;             /* N, Q0.32 */
+    uint32_t* y;
+    float* agent_food;       /* N */
+    uint32_t* slot;          /* N, reference slot ids (always materialised) */
+    float* heading;          /* N, the agent object's _direction_rads in this order */
+    uint32_t *off, *n, *s, *inc;   /* die_pic_tiles() words each */
+} die_pic_layout;
+
+typedef struct die_pic {
+    int32_t tile_xs, tile_ys;    /* log2 of the tile shape */
+    int64_t N;                   /* agents = slots, all alive */
+    die_pic_layout layout[2];
+    float* dep;                  /* N floats of scratch */
+    float* dep_plane;            /* W*H: per cell the deposit of the highest slot standing on it, or 0xFFFFFFFF */
+    void* part_gain;             /* die_pic_tiles() 64-bit words: reward partials (also the binning scratch) */
+    uint32_t* error;             /* device word, 0 = fine; non-zero after a step: an agent moved further than a tile */
+    int32_t k1_threads;          /* tuning: workgroup size of the agent kernel (multiple of 64, <= 512); 0 = default */
+    int32_t stages;              /* 0 = the whole step; else a bit mask of the launches to run (per-kernel timing: bench.py):
+                                    1 agent kernel (repeatable: reads layout[from] only), 2 claim resolution + next offsets,
+                                    4 field sweep */
+} die_pic;
+
+/* number of tiles (words per per-tile array), or -1 if the shape is not compiled in */
+int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
+/* Bin agents held in any order (die_agents; `heading` in the same order) into layout[into]; both layouts' per-tile words
+ * are initialised.  DIE_ERR_UNSUPPORTED unless the world splits into at least 3×3 whole tiles. */
+int die_pic_bin(const die_medium* m, const die_agents* a, const float* heading, const die_pic* p, int32_t into, void* stream);
+/* GradientAgent/PhysarumAgent.forward (core/agent/gradient.py:96-124) + Env.step (core/env.py:101-131) on binned agents:
+ * three launches (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  The
+ * agent state (g->heading is ignored: layout[from].heading) moves with the agents; `act` receives the action in the order
+ * of layout[from].  Requires: every slot alive, no agents_die / sense mask, normalised gradient without inertia or noise
+ * and |scale| * (max(W, H) - 1) <= tile - 1 (else DIE_ERR_UNSUPPORTED / DIE_ERR_ARG: use die_forward_env_step). */
+int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g, const die_action* act,
+                             const die_dynamics* d, die_step_result* result, void* stream);
+/* Rebuild the 'agents' channel from the agent arrays: atomicMax of (m->epoch, slot) claims (deposit bits 0) for every
+ * alive agent.  The caller advances m->epoch (or zeroes the plane) first. */
+int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream);
+
 /* ---- message packing for decomposed worlds (die_amd/dist.py; no reference counterpart) ----------
  * A block [r0, r1) x [c0, c1) of a row-major plane (pitch in elements, 2/4/8-byte elements) copied
  * to / from byte offset buf_offset of one contiguous message buffer; up to 16 blocks per launch. */

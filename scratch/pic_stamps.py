@@ -1,0 +1,22 @@
+"""Phase shares of k_pic_forward_move from a -DPIC_STAMPS build (scratch/libs/libdie_stamps.so): s_memtime at the phase
+boundaries of wave 0 of every tile's workgroup.  Shares only — the stamped build is not the shipped kernel."""
+import os, sys
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+import numpy as np, torch
+import die_amd
+W = 4096
+env = die_amd.Env((W, W), die_amd.Dynamics(init_agent_ratio=0.15), seed=1234, max_agents='alive', sync=False)
+ag = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=1234, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+obs = env._get_current_obs
+for _ in range(40):
+    obs, *_ = env.step(ag.forward(obs))
+torch.cuda.synchronize()
+st = env._pic.error[2:].cpu().numpy().view(np.uint64).reshape(-1, 8)[:, :6].astype(np.float64)
+d = np.diff(st, axis=1)
+names = ['meta+stage issue/wait', 'ranges (2 barriers)', 'filter arrivals + barrier', 'chunk loop (wave 0)', 'final barrier']
+tot = st[:, 5] - st[:, 0]
+print('s_memtime ticks (100 MHz => 10 ns each) per tile workgroup, mean / median / p95')
+for i, n in enumerate(names):
+    print(f'  {n:28s} {d[:, i].mean():8.1f} {np.median(d[:, i]):8.1f} {np.percentile(d[:, i], 95):8.1f}   {100 * d[:, i].sum() / tot.sum():5.1f} %')
+print(f'  {"total":28s} {tot.mean():8.1f} {np.median(tot):8.1f} {np.percentile(tot, 95):8.1f}')
+print('kernel span (first start .. last end):', st[:, 5].max() - st[:, 0].min())

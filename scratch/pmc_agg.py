@@ -16,5 +16,5 @@ for d in sys.argv[1:]:
                     per[did] += v
                 out[k][c] = round(sum(per.values()) / len(per), 1)
                 out[k]['launches'] = len(per)
-keep = {k: v for k, v in out.items() if any(s in k for s in ('forward_move_claim', 'diffuse_rows', 'k_reduce'))}
+keep = {k: v for k, v in out.items() if any(s in k for s in ('forward_move', 'diffuse_rows', 'k_reduce', 'k_pic_'))}
 print(json.dumps(keep, indent=1))

@@ -445,6 +445,58 @@ def test_staged_path_gives_identical_results(die):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('W,H,boundary,f16,tile', [(128, 96, 'wrap', False, (4, 5)), (192, 256, 'limit', False, (6, 6)),
+                                                   (256, 192, 'wrap', True, (5, 6)), (96, 384, 'wrap', False, (5, 7))])
+def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile):
+    """The tile-binned fast path (die_pic_forward_env_step: agents in exact tile order, claims resolved in LDS, deposit
+    plane instead of the claim plane) against the classic fused step: every output bit for bit — fields, ownership,
+    agents, headings, the actions handed back, rewards — with collisions, every compiled tile shape, a mid-run switch
+    between the paths and a re-bin after the arrays were re-ordered behind its back."""
+    N = K = 9000
+    rs = np.random.RandomState(W + H)
+    medium, agents = random_state(W, H, N, K, rs, collide=0.4)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    outs = []
+    for pic in (True, False):
+        env = die.Env.from_numpy(medium, agents, die.Dynamics(boundary=die.BoundaryCondition(boundary)), sort_every=3, pic=pic,
+                                 field_dtype=torch.float16 if f16 else torch.float32)
+        env._pic_tile = tile if pic else None
+        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        acts, rewards = [], []
+        for i in range(11):
+            if i == 4:
+                env._pic_enabled = False                       # classic steps in between: the arrays get re-sorted
+            if i == 7:
+                env._pic_enabled = pic                         # … and the binned path has to re-bin
+            action = ag.forward(obs)
+            obs, rew, _, _, info = env.step(action)
+            acts.append(action.to_numpy())
+            rewards.append((rew, info['num_agents']))
+            if pic and i in (0, 3, 7, 10):
+                assert env._pic is not None and env._pic.held[0] is env.agents.x, 'the tile-binned path did not run'
+                assert (env._pic.xs, env._pic.ys) == tile
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), env.medium.owner_slots().cpu().numpy(),
+                     np.stack(acts), np.array(rewards)))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'owners', 'actions', 'rewards'), outs[0], outs[1]):
+        assert np.array_equal(a, b), name
+
+
+def test_tile_binned_step_refuses_long_steps(die):
+    """A step longer than a tile cannot use the binned path: the env silently takes the classic one."""
+    W, H, N = 128, 96, 3000
+    rs = np.random.RandomState(3)
+    medium, agents = random_state(W, H, N, N, rs)
+    env = die.Env.from_numpy(medium, agents)
+    ag = die.PhysarumAgent(max_agents=N, seed=5, scale=0.2, sense_offset=0.03)
+    obs = env._get_current_obs
+    for _ in range(3):
+        obs, *_ = env.step(ag.forward(obs))
+    assert env._pic is None and env._pic_tile is False
+
+
 @pytest.mark.parametrize('kind', ['physarum', 'gradient'])
 def test_fused_forward_step_equals_separate_calls(die, kind):
     """`env.step(agent.forward(obs))` runs forward inside die_forward_env_step; with `agent.lazy = False`
