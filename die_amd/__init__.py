@@ -6,12 +6,12 @@ All compute runs in libdie_hip.so (hand-written HIP for gfx950, include/die_hip.
 importing this package fails if that library is missing — there is no CPU fallback.
 """
 from . import _lib
-from .agent import Agent, BrownianAgent, ConstAgent, GradientAgent, PhysarumAgent
+from .agent import Agent, BrownianAgent, ConstAgent, ConvolutionModel, GradientAgent, NeuralAutomataAgent, PhysarumAgent
 from .base_types import DataChannels
 from .data_init import DataInitializer, WaveSequence
 from .device_array import DeviceAction, DeviceAgents, DeviceMedium
 from .env import BoundaryCondition, Dynamics, Env, linear_action_cost, zero_cost
 
 __all__ = ['WaveSequence', 'Env', 'Dynamics', 'BoundaryCondition', 'linear_action_cost', 'zero_cost', 'Agent', 'PhysarumAgent',
-           'GradientAgent', 'BrownianAgent', 'ConstAgent', 'DataInitializer', 'DataChannels', 'DeviceMedium',
+           'GradientAgent', 'BrownianAgent', 'ConstAgent', 'NeuralAutomataAgent', 'ConvolutionModel', 'DataInitializer', 'DataChannels', 'DeviceMedium',
            'DeviceAgents', 'DeviceAction']

@@ -54,6 +54,13 @@ class GradientAgent(C.Structure):
                 ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32), ('step_base', C.c_void_p)]
 
 
+class ConvPlane(C.Structure):
+    _fields_ = [('data', C.c_void_p), ('kind', C.c_int32), ('reserved', C.c_int32)]
+
+
+DIE_PLANE_F32, DIE_PLANE_F16, DIE_PLANE_AGENTS = 0, 1, 2
+
+
 class PicLayout(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('agent_food', C.c_void_p), ('slot', C.c_void_p), ('heading', C.c_void_p),
                 ('off', C.c_void_p), ('n', C.c_void_p), ('s', C.c_void_p), ('inc', C.c_void_p)]
@@ -146,6 +153,9 @@ _SIGNATURES = {
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),
+    'die_conv2d_circular': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,
+                                      C.c_void_p, C.c_int32, C.c_void_p]),
+    'die_gather_scale': (C.c_int, [_P(Medium), _P(Agents), _P(C.c_void_p), _P(C.c_float), _P(Action), C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,
                                   C.c_int64, C.c_void_p]),

@@ -362,6 +362,25 @@ int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from
  * alive agent.  The caller advances m->epoch (or zeroes the plane) first. */
 int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream);
 
+/* ---- NeuralAutomataAgent sensing (core/agent/evo.py:45-118,150-174; die_nca.hip) -----------------------------------
+ * One layer of ConvolutionModel: a bias-free Conv2d with 'same' circular padding over (channel, x, y) planes,
+ *   out[o, x, y] = sum_i sum_a sum_b w[o, i, a, b] * in[i, (x + a - r) mod W, (y + b - r) mod H],  r = k / 2,
+ * k odd (1, 3, 5, 7), at most 4 channels in and out, weights (cout, cin, k, k) fp32 in device memory; the last layer of the
+ * stack applies tanh (:97-99).  Input planes may be the medium's own: fp32 / fp16 fields, or the 'agents' channel read
+ * from the claim plane (occupied cells are 1.0; `epoch` = die_medium.epoch).  Outputs are fp32 planes, never an input. */
+typedef enum die_plane_kind { DIE_PLANE_F32 = 0, DIE_PLANE_F16 = 1, DIE_PLANE_AGENTS = 2 } die_plane_kind;
+typedef struct die_conv_plane {
+    const void* data;
+    int32_t kind;            /* die_plane_kind */
+    int32_t reserved;
+} die_conv_plane;
+int die_conv2d_circular(int32_t W, int32_t H, int32_t cin, const die_conv_plane* in, int32_t epoch, int32_t cout,
+                        float* const* out, int32_t k, const float* weights, int32_t apply_tanh, void* stream);
+/* NeuralAutomataAgent.forward's per-agent read-out (core/agent/evo.py:161-170, core/utils.py:56-65): for EVERY slot
+ * action[c, n] = planes[c][cell(x_n), cell(y_n)] * coefs[c], c = dx, dy, deposit1. */
+int die_gather_scale(const die_medium* m, const die_agents* a, const float* const* planes, const float* coefs,
+                     const die_action* out, void* stream);
+
 /* ---- message packing for decomposed worlds (die_amd/dist.py; no reference counterpart) ----------
  * A block [r0, r1) x [c0, c1) of a row-major plane (pitch in elements, 2/4/8-byte elements) copied
  * to / from byte offset buf_offset of one contiguous message buffer; up to 16 blocks per launch. */

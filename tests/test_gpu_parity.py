@@ -1065,3 +1065,55 @@ def test_minimal_run_example(die):
     total, env = mod.run_minimal(die.PhysarumAgent(max_agents=64 * 64, scale=0.006, turn_angle=30, sense_offset=0.04, seed=1),
                                  agent_ratio=0.15, field_size=(64, 64), iters=20, seed=1)
     assert np.isfinite(total) and float(env.medium.chem.max()) > 0
+
+
+# ------------------------------------------------------------------------------------ NeuralAutomataAgent sensing
+@pytest.mark.parametrize('W,H', [(12, 12), (96, 96), (12, 8), (250, 132)])
+@pytest.mark.parametrize('kernel_sizes', [(3,), (5,), (3, 3), (3, 5), (3, 5, 3), (7, 1)])
+def test_neural_automata_forward_parity(die, W, H, kernel_sizes):
+    """NeuralAutomataAgent.forward on the device (die_conv2d_circular per layer + die_gather_scale) against the oracle
+    (float64; itself pinned to torch's Conv2d in tests/test_nca_cpu.py) and against the torch evaluation of the same
+    model in fp32: the transformed medium and the action within 1e-5 (north-star tolerance; tanh output is O(1), so atol =
+    1e-5 as well).  Field sizes and kernel stacks of the reference's own model tests (test/unit/agent.py:11,30-31)."""
+    import torch as th
+    N, K = max(W * H // 3, 8), max(W * H // 5, 4)
+    rs = np.random.RandomState(W * 31 + H + len(kernel_sizes))
+    medium, agents = random_state(W, H, N, K, rs, collide=0.2)
+    th.manual_seed(W + H)
+    for with_agents in (True, False):
+        ag = die.NeuralAutomataAgent(scale=0.07, deposit=1.5, with_agent_channel=with_agents, kernel_sizes=kernel_sizes)
+        ag.model.init_weights()
+        env = die.Env.from_numpy(medium, agents)
+        action = ag.forward(env._get_current_obs)
+        ws = [k.weight.detach().numpy().astype(np.float64) for k in ag.model.conv_layers()]
+        want_sense = R.nca_sense(medium, ws, with_agents)
+        got_sense = ag._sense_output.cpu().numpy().astype(np.float64)
+        assert np.allclose(got_sense, want_sense, rtol=RTOL, atol=1e-5)
+        want = R.nca_forward((agents, medium), ws, 0.07, 1.5, with_agents)
+        assert np.allclose(action.to_numpy(), want, rtol=RTOL, atol=1e-5)
+        x = th.from_numpy((medium if with_agents else medium[1:]).astype(np.float32))[None]
+        assert np.allclose(got_sense, ag.model.forward(x)[0].detach().numpy(), rtol=RTOL, atol=1e-5)
+        assert ag.render()[0].shape == (W, H, 3)
+        # the action drives an env step like any other
+        env.step(action)
+
+
+def test_neural_automata_on_f16_fields_and_after_binned_steps(die):
+    """fp16 field planes are read directly; after tile-binned steps (claim plane not maintained) the 'agents' channel is
+    rebuilt before it is sensed."""
+    W, H, N = 128, 96, 4000
+    rs = np.random.RandomState(5)
+    medium, agents = random_state(W, H, N, N, rs)
+    env = die.Env.from_numpy(medium, agents, field_dtype=torch.float16)
+    phys = die.PhysarumAgent(max_agents=N, seed=1, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    obs = env._get_current_obs
+    for _ in range(3):
+        obs, *_ = env.step(phys.forward(obs))
+    assert env._pic is not None and env.medium.owner_stale is not None
+    nca = die.NeuralAutomataAgent(kernel_sizes=(3, 3))
+    nca.model.init_weights()
+    action = nca.forward(obs)
+    m, a = env.medium.to_numpy(), env.agents.to_numpy()
+    ws = [k.weight.detach().numpy().astype(np.float64) for k in nca.model.conv_layers()]
+    assert m[0].sum() > 0
+    assert np.allclose(action.to_numpy(), R.nca_forward((a, m), ws), rtol=RTOL, atol=1e-5)
