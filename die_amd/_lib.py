@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class Medium(C.Structure):
@@ -48,8 +48,8 @@ class Dynamics(C.Structure):
 class GradientAgent(C.Structure):
     _fields_ = [('kind', C.c_int32), ('normalized_grad', C.c_int32), ('scale', C.c_float), ('deposit', C.c_float),
                 ('inertia', C.c_float), ('sense_offset', C.c_float), ('noise_scale', C.c_float),
-                ('grad_clip', C.c_float), ('turn_radians', C.c_float), ('sense_radians', C.c_float),
-                ('turn_tolerance', C.c_float), ('reserved', C.c_int32), ('heading', C.c_void_p),
+                ('grad_clip', C.c_float), ('turn_radians', C.c_double), ('sense_radians', C.c_double),
+                ('turn_tolerance', C.c_double), ('heading_hi', C.c_void_p), ('heading_lo', C.c_void_p),
                 ('prev_gx', C.c_void_p), ('prev_gy', C.c_void_p), ('turn_sign', C.c_void_p),
                 ('seed', C.c_uint64), ('step', C.c_uint32), ('reserved2', C.c_uint32), ('step_base', C.c_void_p)]
 
@@ -62,7 +62,8 @@ DIE_PLANE_F32, DIE_PLANE_F16, DIE_PLANE_AGENTS = 0, 1, 2
 
 
 class PicLayout(C.Structure):
-    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('agent_food', C.c_void_p), ('slot', C.c_void_p), ('heading', C.c_void_p),
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('agent_food', C.c_void_p), ('slot', C.c_void_p), ('heading_hi', C.c_void_p),
+                ('heading_lo', C.c_void_p),
                 ('off', C.c_void_p), ('n', C.c_void_p), ('s', C.c_void_p), ('inc', C.c_void_p)]
 
 
@@ -127,7 +128,7 @@ _SIGNATURES = {
                                     C.c_void_p]),
     'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),
     'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
-    'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_uint64, C.c_void_p]),
+    'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p]),
     'die_food_flow_wave': (C.c_int, [_P(Medium), C.c_double, C.c_double, C.c_double, C.c_void_p]),
     'die_sense_mask': (C.c_int, [_P(Medium), C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'die_render_frames': (C.c_int, [_P(Medium), C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -149,7 +150,7 @@ _SIGNATURES = {
     'die_ghost_apply': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, _P(C.c_int64), _P(C.c_int64),
                                   _P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_pic_tiles': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
-    'die_pic_bin': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
+    'die_pic_bin': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),

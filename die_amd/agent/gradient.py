@@ -15,6 +15,16 @@ from ..device_array import DeviceAction, PendingAction, _ptr, stream_ptr
 from .base import Agent, save_args
 
 
+def split64(t64: torch.Tensor):
+    """float64 (N,) → (hi, lo) int32 (N,) tensors: the two halves of every value (die_gradient_agent.heading_hi / _lo)."""
+    v = t64.to(torch.float64).contiguous().view(torch.int32).reshape(-1, 2)       # little endian: [lo, hi]
+    return v[:, 1].contiguous(), v[:, 0].contiguous()
+
+
+def join64(hi: torch.Tensor, lo: torch.Tensor) -> torch.Tensor:
+    return torch.stack([lo, hi], dim=1).contiguous().view(torch.float64).reshape(-1)
+
+
 class GradientAgent(Agent):
     _kind = _lib.DIE_AGENT_GRADIENT
 
@@ -43,7 +53,10 @@ class GradientAgent(Agent):
         self._sense_radians = 0.0
         self._rtol = 0.0
         self._calls = 0
-        self._direction_rads: Optional[torch.Tensor] = None     # allocated on first forward (needs the device)
+        # `_direction_rads` is float64 like the reference's; on the device it is held as two int32 arrays (high / low
+        # halves), which lets it travel through the 4-byte sort / migration machinery.  Allocated on first forward.
+        self._hd_hi: Optional[torch.Tensor] = None
+        self._hd_lo: Optional[torch.Tensor] = None
         self._prev_grad: Optional[torch.Tensor] = None
         self._turn_sign: Optional[torch.Tensor] = None            # test hook: per-slot ±1 instead of Philox
         self._order: Optional[torch.Tensor] = None                # slot tensor the state arrays are aligned with
@@ -55,30 +68,36 @@ class GradientAgent(Agent):
     def init_params(self) -> Dict[str, Any]:
         return self._init_params
 
+    @property
+    def _direction_rads(self) -> Optional[torch.Tensor]:
+        """The headings as one float64 tensor in the current array order (read-only view of the two halves)."""
+        return None if self._hd_hi is None else join64(self._hd_hi, self._hd_lo)
+
     def _alloc_state(self, device):
         """__init__ state of the reference (:42-43,163): heading from N(0, .4) noise."""
-        self._direction_rads = torch.empty(self._size, dtype=torch.float32, device=device)
+        self._hd_hi = torch.empty(self._size, dtype=torch.int32, device=device)
+        self._hd_lo = torch.empty(self._size, dtype=torch.int32, device=device)
         if self._inertia != 0:
             self._prev_grad = torch.empty((2, self._size), dtype=torch.float32, device=device)
         pg = self._prev_grad
-        _lib.check(_lib.lib.die_init_heading(_ptr(self._direction_rads), _ptr(pg[0]) if pg is not None else None,
+        _lib.check(_lib.lib.die_init_heading(_ptr(self._hd_hi), _ptr(self._hd_lo), _ptr(pg[0]) if pg is not None else None,
                                              _ptr(pg[1]) if pg is not None else None, self._size,
                                              float(self._turn_radians), self._seed & 0xFFFFFFFFFFFFFFFF,
                                              stream_ptr(device)), 'die_init_heading')
 
     # -- per-slot state follows the agents' array order (Env.sort_agents) ---------------------
     def _die_state_tensors(self, agents):
-        if self._direction_rads is None or self._order is not agents.slot:
+        if self._hd_hi is None or self._order is not agents.slot:
             return []
-        ts = [self._direction_rads]
+        ts = [self._hd_hi, self._hd_lo]
         if self._prev_grad is not None:
             ts += [self._prev_grad[0], self._prev_grad[1]]
         return ts
 
     def _die_state_permuted(self, tensors, slot):
-        self._direction_rads = tensors[0]
+        self._hd_hi, self._hd_lo = tensors[0], tensors[1]
         if self._prev_grad is not None:
-            self._prev_grad = torch.stack([tensors[1], tensors[2]])
+            self._prev_grad = torch.stack([tensors[2], tensors[3]])
         self._order = slot
 
     def _align_to(self, slot):
@@ -87,7 +106,7 @@ class GradientAgent(Agent):
         def move(t):
             v = unpermute(t, self._order)
             return v if slot is None else v[..., slot.to(torch.int64)].contiguous()
-        self._direction_rads = move(self._direction_rads)
+        self._hd_hi, self._hd_lo = move(self._hd_hi), move(self._hd_lo)
         if self._prev_grad is not None:
             self._prev_grad = move(self._prev_grad)
         self._order = slot
@@ -95,23 +114,23 @@ class GradientAgent(Agent):
     def direction_rads_numpy(self) -> np.ndarray:
         """`_direction_rads` in slot order (float64)."""
         from ..device_array import unpermute
-        return unpermute(self._direction_rads, self._order).to(torch.float64).cpu().numpy()
+        return unpermute(self._direction_rads, self._order).cpu().numpy()
 
     def prev_grad_numpy(self) -> np.ndarray:
         from ..device_array import unpermute
         return unpermute(self._prev_grad, self._order).to(torch.float64).cpu().numpy()
 
     def set_state_local(self, agents, direction_rads: torch.Tensor, prev_grad: Optional[torch.Tensor] = None):
-        """Decomposed world: state already in the local array order of `agents` (capacity-sized)."""
-        self._direction_rads = direction_rads
+        """Decomposed world: state already in the local array order of `agents` (capacity-sized; any float dtype)."""
+        self._hd_hi, self._hd_lo = split64(direction_rads)
         self._prev_grad = prev_grad
         self._order = agents.slot
 
     def set_state(self, direction_rads: np.ndarray, prev_grad: Optional[np.ndarray] = None, device='cuda:0'):
         """Load `_direction_rads` (and `_prev_grad`) from host arrays given in slot order."""
         self._order = None
-        self._direction_rads = torch.from_numpy(np.asarray(direction_rads, dtype=np.float32)).to(device)
-        assert self._direction_rads.numel() == self._size
+        self._hd_hi, self._hd_lo = split64(torch.from_numpy(np.ascontiguousarray(direction_rads, dtype=np.float64)).to(device))
+        assert self._hd_hi.numel() == self._size
         if prev_grad is not None:
             self._prev_grad = torch.from_numpy(np.ascontiguousarray(prev_grad, dtype=np.float32)).to(device)
         elif self._inertia != 0:
@@ -127,7 +146,7 @@ class GradientAgent(Agent):
         if agents.capacity != self._size:
             raise ValueError(f'agent built for max_agents={self._size}, observation has {agents.capacity} slots')
         dev = agents.device
-        if self._direction_rads is None:
+        if self._hd_hi is None:
             self._alloc_state(dev)
         if self._order is not agents.slot:
             if agents.global_slots:                # decomposed world: state is kept in local array order
@@ -141,12 +160,12 @@ class GradientAgent(Agent):
         g = _lib.GradientAgent(
             self._kind, int(bool(self._normalized)), self._scale, self._deposit, self._inertia,
             self._sense_offset_scale, self._noise_scale, -1.0 if self._grad_clip is None else self._grad_clip,
-            self._turn_radians, self._sense_radians, self._rtol, 0, _ptr(self._direction_rads),
+            self._turn_radians, self._sense_radians, self._rtol, _ptr(self._hd_hi), _ptr(self._hd_lo),
             _ptr(pg[0]) if pg is not None else None, _ptr(pg[1]) if pg is not None else None,
             _ptr(self._turn_sign), self._seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF, 0,
             _ptr(self._step_base))
         self._calls += 1
-        action = PendingAction(self, agents, medium, g, (self._direction_rads, pg, self._turn_sign))
+        action = PendingAction(self, agents, medium, g, (self._hd_hi, self._hd_lo, pg, self._turn_sign))
         self._pending = action
         if not self.lazy:
             action.ensure()

@@ -12,8 +12,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;     // reference slot id: keys the random streams
-        const FwdOut o = die_forward_agent<T, KIND>(a, a.x[n], a.y[n], a.heading[n], sid, n);
-        a.heading[n] = o.heading;
+        const FwdOut o = die_forward_agent<T, KIND>(a, a.x[n], a.y[n], die_heading_ld(a.heading_hi, a.heading_lo, n), sid, n);
+        die_heading_st(a.heading_hi, a.heading_lo, n, o.heading);
         a.dx[n] = o.dx;
         a.dy[n] = o.dy;
         a.dep[n] = o.dep;
@@ -67,13 +67,13 @@ int die_fill_fwd_args(FwdArgs& k, const die_medium* m, const die_agents* a, cons
     DIE_REQUIRE(a->N > 0, "%s: no agent slots", who);
     DIE_REQUIRE(!out || (out->N == a->N && out->dx && out->dy && out->deposit), "%s: action has %lld slots, agents %lld",
                 who, (long long)(out ? out->N : 0), (long long)a->N);
-    DIE_REQUIRE(m->chem && m->food && a->x && a->y && g->heading, "%s: null device pointer", who);
+    DIE_REQUIRE(m->chem && m->food && a->x && a->y && g->heading_hi && g->heading_lo, "%s: null device pointer", who);
     DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "%s: bad field dtype %d", who, m->dtype);
     DIE_REQUIRE(g->kind == DIE_AGENT_GRADIENT || g->kind == DIE_AGENT_PHYSARUM, "%s: bad kind %d", who, g->kind);
     DIE_REQUIRE(g->inertia == 0.f || (g->prev_gx && g->prev_gy), "%s: inertia needs prev_gx/prev_gy", who);
     k.g = geo; k.N = a->N;
     k.chem = m->chem; k.food = m->food; k.mask = m->sense_mask; k.x = a->x; k.y = a->y; k.slot = a->slot;
-    k.heading = g->heading; k.pgx = g->prev_gx; k.pgy = g->prev_gy; k.turn_sign = g->turn_sign;
+    k.heading_hi = g->heading_hi; k.heading_lo = g->heading_lo; k.pgx = g->prev_gx; k.pgy = g->prev_gy; k.turn_sign = g->turn_sign;
     k.dx = out ? out->dx : nullptr; k.dy = out ? out->dy : nullptr; k.dep = out ? out->deposit : nullptr;
     k.scale = g->scale; k.deposit = g->deposit; k.inertia = g->inertia; k.sense_offset = g->sense_offset;
     k.noise_scale = g->noise_scale; k.grad_clip = g->grad_clip; k.turn_rad = g->turn_radians;

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) void k_forward_move_claim(FwdArgs f
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
         const uint32_t X = a.x[n], Y = a.y[n];
-        const FwdOut o = die_forward_agent<T, KIND, EXT>(f, X, Y, f.heading[n], sid, n);
-        f.heading[n] = o.heading;
+        const FwdOut o = die_forward_agent<T, KIND, EXT>(f, X, Y, die_heading_ld(f.heading_hi, f.heading_lo, n), sid, n);
+        die_heading_st(f.heading_hi, f.heading_lo, n, o.heading);
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
         gsum += die_fix(move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt));
     }
@@ -262,9 +262,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < DIF_TX * LWV; idx += DIE_BLOCK) {
         const int i = idx / LWV, j = idx - i * LWV;
-        float t = 0.f;
+        float t = a.w[R] * s_in[(i + R) * LW + j];            // scipy's correlate1d on a symmetric kernel: the centre, then
 #pragma unroll
-        for (int k = 0; k <= 2 * R; ++k) t += a.w[k] * s_in[(i + k) * LW + j];
+        for (int k = 0; k < R; ++k) t += (s_in[(i + k) * LW + j] + s_in[(i + 2 * R - k) * LW + j]) * a.w[k];   // pairs, outermost first
         s_mid[i * LW + j] = t;
     }
     __syncthreads();
@@ -272,9 +272,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_diffuse(DiffuseArgs a) {
         const int i = idx / DIF_TY, j = idx - i * DIF_TY;
         const int gx = x0 + i, gy = y0 + j;
         if (gx < W && gy < H) {
-            float o = 0.f;
+            float o = a.w[R] * s_mid[i * LW + j + R];
 #pragma unroll
-            for (int k = 0; k <= 2 * R; ++k) o += a.w[k] * s_mid[i * LW + j + k];
+            for (int k = 0; k < R; ++k) o += (s_mid[i * LW + j + k] + s_mid[i * LW + j + 2 * R - k]) * a.w[k];
             die_st(dst, (int64_t)gx * H + gy, o * a.keep);
         }
     }
@@ -461,9 +461,9 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
         float xf[4 + 2 * 4];                                   // [4 − R .. 4 + 4 + R): own 4 at [4..8)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float t = 0.f;
+            float t = a.w[R] * win[R][j];                      // centre, then symmetric pairs from the outermost inwards: mirror
 #pragma unroll
-            for (int k = 0; k <= 2 * R; ++k) t += a.w[k] * win[k][j];
+            for (int k = 0; k < R; ++k) t += (win[k][j] + win[2 * R - k][j]) * a.w[k];      // cells get identical sums, as in scipy
             xf[4 + j] = t;
         }
 #pragma unroll
@@ -475,9 +475,9 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float t = 0.f;
+                float t = a.w[R] * xf[4 + j];
 #pragma unroll
-                for (int k = 0; k <= 2 * R; ++k) t += a.w[k] * xf[4 + j - R + k];
+                for (int k = 0; k < R; ++k) t += (xf[4 + j - R + k] + xf[4 + j + R - k]) * a.w[k];
                 o[j] = t * a.keep;
             }
             Vec4<T>::st(dst + (int64_t)(x0 + orow) * H + col, o);

@@ -14,14 +14,16 @@ struct FwdArgs {
     const uint32_t* x;
     const uint32_t* y;
     const uint32_t* slot;
-    float* heading;
+    uint32_t* heading_hi;      // _direction_rads, float64 in two 4-byte halves (die_gradient_agent)
+    uint32_t* heading_lo;
     float* pgx;
     float* pgy;
     const int8_t* turn_sign;
     float* dx;
     float* dy;
     float* dep;
-    float scale, deposit, inertia, sense_offset, noise_scale, grad_clip, turn_rad, sense_rad, rtol;
+    float scale, deposit, inertia, sense_offset, noise_scale, grad_clip;
+    double turn_rad, sense_rad, rtol;
     int normalized;
     uint64_t seed;
     uint32_t step;
@@ -51,11 +53,24 @@ __device__ __forceinline__ void die_sincos(float x, float* s, float* c) {
     *c = ((q + 1) & 2) ? -cc : cc;
 }
 
-// core/utils.py:178-180 for |r| < 3π: into (-π, π]
-__device__ __forceinline__ float renorm_rad(float r) {
-    if (r > DIE_PI_F) r -= DIE_2PI_F;
-    if (r <= -DIE_PI_F) r += DIE_2PI_F;
-    return r;
+// renormalize_radians (core/utils.py:178-180) as numpy evaluates it in float64: (r − π) % (−2π) + π, `%` being
+// np.remainder (fmod, then the result takes the divisor's sign).  Every operation is an IEEE one, so the value — down
+// to the bit that decides an exact tie — is the reference's.
+#define DIE_PI_D 3.141592653589793
+#define DIE_2PI_D 6.283185307179586
+__device__ __forceinline__ double renorm_rad(double r) {
+    double m = fmod(r - DIE_PI_D, -DIE_2PI_D);
+    if (m != 0.0) { if (!(m < 0.0)) m += -DIE_2PI_D; }
+    else m = -0.0;
+    return m + DIE_PI_D;
+}
+
+__device__ __forceinline__ double die_heading_ld(const uint32_t* hi, const uint32_t* lo, int64_t n) {
+    return __hiloint2double((int)hi[n], (int)lo[n]);
+}
+__device__ __forceinline__ void die_heading_st(uint32_t* hi, uint32_t* lo, int64_t n, double d) {
+    hi[n] = (uint32_t)__double2hiint(d);
+    lo[n] = (uint32_t)__double2loint(d);
 }
 
 // np.angle(x + 1j*y) as numpy evaluates it (core/utils.py:158-169): 1j*y is (0·y − 0) + (0 + y)j and the
@@ -67,8 +82,20 @@ __device__ __forceinline__ float die_np_angle(float x, float y) {
     return atan2f(im, re);
 }
 
+// np.angle(x + 1j*y) in float64 for float32 components: exact constants where a component is an exact zero (the
+// symmetric cases in which the reference's decisions are ties), the fp32 arctangent elsewhere (1e-7: a generic angle is
+// that far from every threshold).
+__device__ __forceinline__ double die_np_angle64(float x, float y) {
+    const float re = x + (0.f * y - 0.f);
+    const float im = 0.f + (0.f + y);
+    if (im == 0.f) return copysign((re < 0.f || (re == 0.f && signbit(re))) ? DIE_PI_D : 0.0, (double)im);
+    if (re == 0.f) return copysign(0.5 * DIE_PI_D, (double)im);
+    return (double)atan2f(im, re);
+}
+
 struct FwdOut {
-    float dx, dy, dep, heading;
+    float dx, dy, dep;
+    double heading;
 };
 
 // Reads the 4 chem taps around the probe cell and the food under the agent, decides the turn,
@@ -98,8 +125,9 @@ struct FwdTileMem {
 };
 
 template <typename T, int KIND, bool EXT, class MEM>
-__device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const MEM& mem, const uint32_t X, const uint32_t Y, const float d,
+__device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const MEM& mem, const uint32_t X, const uint32_t Y, const double d64,
                                                        const uint32_t sid, const int64_t n) {
+    const float d = (float)d64;             // trigonometry in fp32 (1e-7 of a cell on the probe), decisions in float64
     const die_geo g = a.g;
     const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
     float sd, cd;
@@ -128,34 +156,35 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     // therefore NOT "undetermined" in the reference.  Keep the signs.
     if (a.grad_clip >= 0.f && !(norm >= a.grad_clip)) { ux = copysignf(0.f, ux); uy = copysignf(0.f, uy); }
 
-    float d_new = d;
+    double d_new = d64;
     float dep_mask = 1.0f;
     bool heading_from_vector = true;
     if (KIND == DIE_AGENT_PHYSARUM) {
-        // _discrete_turn / _choose_turn (gradient.py:168-208)
+        // _discrete_turn / _choose_turn (gradient.py:168-208), in float64 like the reference
         const float dr = sqrtf(ux * ux + uy * uy);
-        const float drads = die_np_angle(ux, uy);
-        const float delta = renorm_rad(d - drads);
-        const float atol = a.turn_rad * a.rtol;
-        const bool und_grad = fabsf(drads) <= 1e-8f + 1e-5f * fabsf(drads);
-        const bool und_turn = fabsf(delta) <= atol + 1e-2f * fabsf(delta);
-        const bool unseen = fabsf(delta) > a.sense_rad;
+        const double drads = die_np_angle64(ux, uy);
+        const double delta = renorm_rad(d64 - drads);
+        const double atol = a.turn_rad * a.rtol;
+        const bool und_grad = fabs(drads) <= 1e-8 + 1e-5 * fabs(drads);
+        const bool und_turn = fabs(delta) <= atol + 1e-2 * fabs(delta);
+        const bool unseen = fabs(delta) > a.sense_rad;
         const bool und = und_grad || und_turn || unseen;
-        float sgn;
+        double sgn;
         if (und) {
-            if (a.turn_sign) sgn = (float)a.turn_sign[sid];
-            else sgn = (die_draw(a.seed, a.step + (a.step_base ? *a.step_base : 0u), (uint64_t)sid, DIE_STREAM_TURN).v[0] & 1u) ? 1.f : -1.f;
+            if (a.turn_sign) sgn = (double)a.turn_sign[sid];
+            else sgn = (die_draw(a.seed, a.step + (a.step_base ? *a.step_base : 0u), (uint64_t)sid, DIE_STREAM_TURN).v[0] & 1u) ? 1.0 : -1.0;
         } else {
-            sgn = delta > atol ? -1.f : 1.f;  // right (clockwise) / left
+            sgn = delta > atol ? -1.0 : 1.0;  // right (clockwise) / left
         }
-        const float d2 = renorm_rad(d + sgn * a.turn_rad);
+        const double d2_64 = renorm_rad(d64 + sgn * a.turn_rad);
+        const float d2 = (float)d2_64;
         float s2, c2;
         die_sincos(d2, &s2, &c2);
         const float r = a.normalized ? 1.f : dr;
         ux = r * c2 - 0.f * s2;                            // polar2xy: (r + 0j)·(cos + i·sin), zero signs included
         uy = r * s2 + 0.f * c2;
         dep_mask = (und_grad || und_turn) ? 0.1f : 1.0f;   // clip(mask, .1, 1) (gradient.py:210-214)
-        d_new = d2;
+        d_new = d2_64;            // (the reference re-derives it as angle(exp(i·d2)): the same value up to one ulp of libm noise)
         heading_from_vector = !a.normalized;               // |g| may be 0 there: angle(0) = 0
     }
     // _process_momentum (gradient.py:82-91)
@@ -181,7 +210,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
         uy += 0.f;
     }
     if (a.pgx) { a.pgx[n] = ux; a.pgy[n] = uy; }
-    if (heading_from_vector) d_new = die_np_angle(ux, uy);    // get_radians (gradient.py:110)
+    if (heading_from_vector) d_new = (double)die_np_angle(ux, uy);    // get_radians (gradient.py:110)
     FwdOut o;
     o.heading = d_new;
     o.dx = ux * a.scale;
@@ -191,7 +220,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
 }
 
 template <typename T, int KIND, bool EXT = true>
-__device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint32_t X, const uint32_t Y, const float d,
+__device__ __forceinline__ FwdOut die_forward_agent(const FwdArgs& a, const uint32_t X, const uint32_t Y, const double d,
                                                    const uint32_t sid, const int64_t n) {
     return die_forward_agent_mem<T, KIND, EXT>(a, FwdGlobalMem<T, EXT>(a), X, Y, d, sid, n);
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_zero_tail(const int64_t* total, i
     }
 }
 
-__global__ __launch_bounds__(DIE_BLOCK) void k_init_heading(float* heading, float* pgx, float* pgy, int64_t N, double turn,
+__global__ __launch_bounds__(DIE_BLOCK) void k_init_heading(uint32_t* hhi, uint32_t* hlo, float* pgx, float* pgy, int64_t N, double turn,
                                                             uint64_t seed) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
@@ -150,7 +150,9 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_init_heading(float* heading, floa
         const double gx = rad * cos(6.283185307179586476925 * u2), gy = rad * sin(6.283185307179586476925 * u2);
         double ang = atan2(gy, gx);
         if (turn > 0.0) ang = floor(ang / turn) * turn;      // discretize (core/utils.py:183-184)
-        heading[n] = (float)ang;
+        const double h = (double)(float)ang;                 // float64 state holding the fp32 rounding of the lattice angle
+        hhi[n] = (uint32_t)__double2hiint(h);
+        hlo[n] = (uint32_t)__double2loint(h);
         if (pgx) { pgx[n] = (float)gx; pgy[n] = (float)gy; }
     }
 }
@@ -207,11 +209,11 @@ extern "C" int die_init_agents(const die_medium* m, const die_agents* a, uint64_
     return DIE_OK;
 }
 
-extern "C" int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, float turn_radians,
+extern "C" int die_init_heading(uint32_t* heading_hi, uint32_t* heading_lo, float* prev_gx, float* prev_gy, int64_t N, double turn_radians,
                                 uint64_t seed, void* stream) {
-    DIE_REQUIRE(heading && N > 0, "die_init_heading: bad arguments");
+    DIE_REQUIRE(heading_hi && heading_lo && N > 0, "die_init_heading: bad arguments");
     DIE_REQUIRE((prev_gx == nullptr) == (prev_gy == nullptr), "die_init_heading: prev_gx/prev_gy must come together");
-    k_init_heading<<<init_grid(N), DIE_BLOCK, 0, (hipStream_t)stream>>>(heading, prev_gx, prev_gy, N, (double)turn_radians,
+    k_init_heading<<<init_grid(N), DIE_BLOCK, 0, (hipStream_t)stream>>>(heading_hi, heading_lo, prev_gx, prev_gy, N, turn_radians,
                                                                           seed);
     DIE_CHECK_LAUNCH("die_init_heading");
     return DIE_OK;

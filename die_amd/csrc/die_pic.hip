@@ -43,7 +43,7 @@ struct PicLayout {
     uint32_t *x, *y;
     float* agent_food;
     uint32_t* slot;
-    float* heading;
+    uint32_t *hhi, *hlo;            // heading, float64 halves
     uint32_t *off, *n, *s, *inc;    // per tile
 };
 
@@ -174,11 +174,11 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f,
     }
     const uint32_t pidx = (uint32_t)(wave * DIE_WAVE + lane);
     const bool phas = pidx < own;
-    uint32_t pX = 0, pY = 0, pS = 0;
-    float pH = 0.f, pA = 0.f;
+    uint32_t pX = 0, pY = 0, pS = 0, pHh = 0, pHl = 0;
+    float pA = 0.f;
     if (phas) {
         const uint32_t j = base0 + pidx;
-        pX = p.in.x[j]; pY = p.in.y[j]; pS = p.in.slot[j]; pH = p.in.heading[j]; pA = p.in.agent_food[j];
+        pX = p.in.x[j]; pY = p.in.y[j]; pS = p.in.slot[j]; pHh = p.in.hhi[j]; pHl = p.in.hlo[j]; pA = p.in.agent_food[j];
     }
     const T* food = (const T*)p.food;
     FwdTileMem<T> tm;
@@ -238,19 +238,22 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f,
             const uint32_t idx = c + lane;
             const bool act = idx < count;
             bool stay = false;
-            uint32_t X = 0, Y = 0, sid = 0;
-            float hd = 0.f, af = 0.f, dep = 0.f;
+            uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0;
+            float af = 0.f, dep = 0.f;
+            double hd = 0.0;
             if (act) {
                 const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
                 if (first && idx < n_own) {
-                    X = pX; Y = pY; sid = pS; hd = pH; af = pA;
+                    X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
                 } else {
-                    X = p.in.x[j];                                 // all five streams in flight together
+                    X = p.in.x[j];                                 // all six streams in flight together
                     Y = p.in.y[j];
                     sid = p.in.slot[j];
-                    hd = p.in.heading[j];
+                    hh = p.in.hhi[j];
+                    hl = p.in.hlo[j];
                     af = p.in.agent_food[j];
                 }
+                hd = __hiloint2double((int)hh, (int)hl);
                 const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
                                        : die_forward_agent<T, KIND, false>(f, X, Y, hd, sid, (int64_t)j);
                 if (p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f,
                     p.out.y[q] = Y;
                     p.out.agent_food[q] = af;
                     p.out.slot[q] = sid;
-                    p.out.heading[q] = hd;
+                    p.out.hhi[q] = (uint32_t)__double2hiint(hd);
+                    p.out.hlo[q] = (uint32_t)__double2loint(hd);
                     p.dep[q] = dep;
                 } else {
                     atomicOr(p.error, 1u);
@@ -399,7 +403,8 @@ struct PicBinArgs {
     int64_t N;
     int nty, xs, ys;
     const uint32_t *x, *y, *slot;
-    const float *agent_food, *heading;
+    const float* agent_food;
+    const uint32_t *hhi, *hlo;
     PicLayout out;
     uint32_t* cursor;
 };
@@ -456,7 +461,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
         a.out.y[j] = Y;
         a.out.agent_food[j] = a.agent_food[n];
         a.out.slot[j] = a.slot ? a.slot[n] : (uint32_t)n;
-        a.out.heading[j] = a.heading[n];
+        a.out.hhi[j] = a.hhi[n];
+        a.out.hlo[j] = a.hlo[n];
     }
 }
 
@@ -490,7 +496,7 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
     DIE_REQUIRE(p->N > 0 && p->N < ((int64_t)1 << 31), "%s: bad agent count", who);
     for (int l = 0; l < 2; ++l) {
         const die_pic_layout& L = p->layout[l];
-        DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
+        DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
     }
     DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
     DIE_REQUIRE(p->dep && p->dep_plane && p->part_gain && p->error, "%s: null workspace pointer", who);
@@ -499,7 +505,7 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
 
 static PicLayout pic_layout(const die_pic_layout& L) {
     PicLayout o;
-    o.x = L.x; o.y = L.y; o.agent_food = L.agent_food; o.slot = L.slot; o.heading = L.heading;
+    o.x = L.x; o.y = L.y; o.agent_food = L.agent_food; o.slot = L.slot; o.hhi = L.heading_hi; o.hlo = L.heading_lo;
     o.off = L.off; o.n = L.n; o.s = L.s; o.inc = L.inc;
     return o;
 }
@@ -509,11 +515,11 @@ extern "C" int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t 
     return (int64_t)(W >> tile_xs) * (H >> tile_ys);
 }
 
-extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const float* heading, const die_pic* p, int32_t into,
-                           void* stream) {
+extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
+                           const die_pic* p, int32_t into, void* stream) {
     int rc = pic_check(m, p, "die_pic_bin");
     if (rc != DIE_OK) return rc;
-    DIE_REQUIRE(a && a->N == p->N && a->x && a->y && a->agent_food && heading, "die_pic_bin: bad agent arrays");
+    DIE_REQUIRE(a && a->N == p->N && a->x && a->y && a->agent_food && heading_hi && heading_lo, "die_pic_bin: bad agent arrays");
     DIE_REQUIRE(into == 0 || into == 1, "die_pic_bin: layout index %d", into);
     DIE_REQUIRE(a->x != p->layout[into].x, "die_pic_bin: the agents are already held in layout %d: bin into the other one", into);
     const int NT = (int)die_pic_tiles(m->W, m->H, p->tile_xs, p->tile_ys);
@@ -524,7 +530,7 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const float
     if (e != hipSuccess) { die_set_error("die_pic_bin: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
     PicBinArgs b;
     b.g = die_geo_of(m); b.N = a->N; b.nty = m->H >> p->tile_ys; b.xs = p->tile_xs; b.ys = p->tile_ys;
-    b.x = a->x; b.y = a->y; b.slot = a->slot; b.agent_food = a->agent_food; b.heading = heading;
+    b.x = a->x; b.y = a->y; b.slot = a->slot; b.agent_food = a->agent_food; b.hhi = heading_hi; b.hlo = heading_lo;
     b.out = pic_layout(p->layout[into]); b.cursor = cursor;
     int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
     const int grid = (int)(g < 4096 ? g : 4096);
@@ -571,7 +577,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     die_agents a;
     a.N = p->N; a.x = Lin.x; a.y = Lin.y; a.alive = nullptr; a.agent_food = Lin.agent_food; a.slot = Lin.slot;
     die_gradient_agent gg = *g;
-    gg.heading = Lin.heading;
+    gg.heading_hi = Lin.heading_hi; gg.heading_lo = Lin.heading_lo;
     FwdArgs f;
     rc = die_fill_fwd_args(f, m, &a, &gg, act, "die_pic_forward_env_step");
     if (rc != DIE_OK) return rc;

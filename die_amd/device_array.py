@@ -287,9 +287,9 @@ class PendingAction(DeviceAction):
     def rebind(self, agents):
         """The agents (and the agent object's state) were re-ordered between forward() and the fused step."""
         self.slot = agents.slot
-        hd = self.agent._direction_rads
-        self.g_struct.heading = hd.data_ptr()
-        self._keepalive = (hd,) + tuple(self._keepalive[1:])
+        hi, lo = self.agent._hd_hi, self.agent._hd_lo
+        self.g_struct.heading_hi, self.g_struct.heading_lo = hi.data_ptr(), lo.data_ptr()
+        self._keepalive = (hi, lo) + tuple(self._keepalive[2:])
 
     def ensure(self):
         if self.pending:

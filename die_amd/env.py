@@ -358,7 +358,7 @@ class Env(_EnvBase):
         """The captured K-step graph for the current alignment (epoch, chem plane, sort phase, array storages)."""
         A, M = self.agents, self.medium
         key = (id(agent), K, M.epoch, M.chem.data_ptr(), self._steps % max(self._sort_every, 1), A.x.data_ptr(),
-               agent._direction_rads.data_ptr() if agent._direction_rads is not None else 0, A.N)
+               agent._hd_hi.data_ptr() if agent._hd_hi is not None else 0, A.N)
         cache = self.__dict__.setdefault('_graphs', {})
         G = cache.get(key)
         if G is not None:
@@ -366,7 +366,7 @@ class Env(_EnvBase):
         cache.clear()                                  # one alignment at a time: the pools hold K steps of temporaries
         # everything the K steps may re-seat, and where it has to be again afterwards
         holders = [(A, n) for n in ('x', 'y', 'alive', 'agent_food', 'slot')] + [(M, 'chem'), (M, 'chem_next')] + \
-                  [(agent, '_direction_rads'), (agent, '_prev_grad'), (agent, '_order'), (self, '_shadow')]
+                  [(agent, '_hd_hi'), (agent, '_hd_lo'), (agent, '_prev_grad'), (agent, '_order'), (self, '_shadow')]
         init = [(o, n, getattr(o, n)) for o, n in holders]
         steps0, calls0, epoch0 = self._steps, agent._calls, M.epoch
         results = torch.empty((K, 2), dtype=torch.float64, device=self.device)

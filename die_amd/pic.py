@@ -36,17 +36,17 @@ class PicState:
         self.dep_plane = torch.empty((W, H), dtype=torch.float32, device=dev)
         self.part = torch.zeros(self.NT, dtype=torch.int64, device=dev)
         self.error = torch.zeros(2 + 16 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
-        self.spare = [torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev),
-                      torch.empty(N, dtype=torch.float32, device=dev), torch.empty(N, dtype=torch.float32, device=dev)]
+        i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
+        self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
         self.k1_threads = 0          # tuning knob of die_pic (0 = library default)
         self.cur = 0                 # layout index that holds the agents
-        self.held = None             # (x, y, agent_food, slot, heading) tensors of layout[cur] — identity = validity
+        self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
         self.agent = None
 
     # ------------------------------------------------------------------
     def _layout(self, tensors, meta) -> _lib.PicLayout:
-        x, y, af, slot, hd = tensors
-        return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hd), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
+        x, y, af, slot, hh, hl = tensors
+        return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hh), _ptr(hl), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
 
     def _struct(self, cur_tensors, other_tensors, stages: int = 0) -> _lib.Pic:
         lay = [None, None]
@@ -58,30 +58,30 @@ class PicState:
     def is_current(self, env, agent) -> bool:
         A, h = env.agents, self.held
         return h is not None and self.agent is agent and A.x is h[0] and A.y is h[1] and A.agent_food is h[2] and A.slot is h[3] and \
-            agent._direction_rads is h[4] and agent._order is A.slot
+            agent._hd_hi is h[4] and agent._hd_lo is h[5] and agent._order is A.slot
 
     def _adopt(self, env, agent, new):
-        """The agents now live in `new` = (x, y, agent_food, slot, heading): hand the arrays to their owners and keep the
+        """The agents now live in `new` = (x, y, agent_food, slot, heading hi, lo): hand the arrays to their owners and keep the
         old ones as the next step's output buffers (the slot array is never reused: actions may still refer to it)."""
         A = env.agents
-        self.spare = [A.x, A.y, A.agent_food, agent._direction_rads]
+        self.spare = [A.x, A.y, A.agent_food, agent._hd_hi, agent._hd_lo]
         A.x, A.y, A.agent_food, A.slot = new[0], new[1], new[2], new[3]
-        agent._direction_rads = new[4]
+        agent._hd_hi, agent._hd_lo = new[4], new[5]
         agent._order = A.slot
         self.held, self.agent = tuple(new), agent
 
     def _out_tensors(self, env):
         slot = torch.empty(self.N, dtype=torch.int32, device=env.device)
-        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3])
+        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4])
 
     def bin(self, env, agent):
         """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset."""
         A = env.agents
         out = self._out_tensors(env)
-        cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._direction_rads)
+        cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo)
         p = self._struct(cur_t, out)
         m, a = env.medium.c_struct(need_owner=False), A.c_struct()
-        _lib.check(_lib.lib.die_pic_bin(C.byref(m), C.byref(a), _ptr(agent._direction_rads), C.byref(p), 1 - self.cur,
+        _lib.check(_lib.lib.die_pic_bin(C.byref(m), C.byref(a), _ptr(agent._hd_hi), _ptr(agent._hd_lo), C.byref(p), 1 - self.cur,
                                         stream_ptr(env.device)), 'die_pic_bin')
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 13
+#define DIE_ABI_VERSION 14
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -137,11 +137,14 @@ typedef struct die_gradient_agent {
     float sense_offset;
     float noise_scale;
     float grad_clip;         /* < 0: None */
-    float turn_radians;      /* physarum only */
-    float sense_radians;
-    float turn_tolerance;
-    int32_t reserved;
-    float* heading;          /* N, _direction_rads (state, read and written) */
+    /* The heading and the turn decision are float64, like the reference's (core/agent/gradient.py:168-208): the decision
+     * `abs(dir_delta) > sense_radians` is an exact tie whenever a probe sits on the symmetry axis of a deposit, and which way
+     * it falls is decided by the low bits of the heading — fp32 headings resolved ~0.1 % of agents differently per step. */
+    double turn_radians;     /* physarum only: np.radians(turn_angle) */
+    double sense_radians;
+    double turn_tolerance;
+    uint32_t* heading_hi;    /* N + N words: _direction_rads as float64, high and low halves in two arrays (state, read and */
+    uint32_t* heading_lo;    /* written) — two 4-byte arrays travel through the sort / migration machinery like any other */
     float* prev_gx;          /* N, _prev_grad[0]; may be NULL when inertia == 0 */
     float* prev_gy;          /* N */
     const int8_t* turn_sign; /* N entries ±1 (indexed by SLOT id) replacing the random turn, or NULL → Philox(seed, step, slot) */
@@ -282,8 +285,8 @@ int die_init_medium(const die_medium* m, double agent_ratio, uint64_t seed, cons
 int die_init_agents(const die_medium* m, const die_agents* a, uint64_t seed, int64_t* num_alive_dev,
                     void* workspace, int64_t workspace_bytes, void* stream);
 /* GradientAgent/PhysarumAgent.__init__ state (:42-43,163): heading from N(0,.4) noise,
- * discretised to the turn lattice when turn_radians > 0. */
-int die_init_heading(float* heading, float* prev_gx, float* prev_gy, int64_t N, float turn_radians,
+ * discretised to the turn lattice when turn_radians > 0; stored as the float64 of its fp32 rounding. */
+int die_init_heading(uint32_t* heading_hi, uint32_t* heading_lo, float* prev_gx, float* prev_gy, int64_t N, double turn_radians,
                      uint64_t seed, void* stream);
 
 /* Env._medium_resource_dynamics (core/env.py:147-150) with the flow operator of WaveSequence.get_flow_operator
@@ -328,7 +331,8 @@ typedef struct die_pic_layout {
     uint32_t* y;
     float* agent_food;       /* N */
     uint32_t* slot;          /* N, reference slot ids (always materialised) */
-    float* heading;          /* N, the agent object's _direction_rads in this order */
+    uint32_t* heading_hi;    /* N, the agent object's _direction_rads (float64 halves, die_gradient_agent) in this order */
+    uint32_t* heading_lo;
     uint32_t *off, *n, *s, *inc;   /* die_pic_tiles() words each */
 } die_pic_layout;
 
@@ -350,10 +354,11 @@ typedef struct die_pic {
 int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 /* Bin agents held in any order (die_agents; `heading` in the same order) into layout[into]; both layouts' per-tile words
  * are initialised.  DIE_ERR_UNSUPPORTED unless the world splits into at least 3×3 whole tiles. */
-int die_pic_bin(const die_medium* m, const die_agents* a, const float* heading, const die_pic* p, int32_t into, void* stream);
+int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo, const die_pic* p,
+                int32_t into, void* stream);
 /* GradientAgent/PhysarumAgent.forward (core/agent/gradient.py:96-124) + Env.step (core/env.py:101-131) on binned agents:
  * three launches (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  The
- * agent state (g->heading is ignored: layout[from].heading) moves with the agents; `act` receives the action in the order
+ * agent state (g->heading_* are ignored: layout[from].heading_*) moves with the agents; `act` receives the action in the order
  * of layout[from].  Requires: every slot alive, no agents_die / sense mask, normalised gradient without inertia or noise
  * and |scale| * (max(W, H) - 1) <= tile - 1 (else DIE_ERR_UNSUPPORTED / DIE_ERR_ARG: use die_forward_env_step). */
 int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g, const die_action* act,

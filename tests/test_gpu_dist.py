@@ -282,7 +282,7 @@ def test_configs3_8192_world_2x2_ranks_equals_single_device(tmp_path):
     agent._alloc_state('cuda:0')
     np.save(os.path.join(tmp, 'medium.npy'), env.medium.to_numpy().astype(np.float32))
     np.save(os.path.join(tmp, 'agents.npy'), env.agents.to_numpy())
-    np.save(os.path.join(tmp, 'dir0.npy'), agent._direction_rads.cpu().numpy())
+    np.save(os.path.join(tmp, "dir0.npy"), agent._direction_rads.cpu().numpy().astype(np.float32))
     rewards = check_step_invariants(env, agent, steps, W, H, 1.53 / (W - 1))
     want = dict(occ=env.medium.occupied().cpu().numpy(), food=env.medium.food.cpu().numpy(), chem=env.medium.chem.cpu().numpy(),
                 x=unpermute(env.agents.x, env.agents.slot).cpu().numpy(), y=unpermute(env.agents.y, env.agents.slot).cpu().numpy(),
