@@ -59,6 +59,7 @@ class ConvPlane(C.Structure):
 
 
 DIE_PLANE_F32, DIE_PLANE_F16, DIE_PLANE_AGENTS = 0, 1, 2
+DIE_FIELD_CONST, DIE_FIELD_NOISE, DIE_FIELD_AGENTS, DIE_FIELD_PERLIN = 0, 1, 2, 3
 
 
 class PicLayout(C.Structure):
@@ -79,7 +80,7 @@ class Rect(C.Structure):
 
 
 class FoodSpec(C.Structure):
-    _fields_ = [('n_waves', C.c_int32), ('scale', C.c_float), ('fx', C.c_double * 8), ('fy', C.c_double * 8),
+    _fields_ = [('n_waves', C.c_int32), ('scale', C.c_float), ('perlin_octaves', C.c_int32), ('threshold', C.c_float), ('fx', C.c_double * 8), ('fy', C.c_double * 8),
                 ('phase', C.c_double * 8), ('amp', C.c_double * 8)]
 
 
@@ -129,6 +130,9 @@ _SIGNATURES = {
     'die_init_medium': (C.c_int, [_P(Medium), C.c_double, C.c_uint64, _P(FoodSpec), C.c_void_p]),
     'die_init_agents': (C.c_int, [_P(Medium), _P(Agents), C.c_uint64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_init_heading': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_double, C.c_uint64, C.c_void_p]),
+    'die_field_fill': (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_uint32,
+                                 C.c_uint32, C.c_void_p]),
+    'die_medium_from_fields': (C.c_int, [_P(Medium), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     'die_food_flow_wave': (C.c_int, [_P(Medium), C.c_double, C.c_double, C.c_double, C.c_void_p]),
     'die_sense_mask': (C.c_int, [_P(Medium), C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'die_render_frames': (C.c_int, [_P(Medium), C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,

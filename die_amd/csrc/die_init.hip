@@ -15,8 +15,29 @@
 struct FoodArgs {
     int n_waves;
     float scale;
+    int perlin_octaves;        // > 0: Perlin food, _mask(perlin(x·octaves, y·octaves).round(3), mask_above=threshold) (:228-231)
+    float threshold;
     double fx[8], fy[8], phase[8], amp[8];
 };
+
+// _mask (core/data_init.py:181-185) of a value already rounded to 3 decimals
+__device__ __forceinline__ double mask_range(double v, double below, double above) { return (below <= v && v <= above) ? v : 0.0; }
+
+// food value of world cell (ix, iy): with_food_perlin (:228-231) on the linspace(0, 1, n) labels, or the sinusoid mix
+__device__ __forceinline__ float init_food_value(const die_geo& g, const FoodArgs& fa, uint64_t seed, int ix, int iy) {
+    if (fa.perlin_octaves > 0) {
+        const double x = g.gW > 1 ? (double)ix / (double)(g.gW - 1) : 0.0, y = g.gH > 1 ? (double)iy / (double)(g.gH - 1) : 0.0;
+        const double p = rint(die_perlin2(seed, x * fa.perlin_octaves, y * fa.perlin_octaves) * 1000.0) / 1000.0;
+        return (float)mask_range(p, 0.0, (double)fa.threshold);
+    }
+    const double x = (double)ix / g.gW, y = (double)iy / g.gH;
+    double s = 0.0;
+    for (int k = 0; k < fa.n_waves; ++k)
+        s += fa.amp[k] * sin(6.283185307179586476925 * (fa.fx[k] * x + fa.fy[k] * y) + fa.phase[k]);
+    s = 2.0 * (double)fa.scale * s;
+    s = s < 0.0 ? 0.0 : (s > (double)fa.scale ? (double)fa.scale : s);
+    return (float)(rint(s * 1000.0) / 1000.0);   // .round(3) (:196)
+}
 
 template <typename T>
 __global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(die_geo g, uint64_t* owner, T* food, T* chem, double ratio,
@@ -35,13 +56,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_init_medium(die_geo g, uint64_t* 
         const int r = die_round3_units(die_draw(seed, 0, gc, DIE_STREAM_INIT_AGENTS).v[0]);
         const double u = r / 1000.0;
         owner[c] = (r > 0 && u <= ratio) ? 1ull : 0ull;    // provisional flag; k_scatter writes the claim word
-        const double x = (double)ix / g.gW, y = (double)iy / g.gH;
-        double s = 0.0;
-        for (int k = 0; k < fa.n_waves; ++k)
-            s += fa.amp[k] * sin(6.283185307179586476925 * (fa.fx[k] * x + fa.fy[k] * y) + fa.phase[k]);
-        s = 2.0 * (double)fa.scale * s;
-        s = s < 0.0 ? 0.0 : (s > (double)fa.scale ? (double)fa.scale : s);
-        die_st(food, c, (float)(rint(s * 1000.0) / 1000.0));   // .round(3) (:196)
+        die_st(food, c, init_food_value(g, fa, seed, ix, iy));
         die_st(chem, c, 0.f);
     }
 }
@@ -176,6 +191,9 @@ extern "C" int die_init_medium(const die_medium* m, double agent_ratio, uint64_t
     FoodArgs fa;
     fa.n_waves = food->n_waves;
     fa.scale = food->scale;
+    fa.perlin_octaves = food->perlin_octaves;
+    fa.threshold = food->threshold;
+    DIE_REQUIRE(food->perlin_octaves >= 0 && food->perlin_octaves < (1 << 19), "die_init_medium: bad perlin_octaves %d", food->perlin_octaves);
     for (int i = 0; i < 8; ++i) { fa.fx[i] = food->fx[i]; fa.fy[i] = food->fy[i]; fa.phase[i] = food->phase[i]; fa.amp[i] = food->amp[i]; }
     const int grid = init_grid((int64_t)m->W * m->H);
     if (m->dtype == DIE_F32)
@@ -255,5 +273,82 @@ extern "C" int die_food_flow_wave(const die_medium* m, double t, double scale, d
     if (m->dtype == DIE_F32) k_food_flow_wave<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((float*)m->food, g, t, scale, 1.0 - decay);
     else k_food_flow_wave<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((__half*)m->food, g, t, scale, 1.0 - decay);
     DIE_CHECK_LAUNCH("die_food_flow_wave");
+    return DIE_OK;
+}
+
+
+// ---- DataInitializer builder steps on plain fp32 arrays (core/data_init.py:171-253) --------------------------------
+// with_const (:214-216), with_noise / get_random (:168-169,218-220), with_agents (:222-226), with_food_perlin / with_chem
+// (:228-236) fill one channel; build / build_agents (:238-253) multiply by the static mask and hand the channels over.
+struct FieldOpArgs {
+    float* dst;
+    int64_t n;
+    int op;                    // die_field_op
+    int W, H;                  // perlin: the field shape (labels linspace(0, 1, W) × linspace(0, 1, H))
+    double a, b;               // const: a; noise: range [a, b]; agents: ratio = b; perlin: threshold = b, octaves = a
+    uint64_t seed;
+    uint32_t step, word;
+};
+
+__global__ __launch_bounds__(DIE_BLOCK) void k_field_op(FieldOpArgs q) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.n; i += stride) {
+        double v = 0.0;
+        if (q.op == DIE_FIELD_CONST) {
+            v = q.a;
+        } else if (q.op == DIE_FIELD_NOISE) {                 // (b − a)·random_sample().round(3) + a
+            const int r = die_round3_units(die_draw(q.seed, q.step, (uint64_t)i, DIE_STREAM_BUILDER).v[q.word & 3u]);
+            v = (q.b - q.a) * (r / 1000.0) + q.a;
+        } else if (q.op == DIE_FIELD_AGENTS) {                // ceil(_mask(u, mask_above=ratio)): the stream of die_init_medium
+            const int r = die_round3_units(die_draw(q.seed, q.step, (uint64_t)i, DIE_STREAM_INIT_AGENTS).v[0]);
+            v = (r > 0 && r / 1000.0 <= q.b) ? 1.0 : 0.0;
+        } else {                                              // DIE_FIELD_PERLIN
+            const int ix = (int)(i / q.H), iy = (int)(i - (int64_t)ix * q.H);
+            const double x = q.W > 1 ? (double)ix / (double)(q.W - 1) : 0.0, y = q.H > 1 ? (double)iy / (double)(q.H - 1) : 0.0;
+            const double p = rint(die_perlin2(q.seed + q.step, x * q.a, y * q.a) * 1000.0) / 1000.0;
+            v = mask_range(p, 0.0, q.b);
+        }
+        q.dst[i] = (float)v;
+    }
+}
+
+extern "C" int die_field_fill(float* dst, int64_t n, int32_t op, int32_t W, int32_t H, double a, double b, uint64_t seed,
+                              uint32_t step, uint32_t word, void* stream) {
+    DIE_REQUIRE(dst && n > 0, "die_field_fill: bad array");
+    DIE_REQUIRE(op >= DIE_FIELD_CONST && op <= DIE_FIELD_PERLIN, "die_field_fill: bad op %d", op);
+    DIE_REQUIRE(op != DIE_FIELD_PERLIN || (W >= 1 && H >= 1 && (int64_t)W * H == n && a >= 1.0 && a < 524288.0), "die_field_fill: bad perlin shape");
+    FieldOpArgs q;
+    q.dst = dst; q.n = n; q.op = op; q.W = W; q.H = H; q.a = a; q.b = b; q.seed = seed; q.step = step; q.word = word;
+    k_field_op<<<init_grid(n), DIE_BLOCK, 0, (hipStream_t)stream>>>(q);
+    DIE_CHECK_LAUNCH("die_field_fill");
+    return DIE_OK;
+}
+
+// build (:238-246): the three channels × mask into the medium's own representation (occupied cells get the
+// provisional flag die_init_agents turns into claim words).  Any channel / the mask may be NULL (zeros / ones).
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_medium_from_fields(int64_t C, uint64_t* owner, T* food, T* chem, const float* fa,
+                                                                  const float* ff, const float* fc, const float* mask, float mask_scalar) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += stride) {
+        const float mk = mask ? mask[c] : mask_scalar;
+        owner[c] = (fa && fa[c] * mk > 0.f) ? 1ull : 0ull;
+        die_st(food, c, ff ? ff[c] * mk : 0.f);
+        die_st(chem, c, fc ? fc[c] * mk : 0.f);
+    }
+}
+
+extern "C" int die_medium_from_fields(const die_medium* m, const float* agents, const float* food, const float* chem,
+                                      const float* mask, float mask_scalar, void* stream) {
+    DIE_REQUIRE(m && m->owner && m->food && m->chem && m->W >= 1 && m->H >= 1, "die_medium_from_fields: bad medium");
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "die_medium_from_fields: bad dtype %d", m->dtype);
+    const int64_t C = (int64_t)m->W * m->H;
+    if (m->dtype == DIE_F32)
+        k_medium_from_fields<float><<<init_grid(C), DIE_BLOCK, 0, (hipStream_t)stream>>>(C, m->owner, (float*)m->food, (float*)m->chem,
+                                                                                         agents, food, chem, mask, mask_scalar);
+    else
+        k_medium_from_fields<__half><<<init_grid(C), DIE_BLOCK, 0, (hipStream_t)stream>>>(C, m->owner, (__half*)m->food, (__half*)m->chem,
+                                                                                          agents, food, chem, mask, mask_scalar);
+    DIE_CHECK_LAUNCH("die_medium_from_fields");
     return DIE_OK;
 }

@@ -11,6 +11,7 @@
 #define DIE_STREAM_INIT_FOOD 4u
 #define DIE_STREAM_INIT_HEADING 5u
 #define DIE_STREAM_INIT_AGENT_FOOD 6u
+#define DIE_STREAM_BUILDER 7u
 
 struct die_u32x4 { uint32_t v[4]; };
 
@@ -39,4 +40,26 @@ __host__ __device__ inline die_u32x4 die_draw(uint64_t seed, uint32_t step, uint
 // numerator r in [0, 1000] of `random_sample().round(3)` (core/data_init.py:168-169)
 __host__ __device__ inline int die_round3_units(uint32_t bits) {
     return (int)(((uint64_t)bits * 1000ull + 0x80000000ull) >> 32);
+}
+
+
+// 2-D gradient ("Perlin") noise — Perlin 1985 / 2002: a unit gradient on every integer lattice point, the four corner
+// dot products blended with the quintic fade 6t^5 − 15t^4 + 10t^3.  Stands in for the un-vendored `perlin_noise`
+// package of core/data_init.py:190-196, whose `octaves` is the number of lattice cells per unit length: the caller
+// passes (x·octaves, y·octaves).  The lattice gradients come from Philox(seed, lattice point); oracle/cpu_ref.py
+// perlin2 is the same function in numpy.  Values lie in [−√½, √½].
+__device__ inline double die_perlin_dot(uint64_t seed, int64_t i, int64_t j, double dx, double dy) {
+    const die_u32x4 r = die_draw(seed, 0u, (uint64_t)(i & 0xFFFFF) | ((uint64_t)(j & 0xFFFFF) << 20), DIE_STREAM_INIT_FOOD);
+    const double th = 6.283185307179586476925 * ((double)r.v[0] * (1.0 / 4294967296.0));
+    return cos(th) * dx + sin(th) * dy;
+}
+__device__ inline double die_perlin2(uint64_t seed, double x, double y) {
+    const double fx0 = floor(x), fy0 = floor(y);
+    const int64_t i = (int64_t)fx0, j = (int64_t)fy0;
+    const double tx = x - fx0, ty = y - fy0;
+    const double d00 = die_perlin_dot(seed, i, j, tx, ty), d10 = die_perlin_dot(seed, i + 1, j, tx - 1.0, ty);
+    const double d01 = die_perlin_dot(seed, i, j + 1, tx, ty - 1.0), d11 = die_perlin_dot(seed, i + 1, j + 1, tx - 1.0, ty - 1.0);
+    const double u = tx * tx * tx * (tx * (tx * 6.0 - 15.0) + 10.0), v = ty * ty * ty * (ty * (ty * 6.0 - 15.0) + 10.0);
+    const double a = d00 + u * (d10 - d00), b = d01 + u * (d11 - d01);
+    return a + v * (b - a);
 }

@@ -270,9 +270,11 @@ int die_diffuse_decay_mode(const void* src, void* dst, int32_t W, int32_t H, int
                            int32_t mode, void* stream);
 
 /* ---- DataInitializer (core/data_init.py:92-253, core/env.py:74-86) ------------------- */
-typedef struct die_food_spec {   /* synthetic stand-in for the Perlin food field (:190-196) */
-    int32_t n_waves;             /* <= 8 */
+typedef struct die_food_spec {
+    int32_t n_waves;             /* sinusoid mix (<= 8 waves), used when perlin_octaves == 0 */
     float scale;
+    int32_t perlin_octaves;      /* > 0: with_food_perlin (:228-231): 2-D gradient noise of that many lattice cells per unit */
+    float threshold;             /*      length, .round(3), values outside [0, threshold] masked to 0 (Env: 8, 1.0) */
     double fx[8], fy[8], phase[8], amp[8];
 } die_food_spec;
 
@@ -288,6 +290,22 @@ int die_init_agents(const die_medium* m, const die_agents* a, uint64_t seed, int
  * discretised to the turn lattice when turn_radians > 0; stored as the float64 of its fp32 rounding. */
 int die_init_heading(uint32_t* heading_hi, uint32_t* heading_lo, float* prev_gx, float* prev_gy, int64_t N, double turn_radians,
                      uint64_t seed, void* stream);
+
+/* DataInitializer's builder steps (core/data_init.py:171-253) on plain fp32 device arrays: one channel per call.
+ *   DIE_FIELD_CONST   with_const (:214-216): dst = a
+ *   DIE_FIELD_NOISE   with_noise / get_random (:168-169,218-220): (b - a) * random_sample().round(3) + a, the uniform being
+ *                     word `word` (0..3) of Philox(seed, step, element)
+ *   DIE_FIELD_AGENTS  with_agents (:222-226): ceil(_mask(random_sample().round(3), mask_above = b)), the random stream of
+ *                     die_init_medium at the same `step` (0 there)
+ *   DIE_FIELD_PERLIN  with_food_perlin / with_chem (:228-236): _mask(perlin.round(3), mask_above = b) on the W x H labels,
+ *                     octaves = a (see die_food_spec), lattice seed `seed + step` */
+typedef enum die_field_op { DIE_FIELD_CONST = 0, DIE_FIELD_NOISE = 1, DIE_FIELD_AGENTS = 2, DIE_FIELD_PERLIN = 3 } die_field_op;
+int die_field_fill(float* dst, int64_t n, int32_t op, int32_t W, int32_t H, double a, double b, uint64_t seed, uint32_t step,
+                   uint32_t word, void* stream);
+/* build (:238-246): channels x mask -> the medium (occupied cells flagged for die_init_agents; chem / food converted to
+ * the field dtype).  A NULL channel is zeros, a NULL mask is the scalar. */
+int die_medium_from_fields(const die_medium* m, const float* agents, const float* food, const float* chem, const float* mask,
+                           float mask_scalar, void* stream);
 
 /* Env._medium_resource_dynamics (core/env.py:147-150) with the flow operator of WaveSequence.get_flow_operator
  * (core/data_init.py:29-38): food <- scale * z(x, y, t) + (1 - decay) * food, z = WaveSequence.__getitem__(t)

@@ -477,13 +477,46 @@ class FoodSpec:
         return np.round(s, 3)
 
 
-def synthetic_init(W: int, H: int, ratio: float, seed: int, max_agents: Optional[int] = None):
-    """Env._init_data (core/env.py:74-86) with synthetic food; returns (medium, agents)."""
+def perlin2(seed: int, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+    """2-D gradient noise (Perlin 1985 / 2002) — what the un-vendored `perlin_noise.PerlinNoise(octaves)` of
+    core/data_init.py:190-196 is built from: unit gradients on the integer lattice, corner dot products blended with the
+    quintic fade; the caller scales the coordinates by `octaves`.  Lattice gradient angles come from Philox(seed, lattice
+    point) — the twin of die_perlin2 in die_amd/csrc/die_rng.h."""
+    x, y = np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64)
+    fx0, fy0 = np.floor(x), np.floor(y)
+    i, j = fx0.astype(np.int64), fy0.astype(np.int64)
+    tx, ty = x - fx0, y - fy0
+
+    def dot(ii, jj, dx, dy):
+        key = ((ii & 0xFFFFF).astype(np.uint64) | ((jj & 0xFFFFF).astype(np.uint64) << np.uint64(20))).ravel()
+        r0 = orng._draw(seed, 0, key, orng.STREAM_INIT_FOOD)[0].reshape(dx.shape)
+        th = 6.283185307179586476925 * (r0.astype(np.float64) * (1.0 / 4294967296.0))
+        return np.cos(th) * dx + np.sin(th) * dy
+
+    d00, d10 = dot(i, j, tx, ty), dot(i + 1, j, tx - 1.0, ty)
+    d01, d11 = dot(i, j + 1, tx, ty - 1.0), dot(i + 1, j + 1, tx - 1.0, ty - 1.0)
+    u = tx * tx * tx * (tx * (tx * 6.0 - 15.0) + 10.0)
+    v = ty * ty * ty * (ty * (ty * 6.0 - 15.0) + 10.0)
+    a, b = d00 + u * (d10 - d00), d01 + u * (d11 - d01)
+    return a + v * (b - a)
+
+
+def perlin_field(W: int, H: int, octaves: int, seed: int, threshold: float = 1.0) -> np.ndarray:
+    """with_food_perlin / _get_perlin (core/data_init.py:190-196,228-231): noise at the linspace(0, 1, n) labels times
+    `octaves`, `.round(3)`, values outside [0, threshold] masked to 0."""
+    xs = (np.arange(W, dtype=np.float64) / (W - 1) if W > 1 else np.zeros(1))[:, None] * np.ones((1, H))
+    ys = np.ones((W, 1)) * (np.arange(H, dtype=np.float64) / (H - 1) if H > 1 else np.zeros(1))[None, :]
+    return mask_range(np.round(perlin2(seed, xs * octaves, ys * octaves), 3), mask_above=threshold)
+
+
+def synthetic_init(W: int, H: int, ratio: float, seed: int, max_agents: Optional[int] = None, food: str = 'perlin'):
+    """Env._init_data (core/env.py:74-86): Perlin food (threshold 1.0, 8 octaves), seeded agents; returns (medium,
+    agents).  `food='waves'`: the sinusoid mix of round 1."""
     C = W * H
     u = orng.uniform_round3(seed, 0, C, orng.STREAM_INIT_AGENTS).reshape(W, H)
     medium = np.zeros((3, W, H))
     medium[M_AGENTS] = agents_channel_from_uniform(u, ratio)
-    medium[M_FOOD] = FoodSpec.from_seed(seed).field(W, H)
+    medium[M_FOOD] = perlin_field(W, H, 8, seed) if food == 'perlin' else FoodSpec.from_seed(seed).field(W, H)
     K = int((medium[M_AGENTS] > 0).sum())
     fu = orng.uniform_round3(seed, 0, K, orng.STREAM_INIT_AGENT_FOOD)
     agents = agents_from_medium(medium, fu, max_agents)

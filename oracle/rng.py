@@ -32,6 +32,7 @@ STREAM_INIT_AGENTS = 3
 STREAM_INIT_FOOD = 4
 STREAM_INIT_HEADING = 5
 STREAM_INIT_AGENT_FOOD = 6
+STREAM_BUILDER = 7          # DataInitializer.with_noise (core/data_init.py:218-220): call k uses word k % 4 of step k // 4
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -92,3 +93,8 @@ def normals2(seed: int, step: int, n: int, stream: int = STREAM_NOISE, scale: fl
     u2 = r[1].astype(np.float64) * (1.0 / 4294967296.0)          # [0, 1)
     rad = np.sqrt(-2.0 * np.log(u1))
     return scale * np.stack([rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)])
+
+
+def builder_noise(seed: int, call: int, n: int, a: float, b: float) -> np.ndarray:
+    """The `call`-th with_noise of a DataInitializer (core/data_init.py:168-169,218-220): (b − a)·u.round(3) + a."""
+    return (b - a) * uniform_round3(seed, call // 4, n, STREAM_BUILDER, word=call % 4) + a

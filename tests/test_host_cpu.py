@@ -45,7 +45,7 @@ def test_struct_layouts_match_header(built_lib):
     assert C.sizeof(_lib.Action) == 8 + 3 * 8
     assert C.sizeof(_lib.Dynamics) == 12 * 4
     assert C.sizeof(_lib.GradientAgent) == 8 * 4 + 3 * 8 + 5 * 8 + 8 + 4 + 4 + 8
-    assert C.sizeof(_lib.FoodSpec) == 8 + 4 * 8 * 8
+    assert C.sizeof(_lib.FoodSpec) == 16 + 4 * 8 * 8
 
 
 def test_argument_validation_without_gpu(built_lib):

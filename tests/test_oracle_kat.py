@@ -153,3 +153,20 @@ def test_agents_from_medium_row_major_and_synthetic_init():
     assert np.array_equal(f, np.round(f, 3))
     _, a2 = R.synthetic_init(16, 12, 0.15, seed=1234, max_agents=K)
     assert a2.shape == (4, K)
+
+
+def test_perlin_noise_properties():
+    """oracle.perlin2 (the stand-in for the un-vendored perlin_noise package of core/data_init.py:190-196): gradient noise
+    is exactly 0 on lattice points, bounded by sqrt(1/2), continuous, and fixed by the seed."""
+    xs = np.arange(0, 9, dtype=np.float64)
+    g = R.perlin2(5, xs[:, None] * np.ones((1, 9)), np.ones((9, 1)) * xs[None, :])
+    assert np.array_equal(g, np.zeros((9, 9)))
+    t = np.linspace(0, 8, 4001)
+    f = R.perlin2(5, t[:, None] * np.ones((1, 4)), np.array([[0.25, 1.5, 3.75, 7.1]]) * np.ones((4001, 1)))
+    assert np.abs(f).max() <= np.sqrt(0.5) + 1e-12 and np.abs(f).max() > 0.2
+    assert np.abs(np.diff(f, axis=0)).max() < 0.01                      # smooth at 1/500 of a lattice cell
+    assert np.array_equal(f, R.perlin2(5, t[:, None] * np.ones((1, 4)), np.array([[0.25, 1.5, 3.75, 7.1]]) * np.ones((4001, 1))))
+    assert not np.array_equal(f, R.perlin2(6, t[:, None] * np.ones((1, 4)), np.array([[0.25, 1.5, 3.75, 7.1]]) * np.ones((4001, 1))))
+    food = R.perlin_field(64, 48, 8, 1234, threshold=1.0)
+    assert food.min() >= 0 and 0.3 < (food > 0).mean() < 0.7 and np.array_equal(food, np.round(food, 3))
+    assert (R.perlin_field(64, 48, 8, 1234, threshold=0.1) <= 0.1).all()
