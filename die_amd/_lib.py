@@ -110,6 +110,8 @@ _SIGNATURES = {
     'die_forward_move': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_int32, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_void_p]),
     'die_step_reduce_ex': (C.c_int, [_P(Agents), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_void_p]),
+    'die_agents_lifecycle': (C.c_int, [_P(Agents), C.c_void_p]),
+    'die_gradient_render': (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     'die_agent_claim_feed': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_int64,
                                        C.c_void_p]),
     'die_diffuse_decay_tile': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float,

@@ -154,6 +154,7 @@ class GradientAgent(Agent):
             else:
                 self._align_to(agents.slot)
         agents.attach(self)
+        self._render_src = (medium, medium.chem)    # what render() draws the gradient field of
         if self._pending is not None:               # keep heading updates in call order
             self._pending.ensure()
         pg = self._prev_grad
@@ -187,7 +188,19 @@ class GradientAgent(Agent):
         action.done()
 
     def render(self) -> Sequence[np.ndarray]:
-        return [np.ones((1, 1, 3))]
+        """:126-135: before the first forward one white pixel; afterwards the gradient field the agents sense,
+        0.5·(stack(gx, gy, 0) + 1) as a (W, H, 3) image — computed when asked for (die_gradient_render) from the chem
+        plane the last forward() saw (the fused step leaves that plane untouched as the medium's spare one; two steps
+        later it has been overwritten and the image is that of a newer field)."""
+        src = getattr(self, '_render_src', None)
+        if src is None:
+            return [np.ones((1, 1, 3))]
+        medium, chem = src
+        rgb = torch.empty((medium.W, medium.H, 3), dtype=torch.float32, device=chem.device)
+        _lib.check(_lib.lib.die_gradient_render(_ptr(chem), medium.W, medium.H, _lib.DIE_F32 if chem.dtype == torch.float32 else _lib.DIE_F16,
+                                                int(bool(self._normalized)), -1.0 if self._grad_clip is None else self._grad_clip,
+                                                _ptr(rgb), stream_ptr(chem.device)), 'die_gradient_render')
+        return [rgb.cpu().numpy()]
 
 
 class PhysarumAgent(GradientAgent):

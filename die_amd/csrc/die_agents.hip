@@ -121,3 +121,37 @@ extern "C" int die_const_forward(int64_t N, float dx, float dy, float deposit, d
     DIE_CHECK_LAUNCH("die_const_forward");
     return DIE_OK;
 }
+
+
+// GradientAgent.render (core/agent/gradient.py:126-135): 0.5·(stack(gx, gy, 0) + 1) of the gradient FIELD of
+// _get_gradient (:55-71) — np.gradient (central, one-sided at the four edges), g / |g| with 0/0 → 0, components of cells
+// whose norm is below grad_clip zeroed.  forward() never builds that field (it reads 4 taps per agent); this kernel
+// makes the image when somebody asks for it.
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_gradient_rgb(const T* chem, int W, int H, int normalized, float grad_clip, float* rgb) {
+    const int64_t C = (int64_t)W * H, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < C; c += stride) {
+        const int ix = (int)(c / H), iy = (int)(c - (int64_t)ix * H);
+        const int xm = ix > 0 ? ix - 1 : 0, xp = ix < W - 1 ? ix + 1 : W - 1, ym = iy > 0 ? iy - 1 : 0, yp = iy < H - 1 ? iy + 1 : H - 1;
+        const float gx = xp > xm ? (die_ld(chem, (int64_t)xp * H + iy) - die_ld(chem, (int64_t)xm * H + iy)) * ((xp - xm) == 2 ? 0.5f : 1.0f) : 0.f;
+        const float gy = yp > ym ? (die_ld(chem, (int64_t)ix * H + yp) - die_ld(chem, (int64_t)ix * H + ym)) * ((yp - ym) == 2 ? 0.5f : 1.0f) : 0.f;
+        const float norm = sqrtf(gx * gx + gy * gy);
+        float ux = gx, uy = gy;
+        if (normalized) { ux = norm > 0.f ? gx / norm : 0.f; uy = norm > 0.f ? gy / norm : 0.f; }
+        if (grad_clip >= 0.f && !(norm >= grad_clip)) { ux = 0.f; uy = 0.f; }
+        rgb[c * 3 + 0] = 0.5f * (ux + 1.f);
+        rgb[c * 3 + 1] = 0.5f * (uy + 1.f);
+        rgb[c * 3 + 2] = 0.5f;
+    }
+}
+
+extern "C" int die_gradient_render(const void* chem, int32_t W, int32_t H, int32_t dtype, int32_t normalized, float grad_clip,
+                                   float* rgb_out, void* stream) {
+    DIE_REQUIRE(chem && rgb_out && W >= 2 && H >= 2, "die_gradient_render: bad arguments");
+    DIE_REQUIRE(dtype == DIE_F32 || dtype == DIE_F16, "die_gradient_render: bad dtype %d", dtype);
+    const int grid = agent_grid((int64_t)W * H);
+    if (dtype == DIE_F32) k_gradient_rgb<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((const float*)chem, W, H, normalized, grad_clip, rgb_out);
+    else k_gradient_rgb<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((const __half*)chem, W, H, normalized, grad_clip, rgb_out);
+    DIE_CHECK_LAUNCH("die_gradient_render");
+    return DIE_OK;
+}

@@ -759,12 +759,29 @@ extern "C" int die_step_reduce_ex(const die_agents* a, die_step_result* result, 
     DIE_REQUIRE(ws_bytes >= WS_PARTS, "die_step_reduce_ex: workspace too small");
     const int g = step_grid(a->N);
     // with_second_pass: 0 = claim-pass gains, num_alive = alive_const; 1 = + the dead-slot pass's gains and its
-    // alive count; 2 = claim-pass gains and the claim pass's count of owned alive slots (ghost-agent tiles)
-    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const long long*)ws, g, (const long long*)ws + DIE_MAX_PARTIALS,
-                                                  with_second_pass == 1 ? g : 0,
+    // alive count; 2 = claim-pass gains and the claim pass's count of owned alive slots (ghost-agent tiles);
+    // 3 = both passes' gains, num_alive = alive_const (reference-compatible lifecycle: the count is frozen)
+    const bool both = with_second_pass == 1 || with_second_pass == 3;
+    k_reduce<<<1, 1024, 0, (hipStream_t)stream>>>((const long long*)ws, g, (const long long*)ws + DIE_MAX_PARTIALS, both ? g : 0,
                                                   (const long long*)ws + 2 * DIE_MAX_PARTIALS,
-                                                  with_second_pass ? g : 0, result, with_second_pass ? -1 : alive_const);
+                                                  (with_second_pass == 1 || with_second_pass == 2) ? g : 0, result,
+                                                  (with_second_pass == 1 || with_second_pass == 2) ? -1 : alive_const);
     DIE_CHECK_LAUNCH("die_step_reduce_ex");
+    return DIE_OK;
+}
+
+// _agent_lifecycle (core/env.py:245-250) alone: where(agent_food > 1e-4, agents, 0) on every channel
+__global__ __launch_bounds__(DIE_BLOCK) void k_lifecycle(int64_t N, uint32_t* x, uint32_t* y, uint8_t* alive, float* agent_food) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride)
+        if (!(agent_food[n] > 1e-4f)) { x[n] = 0; y[n] = 0; alive[n] = 0; agent_food[n] = 0.f; }
+}
+
+extern "C" int die_agents_lifecycle(const die_agents* a, void* stream) {
+    DIE_REQUIRE(a && a->N > 0 && a->x && a->y && a->alive && a->agent_food, "die_agents_lifecycle: bad agents");
+    int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
+    k_lifecycle<<<(int)(g < 8192 ? g : 8192), DIE_BLOCK, 0, (hipStream_t)stream>>>(a->N, a->x, a->y, a->alive, a->agent_food);
+    DIE_CHECK_LAUNCH("die_agents_lifecycle");
     return DIE_OK;
 }
 

@@ -69,6 +69,12 @@ class Dynamics:
     agents_die: bool = False
     agents_born: bool = False
     init_agent_ratio: float = 0.1
+    # not a reference field — which `agents_die` the env runs: 'intended' zeroes starved slots and everything follows
+    # them; 'reference' reproduces what the reference actually does: `_agent_lifecycle` rebinds `self.agents`
+    # (core/env.py:249) while the AgentIndexer keeps the array it was built with (core/utils.py:22), so from the second
+    # step on deposits, the agents channel, feeding and `num_agents` use the positions / alive flags frozen at the end
+    # of the first step's move, while the agents the policy sees keep moving, starving and being zeroed
+    compat: str = 'intended'
 
 
 class Env(_EnvBase):
@@ -98,6 +104,8 @@ class Env(_EnvBase):
         d = self.dynamics
         if d.diffuse_mode not in _lib.DIFFUSE_MODES:
             raise ValueError(f"diffuse_mode={d.diffuse_mode!r}: one of {sorted(_lib.DIFFUSE_MODES)}")
+        if d.compat not in ('intended', 'reference'):
+            raise ValueError(f"compat={d.compat!r}: 'intended' or 'reference'")
         if d.op_action_cost not in (linear_action_cost, zero_cost):
             raise NotImplementedError('op_action_cost must be linear_action_cost or zero_cost on device')
         if self._field_size[0] < 2 or self._field_size[1] < 2:
@@ -120,6 +128,7 @@ class Env(_EnvBase):
             self._alloc_sort_buffers()      # no step of a timed loop pays for allocations
         self._fuse_forward = True           # False once die_forward_env_step reports the shape unsupported
         self._pic = None                    # PicState, built at the first eligible step
+        self._frozen = None                 # compat='reference' with agents_die: (x, y, alive, K) the stale indexer sees
         self._pic_tile = None
         self.medium.sense_mask = None
         if self.dynamics.apply_sense_mask:
@@ -195,11 +204,38 @@ class Env(_EnvBase):
             raise ValueError(f'action has {act.N} slots, env has {self.agents.N}')
         return act.in_order_of(self.agents.slot)
 
+    def _step_compat(self, action, result):
+        """One step of `Dynamics(agents_die=True, compat='reference')`: the stages of die_env_step one call each, the
+        claim / deposit / feeding stages looking agents up in the frozen copy (see Dynamics.compat)."""
+        act = self._as_action(action)
+        A, M = self.agents, self.medium
+        M.next_epoch()
+        sp = stream_ptr(self.device)
+        ws, wsn = _ptr(self._workspace), self._workspace.numel()
+        m, a, u, d = M.c_struct(), A.c_struct(), act.c_struct(), self._c_dynamics()
+        d.agents_die = 0
+        tile_of = torch.empty(A.N, dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib.die_agent_move(C.byref(m), C.byref(a), C.byref(u), C.byref(d), M.W, M.H, 1, _ptr(tile_of), sp), 'die_agent_move')
+        if self._frozen is None:            # AgentIndexer's array: what `self.agents` was when the lifecycle first rebound it
+            self._frozen = (A.x.clone(), A.y.clone(), A.alive.clone(), int(A.alive.sum().item()))
+        fx, fy, falive, K0 = self._frozen
+        d.has_dead_slots = int(K0 < A.N)
+        af = _lib.Agents(A.N, _ptr(fx), _ptr(fy), _ptr(falive), _ptr(A.agent_food), _ptr(A.slot))
+        _lib.check(_lib.lib.die_agent_claim_feed(C.byref(m), C.byref(af), C.byref(u), C.byref(d), ws, wsn, sp), 'die_agent_claim_feed')
+        if d.has_dead_slots:
+            _lib.check(_lib.lib.die_agent_dead_slots(C.byref(m), C.byref(af), C.byref(u), C.byref(d), ws, wsn, sp), 'die_agent_dead_slots')
+        _lib.check(_lib.lib.die_step_reduce_ex(C.byref(a), _ptr(result), ws, wsn, 3 if d.has_dead_slots else 0, K0, sp), 'die_step_reduce_ex')
+        _lib.check(_lib.lib.die_medium_deposit_feed_diffuse(C.byref(m), C.byref(d), sp), 'die_medium_deposit_feed_diffuse')
+        _lib.check(_lib.lib.die_agents_lifecycle(C.byref(a), sp), 'die_agents_lifecycle')
+
     def step(self, action):
         """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
         result = torch.empty(2, dtype=torch.float64, device=self.device)
         fused = binned = False
-        if isinstance(action, PendingAction) and action.pending and action.agents is self.agents \
+        if self.dynamics.agents_die and self.dynamics.compat == 'reference':
+            self._step_compat(action, result)
+            fused = binned = True           # (no re-sorting either: the frozen copy is in this array order)
+        if not fused and isinstance(action, PendingAction) and action.pending and action.agents is self.agents \
                 and action.medium is self.medium and action.slot is self.agents.slot and self._fuse_forward:
             fused = binned = self._pic_step(action, result)
         if not fused and isinstance(action, PendingAction) and action.pending and action.agents is self.agents \

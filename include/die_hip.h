@@ -176,6 +176,11 @@ int64_t die_workspace_bytes(int32_t W, int32_t H, int64_t N);
 int die_gradient_forward(const die_medium* m, const die_agents* a, die_gradient_agent* g,
                          die_action* out, void* stream);
 
+/* GradientAgent.render (core/agent/gradient.py:126-135): rgb_out (W, H, 3) fp32 = 0.5 * (stack(gx, gy, 0) + 1) of the
+ * normalised, clipped np.gradient field of the chem plane (_get_gradient, :55-71). */
+int die_gradient_render(const void* chem, int32_t W, int32_t H, int32_t dtype, int32_t normalized, float grad_clip,
+                        float* rgb_out, void* stream);
+
 /* BrownianAgent.forward (core/agent/static.py:40-50): (b-a)*u.round(3)+a per channel, × alive. */
 int die_brownian_forward(const die_agents* a, float move_scale, float deposit_scale,
                          uint64_t seed, uint32_t step, die_action* out, void* stream);
@@ -252,9 +257,14 @@ int die_agent_move(const die_medium* m, const die_agents* a, const die_action* a
 int die_forward_move(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
                      const die_dynamics* d, int32_t tile_w, int32_t tile_h, int32_t tiles_y, int32_t* tile_of, void* stream);
 /* die_step_reduce when the caller knows whether the dead-slot pass ran: without it only the
- * move/claim partials are summed and num_alive = alive_const. */
+ * move/claim partials are summed and num_alive = alive_const (with_second_pass: 0 claim pass only; 1 both passes and the
+ * dead-slot pass's alive count; 2 ghost tiles; 3 both passes' gains with num_alive = alive_const). */
 int die_step_reduce_ex(const die_agents* a, die_step_result* result, void* workspace, int64_t workspace_bytes,
                        int32_t with_second_pass, int64_t alive_const, void* stream);
+/* _agent_lifecycle (core/env.py:245-250) on its own: every channel of the slots with agent_food <= 1e-4 becomes 0.  Used by
+ * the reference-compatible agents_die mode (die_amd/env.py Env._step_compat), whose claim / feeding lookups run on a frozen
+ * copy of the agent array — the reference's stale AgentIndexer (core/env.py:249 vs core/utils.py:22). */
+int die_agents_lifecycle(const die_agents* a, void* stream);
 /* Decomposed step, second half: claim + feeding of die_agent_move_claim without the move. */
 int die_agent_claim_feed(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,
                          void* workspace, int64_t workspace_bytes, void* stream);

@@ -116,6 +116,7 @@ class RefDynamics:
     agents_die: bool = False
     agents_born: bool = False
     init_agent_ratio: float = 0.1
+    compat: str = 'intended'         # 'reference': keep the AgentIndexer's stale array after _agent_lifecycle (see RefEnv)
 
 
 def move_handle_boundary(coords: np.ndarray, boundary: str) -> np.ndarray:
@@ -159,6 +160,9 @@ class RefEnv:
         assert self.medium.ndim == 3 and self.medium.shape[0] == 3
         assert self.agents.ndim == 2 and self.agents.shape[0] == 4
         self.last_gained = None
+        # AgentIndexer(field_size, self.agents) of Env._init_data (core/env.py:83) holds THIS array object
+        # (core/utils.py:22); see agent_lifecycle
+        self._idx_agents = self.agents
 
     @property
     def field_size(self) -> Tuple[int, int]:
@@ -170,8 +174,8 @@ class RefEnv:
         return cell(xy[0], W), cell(xy[1], H)
 
     def alive_index(self) -> np.ndarray:
-        """core/utils.py:67-75."""
-        return (self.agents[A_ALIVE] > 0).nonzero()[0]
+        """core/utils.py:67-75 (the indexer's array)."""
+        return (self._idx_agents[A_ALIVE] > 0).nonzero()[0]
 
     @property
     def num_alive(self) -> int:
@@ -186,7 +190,7 @@ class RefEnv:
         """core/env.py:204-215.  `.loc[cells] += deposit` is get–add–set with fancy
         indices: on a shared cell the LAST alive slot in index order wins."""
         idx = self.alive_index()
-        ix, iy = self.cells_of(self.agents[[A_X, A_Y]][:, idx])
+        ix, iy = self.cells_of(self._idx_agents[[A_X, A_Y]][:, idx])
         deposit = action[U_DEP, idx]
         chem = self.medium[M_CHEM]
         chem[ix, iy] = chem[ix, iy] + deposit
@@ -198,7 +202,7 @@ class RefEnv:
         d = self.dynamics
         food = self.medium[M_FOOD]
         consumed_field = d.rate_feed * food * (self.medium[M_AGENTS] > 0)
-        ix, iy = self.cells_of(self.agents[[A_X, A_Y]])          # all N slots (only_alive=False)
+        ix, iy = self.cells_of(self._idx_agents[[A_X, A_Y]])     # all N slots (only_alive=False), the indexer's array
         consumed = consumed_field[ix, iy]
         if not d.food_infinite:
             self.medium[M_FOOD] = food - consumed_field
@@ -208,12 +212,16 @@ class RefEnv:
         return gained
 
     def agent_lifecycle(self):
-        """core/env.py:245-261.  Intended semantics (zero the slots without food).  The
-        reference rebinds self.agents here while AgentIndexer keeps the old array
-        (core/utils.py:22) — that stale-indexer bug is deliberately not reproduced."""
+        """core/env.py:245-261: `self.agents = self.agents.where(have_food, 0)` REBINDS the attribute to a new array
+        while the AgentIndexer keeps the one it was built with (core/utils.py:22).  compat='reference' reproduces
+        that: from now on deposits, layout, feeding look-ups and num_alive read the old array (positions after this
+        step's move, alive flags never cleared), while moves, agent_food and the zeroing go to the new one.
+        compat='intended': the indexer follows the new array (what the code evidently means)."""
         if self.dynamics.agents_die:
             have_food = self.agents[A_FOOD] > 1e-4
             self.agents = np.where(have_food, self.agents, 0.)
+            if self.dynamics.compat != 'reference':
+                self._idx_agents = self.agents
 
     def medium_resource_dynamics(self):
         """core/env.py:147-150."""

@@ -1184,3 +1184,61 @@ def test_neural_automata_on_f16_fields_and_after_binned_steps(die):
     ws = [k.weight.detach().numpy().astype(np.float64) for k in nca.model.conv_layers()]
     assert m[0].sum() > 0
     assert np.allclose(action.to_numpy(), R.nca_forward((a, m), ws), rtol=RTOL, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------ reference-compat switches
+@pytest.mark.parametrize('N,K', [(3000, 3000), (2500, 1800)])
+def test_agents_die_reference_compat_mode(die, N, K):
+    """Dynamics(agents_die=True, compat='reference'): what the reference really does once `_agent_lifecycle` has rebound
+    `self.agents` (core/env.py:249) while the AgentIndexer still holds the old array (core/utils.py:22) — deposits, the
+    agents channel and feeding stay at the positions of the first step's move, num_agents never drops, the agents the
+    policy sees keep moving / starving / being zeroed.  Against the oracle's restatement of exactly that, several steps,
+    with and without slots that were dead from the start; and the two modes must really differ."""
+    W, H = 64, 48
+    rs = np.random.RandomState(N)
+    medium, agents = random_state(W, H, N, K, rs, collide=0.3)
+    agents[3] = f32(agents[3] * 0.03)                         # little food: many starve within a few steps
+    actions = [quantised_action(N, rs, 3.0 / W) for _ in range(5)]
+    runs = {}
+    for compat in ('reference', 'intended'):
+        env = die.Env.from_numpy(medium, agents, die.Dynamics(agents_die=True, compat=compat))
+        ref = R.RefEnv(medium, agents, R.RefDynamics(agents_die=True, compat=compat, rate_feed=float(np.float32(0.1)),
+                                                     rate_decay_chem=float(np.float32(0.1))))
+        infos = []
+        for act in actions:
+            _, rew, term, _, info = env.step(act)
+            _, rrew, rterm, _, rinfo = ref.step(act)
+            assert info['num_agents'] == rinfo['num_agents'] and term == rterm
+            assert abs(rew - rrew) <= 1e-5 * np.abs(ref.last_gained).sum() + 1e-9
+            infos.append(info['num_agents'])
+        m, a = env.medium.to_numpy(), env.agents.to_numpy()
+        assert np.array_equal(m[0], ref.medium[0])
+        assert np.allclose(m[1], ref.medium[1], rtol=RTOL, atol=1e-8) and np.allclose(m[2], ref.medium[2], rtol=RTOL, atol=1e-7)
+        assert np.array_equal(a[2], ref.agents[2]) and np.abs(a[:2] - ref.agents[:2]).max() <= 2.0 ** -31
+        assert np.allclose(a[3], ref.agents[3], rtol=1e-5, atol=1e-7)
+        runs[compat] = (infos, a[2].sum(), m[0].sum())
+    assert runs['reference'][0] == [K] * 5                      # the stale indexer never sees a death
+    assert runs['intended'][0][-1] < K and runs['reference'][1] < K        # … although agents do die in both
+    assert runs['reference'][2] != runs['intended'][2]
+
+
+def test_gradient_agent_render_is_the_gradient_field(die):
+    """GradientAgent.render (core/agent/gradient.py:126-135): one white pixel before the first forward, then
+    0.5·(stack(gx, gy, 0) + 1) of the normalised, clipped np.gradient field of the chem the last forward saw — also after
+    the step that followed it."""
+    W, H, N = 96, 64, 1500
+    rs = np.random.RandomState(4)
+    medium, agents = random_state(W, H, N, N, rs)
+    env = die.Env.from_numpy(medium, agents)
+    ag = die.PhysarumAgent(max_agents=N, seed=1, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    assert ag.render()[0].shape == (1, 1, 3)
+    obs = env._get_current_obs
+    action = ag.forward(obs)
+    g = R.gradient_field(medium[2])
+    want = 0.5 * (np.stack([g[0], g[1], np.zeros_like(g[0])], axis=-1) + 1.)
+    img = ag.render()[0]
+    assert img.shape == (W, H, 3)
+    bad = ~np.isclose(img, want, rtol=1e-5, atol=2e-6)
+    assert bad.mean() < 1e-4                                   # cells whose norm sits on grad_clip in fp32 vs float64
+    env.step(action)
+    assert np.array_equal(ag.render()[0], img)                 # the fused step left the plane forward() saw untouched
