@@ -581,3 +581,24 @@ def nca_forward(obs, weights, scale=0.1, deposit=1.0, with_agent_channel=True) -
     sense = nca_sense(medium, weights, with_agent_channel)
     ix, iy = cell(agents[A_X], W), cell(agents[A_Y], H)
     return sense[:, ix, iy] * np.array([scale, scale, deposit])[:, None]
+
+
+class RefWaveSequence:
+    """FieldSequence / WaveSequence (core/data_init.py:15-89): `__iter__` cycles over arange(*t_bounds, dt) yielding
+    wave_field(t); `get_flow_operator` (:29-38) returns food_flow(current) = scale·next(it) + (1 − decay)·current."""
+
+    def __init__(self, field_size, dt: float = 0.01, t_bounds=(0, 10)):
+        self._size = tuple(field_size)
+        self._ts = np.arange(*t_bounds, dt)
+
+    def __iter__(self):
+        from itertools import cycle
+        for t in cycle(self._ts):
+            yield wave_field(self._size[0], self._size[1], t)
+
+    def get_flow_operator(self, scale: float = 1.0, decay: float = 0.0):
+        it = iter(self)
+
+        def food_flow(current):
+            return scale * next(it) + (1 - decay) * current
+        return food_flow

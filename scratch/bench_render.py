@@ -1,7 +1,7 @@
 """Render path at 4096²: device frames (die_render_frames + downloads) vs the reference-style host renderer."""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np, torch, die_amd
-from die_amd.render import EnvRenderer
+from oracle.render_ref import EnvRenderer
 W = H = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=0.15), seed=1, max_agents='alive', sync=False)
 agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=1, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))

@@ -171,6 +171,40 @@ def main():
     w._grid = u['get_meshgrid']((9, 6))
     out['wave_9x6_t025'] = wv['__getitem__'](w, 0.25)
 
+    # ---- FieldSequence.get_flow_operator / __iter__ (core/data_init.py:29-38): four calls over a 3-point time axis, so
+    # that the cycle wraps; WaveSequence.__getitem__ supplies the fields
+    from itertools import cycle
+    fs = _exec(_functions('core/data_init.py', ['get_flow_operator', '__iter__'], cls='FieldSequence'), {'np': np, 'cycle': cycle})
+
+    class Seq:
+        pass
+    Seq.__iter__ = fs['__iter__']
+    Seq.get_flow_operator = fs['get_flow_operator']
+    Seq.__getitem__ = wv['__getitem__']
+    sq = Seq()
+    sq._grid = u['get_meshgrid']((7, 5))
+    sq._ts = np.arange(0, 0.75, 0.25)
+    flow = sq.get_flow_operator(scale=0.5, decay=0.25)
+    cur = rs.uniform(0, 1, (7, 5))
+    out['flow_in'] = cur.copy()
+    for k in range(4):
+        cur = flow(cur)
+        out[f'flow_out{k}'] = np.asarray(cur).copy()
+
+    # ---- FieldTrace (core/render.py:9-30): three updates
+    ft = _exec(_functions('core/render.py', ['__init__', 'update'], cls='FieldTrace'), {'np': np})
+
+    class Trace:
+        pass
+    Trace.__init__ = ft['__init__']
+    Trace.update = ft['update']
+    tr = Trace((6, 4), trace_steps=8)
+    fields = (rs.rand(3, 6, 4) < 0.3).astype(np.float64)
+    out['trace_fields'] = fields
+    for k in range(3):
+        tr.update(fields[k])
+        out[f'trace_out{k}'] = tr._trace_field.copy()
+
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, len(out), 'arrays')
 

@@ -967,7 +967,7 @@ def test_custom_food_flow_and_render(die):
 def test_device_render_matches_the_host_renderer(die):
     """Env.render() builds the frames of core/render.py:76-132 on the device (die_render_frames); the checker is the
     same renderer run on downloaded float64 arrays, as the reference does it, over several steps (the trace has state)."""
-    from die_amd.render import EnvRenderer
+    from oracle.render_ref import EnvRenderer
     W, H, N, K = 40, 56, 700, 520
     rs = np.random.RandomState(4)
     medium, agents = random_state(W, H, N, K, rs)

@@ -170,3 +170,28 @@ def test_perlin_noise_properties():
     food = R.perlin_field(64, 48, 8, 1234, threshold=1.0)
     assert food.min() >= 0 and 0.3 < (food > 0).mean() < 0.7 and np.array_equal(food, np.round(food, 3))
     assert (R.perlin_field(64, 48, 8, 1234, threshold=0.1) <= 0.1).all()
+
+
+def test_step_substep_order_is_observable_through_the_food_flow():
+    """core/env.py:101-131: move → deposit + layout → feed → lifecycle → food flow → diffuse/decay.  With a food-flow
+    operator that is not the identity the order shows: feeding sees the food BEFORE the flow, the flow acts on the
+    food AFTER consumption, the deposit lands on the cell the agent MOVED to and is diffused in the same step."""
+    W = H = 6
+    medium = np.zeros((3, W, H))
+    medium[1] = 0.4
+    agents = np.zeros((4, 2))
+    agents[:, 0] = [2 / 5, 3 / 5, 1., 0.5]                      # on cell (2, 3)
+    action = np.array([[1 / 5, 0.], [0., 0.], [2.0, 0.]])       # moves to (3, 3), deposits 2.0; slot 1 is dead and idle
+    flow = lambda food: 2.0 * food + 0.1
+    env = R.RefEnv(medium, agents, R.RefDynamics(op_food_flow=flow))
+    _, reward, term, _, info = env.step(action)
+    eaten = 0.1 * 0.4
+    food = np.full((W, H), 0.4)
+    food[3, 3] -= eaten                                         # consumption at the NEW cell, before the flow
+    assert np.allclose(env.medium[1], flow(food), rtol=0, atol=1e-15)
+    burned = 0.02 * 2.0 + 0.01 * (1 / 5)
+    assert np.isclose(env.agents[3, 0], 0.5 + eaten - burned, rtol=0, atol=1e-15) and np.isclose(reward, eaten - burned)
+    chem = np.zeros((W, H))
+    chem[3, 3] = 2.0
+    assert np.allclose(env.medium[2], R.diffuse_decay_explicit(chem, 0.5, 0.1), rtol=1e-12, atol=1e-15)
+    assert env.medium[0, 3, 3] == 1 and env.medium[0].sum() == 1 and info['num_agents'] == 1 and not term

@@ -124,3 +124,18 @@ def test_ref_boundary_mask_random_wave(G):
     assert np.array_equal(0.9 * G['get_random_raw'].round(3) + 0.1, G['get_random_out_01_1'])
     assert np.allclose(R.wave_field(9, 6, 0.25), G['wave_9x6_t025'], rtol=0, atol=0)
     assert np.array_equal(G['meshgrid_5x7'].shape, (2, 5, 7))
+
+
+def test_ref_flow_operator_sequence_and_field_trace(G):
+    """FieldSequence.get_flow_operator + __iter__ (core/data_init.py:29-38, cycling over the time axis) and
+    FieldTrace.update (core/render.py:29-30), outputs of the reference's own function bodies."""
+    flow = R.RefWaveSequence((7, 5), dt=0.25, t_bounds=(0, 0.75)).get_flow_operator(scale=0.5, decay=0.25)
+    cur = G['flow_in']
+    for k in range(4):
+        cur = flow(cur)
+        assert np.array_equal(cur, G[f'flow_out{k}']), k
+    from oracle.render_ref import FieldTrace
+    tr = FieldTrace((6, 4), trace_steps=8)
+    for k in range(3):
+        tr.update(G['trace_fields'][k])
+        assert np.array_equal(tr.trace, G[f'trace_out{k}'])
