@@ -71,6 +71,7 @@ def parse():
     p.add_argument('--no-pic', action='store_true', help='classic step (claim plane + bucket sort) instead of the tile-binned one')
     p.add_argument('--pic-tile', default='', help='tuning: log2 tile shape of the tile-binned step, e.g. 6,6')
     p.add_argument('--pic-threads', type=int, default=0, help='tuning: workgroup size of the tile-binned agent kernel')
+    p.add_argument('--replicas', type=int, default=0, help='batched env replicas on one GPU (BASELINE configs[4]): R worlds of --size in one launch pair; value = replica-steps/s')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
@@ -237,6 +238,58 @@ def other_cpu_baselines(seed):
     return out
 
 
+def bench_replicas(args, device, agent_kw):
+    """`--replicas R`: R worlds of --size stepped by one launch pair per step (die_forward_env_step_batch), against the
+    same R worlds stepped one Env at a time.  Not the contract metric: its own line, value = replica-steps per second."""
+    import torch
+    import die_amd
+    from die_amd.batch import BatchedEnv, BatchedPhysarumAgent
+    W = H = args.size
+    dt = torch.float16 if args.fields == 'f16' else torch.float32
+    benv = BatchedEnv((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), replicas=args.replicas, seed=args.seed, field_dtype=dt,
+                      device=device)
+    bag = BatchedPhysarumAgent(benv, seed=args.seed, **agent_kw)
+    res = torch.empty((benv.R, 2), dtype=torch.float64, device=device)
+
+    def run(n):
+        for _ in range(n):
+            benv.step(bag, res)
+    run(max(args.warmup, 40))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    dt_b = time.perf_counter() - t0
+    # the same worlds one Env at a time (classic path on small grids; whatever Env picks)
+    envs = [die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed + r, max_agents='alive', device=device,
+                        sync=False, field_dtype=dt) for r in range(min(benv.R, 4))]
+    ags = [die_amd.PhysarumAgent(max_agents=e.agents.N, seed=args.seed + r, **agent_kw) for r, e in enumerate(envs)]
+    obs = [e._get_current_obs for e in envs]
+
+    def run1(n):
+        for _ in range(n):
+            for i, e in enumerate(envs):
+                obs[i], *_ = e.step(ags[i].forward(obs[i]))
+    run1(40)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run1(args.steps)
+    torch.cuda.synchronize()
+    dt_1 = (time.perf_counter() - t0) / len(envs)
+    C, K = W * H, sum(benv.n)
+    B = (12 if args.fields == 'f32' else 6) * C * benv.R + (104 if args.fields == 'f32' else 82) * K
+    line = {'metric': 'batched env replica-steps/sec', 'value': round(args.steps * benv.R / dt_b, 1), 'unit': 'replica steps/s', 'n_gpus': 1,
+            'steps': args.steps, 'warmup': max(args.warmup, 40), 'ms_per_step': round(dt_b / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': args.fields, 'data': 'synthetic',
+            'config': {'workload': f'{benv.R} batched replicas of PhysarumAgent {W}x{H} {args.fields} (BASELINE configs[4] form), one launch pair per step',
+                       'alive_agents': K, 'one_env_at_a_time_replica_steps_per_s': round(args.steps / dt_1, 1),
+                       'speedup_vs_one_at_a_time': round((args.steps * benv.R / dt_b) / (args.steps / dt_1), 2)},
+            'roofline': {'bound': 'hbm', 'kernel': 'whole batched step', 'achieved': round(B / (dt_b / args.steps) / 1e9, 1), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(B / (dt_b / args.steps) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'algorithmic_bytes_per_launch': B}}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ and not args.force_dist:
@@ -268,6 +321,8 @@ def main():
     W = H = args.size
     agent_kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), turn_angle=30, sense_angle=90,
                     turn_tolerance=0.1, deposit=4.0)
+    if args.replicas > 0 and not dist_on:
+        return bench_replicas(args, device, agent_kw)
     GRIDS = {1: (1, 1), 2: (1, 2), 4: (2, 2), 8: (2, 4)}
     mode, denv = 'single GPU', None
     # A failure anywhere in the decomposed path ends the run with a non-zero status (torch.distributed.run then stops the

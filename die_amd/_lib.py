@@ -74,6 +74,11 @@ class Pic(C.Structure):
                 ('k1_threads', C.c_int32), ('stages', C.c_int32)]
 
 
+class Batch(C.Structure):
+    _fields_ = [('replicas', C.c_int32), ('reserved', C.c_int32), ('plane_stride', C.c_int64), ('agent_stride', C.c_int64),
+                ('seed_stride', C.c_uint64), ('n', C.c_int64 * 64)]
+
+
 class Rect(C.Structure):
     _fields_ = [('plane', C.c_void_p), ('pitch', C.c_int32), ('r0', C.c_int32), ('r1', C.c_int32), ('c0', C.c_int32),
                 ('c1', C.c_int32), ('elem_bytes', C.c_int32), ('buf_offset', C.c_int64)]
@@ -97,6 +102,9 @@ _SIGNATURES = {
                                C.c_void_p]),
     'die_forward_env_step': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                        C.c_void_p, C.c_int64, C.c_void_p]),
+    'die_batch_workspace_bytes': (C.c_int64, [C.c_int32]),
+    'die_forward_env_step_batch': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), _P(Batch), C.c_void_p,
+                                             C.c_void_p, C.c_int64, C.c_void_p]),
     'die_forward_move_claim_tile': (C.c_int, [_P(Medium), _P(Agents), _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                               C.c_int64, C.c_void_p]),
     'die_env_step_finish': (C.c_int, [_P(Medium), _P(Agents), _P(Action), _P(Dynamics), C.c_void_p, C.c_void_p, C.c_int64,

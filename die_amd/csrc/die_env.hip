@@ -125,8 +125,8 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) void k_move_claim(StepArgs a) {
 
 // Agent.forward fused with the first half of Env.step: the action stays in registers between the two
 // (it is still written out for the caller, but never read back), x / y / slot are loaded once.
-template <typename T, int KIND, bool EXT = true>
-__global__ __launch_bounds__(DIE_STEP_BLOCK) void k_forward_move_claim(FwdArgs f, StepArgs a) {
+template <typename T, int KIND, bool EXT>
+__device__ __forceinline__ void forward_move_claim_body(FwdArgs& f, StepArgs& a) {
     long long gsum = 0;
     long long cnt = 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -140,6 +140,40 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) void k_forward_move_claim(FwdArgs f
         gsum += die_fix(move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt));
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
+}
+
+// Agent.forward fused with the first half of Env.step: the action stays in registers between the two
+// (it is still written out for the caller, but never read back), x / y / slot are loaded once.
+template <typename T, int KIND, bool EXT = true>
+__global__ __launch_bounds__(DIE_STEP_BLOCK) void k_forward_move_claim(FwdArgs f, StepArgs a) {
+    forward_move_claim_body<T, KIND, EXT>(f, a);
+}
+
+// R replicas of one world shape in one launch (blockIdx.y = replica): every array of replica r lies `r` strides behind
+// replica 0's, the Philox key is seed + r·seed_stride, its agent count n[r] — otherwise the kernel above.
+struct BatchArgs {
+    int64_t cells, agents;          // strides: cells per plane, agent slots per replica
+    uint64_t seed_stride;
+    int64_t n[DIE_MAX_REPLICAS];
+};
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(DIE_STEP_BLOCK) void k_forward_move_claim_batch(FwdArgs f, StepArgs a, BatchArgs b) {
+    const int r = blockIdx.y;
+    const int64_t pc = b.cells * r, pa = b.agents * r;
+    f.chem = (const T*)f.chem + pc; f.food = (const T*)f.food + pc;
+    f.x += pa; f.y += pa; f.heading_hi += pa; f.heading_lo += pa;
+    if (f.slot) f.slot += pa;
+    if (f.dx) { f.dx += pa; f.dy += pa; f.dep += pa; }
+    f.N = b.n[r]; f.seed += b.seed_stride * (uint64_t)r;
+    a.owner += pc; a.food = (T*)a.food + pc; a.chem = (T*)a.chem + pc;
+    a.x += pa; a.y += pa; a.alive += pa; a.agent_food += pa;
+    if (a.slot) a.slot += pa;
+    a.N = b.n[r];
+    a.part_gain += (int64_t)DIE_MAX_PARTIALS * 3 * r;               // replica r's own workspace partials
+    a.part_alive = a.part_gain + 2 * DIE_MAX_PARTIALS;
+    forward_move_claim_body<T, KIND, false>(f, a);
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.part_alive[0] = a.N;  // every slot is alive: the sweep's reduction reads the count here
 }
 
 template <typename T>
@@ -304,6 +338,7 @@ struct RowsArgs {
     const float* dep;                  // FUSED == 2: per cell the winner's deposit, or DIE_DEP_EMPTY (tile-binned step, die_pic.hip)
     void* food;                        // FUSED only
     int W, H, epoch, food_infinite;
+    int64_t rep_cells;                 // batched replicas (gridDim.z > 1): plane stride in cells; partials / results stride per replica
     int halo;                          // tile mode: cells within `halo` of the array border belong to neighbours
     int wrapx, wrapy;                  // tile mode: this axis spans the whole world (one rank along it) and is periodic
     // k_reduce folded in: workgroup (0, 0) first sums the claim pass's `n_part` partial gains (a kernel boundary lies
@@ -338,6 +373,17 @@ template <> struct Vec4<__half> {
 template <typename T, int R, int FUSED, bool WRAP>
 __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     static_assert(R >= 1 && R <= 4, "one halo lane of 4 columns per side");
+    if (gridDim.z > 1) {                                    // replica blockIdx.z of a batch: same shape, arrays one stride apart
+        const int64_t pc = a.rep_cells * blockIdx.z;
+        a.src = (const T*)a.src + pc; a.dst = (T*)a.dst + pc;
+        if (FUSED == 1) a.claim += pc;
+        if (FUSED) a.food = (T*)a.food + pc;
+        if (a.result) {
+            a.part_gain += (int64_t)DIE_MAX_PARTIALS * 3 * blockIdx.z;
+            if (a.part_alive) a.part_alive += (int64_t)DIE_MAX_PARTIALS * 3 * blockIdx.z;
+            a.result += blockIdx.z;
+        }
+    }
     if (FUSED && a.result && blockIdx.y == gridDim.y - 1) {
         // an extra row of workgroups past the field: (0, last) reduces, the others have nothing to do.  (Doing it as a
         // prologue of workgroup (0, 0) made the whole sweep 10 µs longer: all its workgroups are resident at once, so
@@ -486,10 +532,10 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
 }
 
 template <typename T, int FUSED, bool WRAP = true>
-static int launch_rows(const RowsArgs& a, int R, hipStream_t s) {
+static int launch_rows(const RowsArgs& a, int R, hipStream_t s, int replicas = 1) {
     const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
     constexpr int WPB = DIF_BLOCK / DIE_WAVE;
-    dim3 grid((strips + WPB - 1) / WPB, (a.W + DIF_ROWS - 1) / DIF_ROWS + (FUSED && a.result ? 1 : 0));
+    dim3 grid((strips + WPB - 1) / WPB, (a.W + DIF_ROWS - 1) / DIF_ROWS + (FUSED && a.result ? 1 : 0), replicas);
     switch (R) {
         case 1: k_diffuse_rows<T, 1, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
         case 2: k_diffuse_rows<T, 2, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
@@ -546,7 +592,7 @@ static int diffuse_decay_mode(const void* src, void* dst, int32_t W, int32_t H, 
         RowsArgs ra;
         double wd[2 * DIF_MAXR + 1];
         gaussian_taps(sigma, wd);
-        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.dep = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+        ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.dep = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0; ra.rep_cells = 0;
         ra.wrapx = ra.wrapy = 1; ra.part_gain = nullptr; ra.part_alive = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
         ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
         for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
@@ -727,7 +773,7 @@ extern "C" int die_diffuse_decay_tile(const void* src, void* dst, int32_t W, int
     RowsArgs ra;
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(sigma, wd);
-    ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.dep = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0;
+    ra.src = src; ra.dst = dst; ra.claim = nullptr; ra.dep = nullptr; ra.food = nullptr; ra.W = W; ra.H = H; ra.epoch = 0; ra.halo = 0; ra.rep_cells = 0;
     ra.wrapx = ra.wrapy = 0; ra.part_gain = nullptr; ra.part_alive = nullptr; ra.n_part = 0; ra.result = nullptr; ra.alive_const = 0;
     ra.food_infinite = 1; ra.keep = (float)(1.0 - (double)decay); ra.rate_feed = 0.f;
     for (int k = 0; k <= 2 * R; ++k) ra.w[k] = (float)wd[k];
@@ -915,6 +961,79 @@ extern "C" int die_forward_env_step(const die_medium* m, const die_agents* a, di
     return env_step_tail(m, a, act, d, result, ws, ws_bytes, stream);
 }
 
+extern "C" int64_t die_batch_workspace_bytes(int32_t replicas) {
+    return replicas >= 1 && replicas <= DIE_MAX_REPLICAS ? (int64_t)replicas * WS_PARTS : -1;
+}
+
+extern "C" int die_forward_env_step_batch(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                                          const die_dynamics* d, const die_batch* b, die_step_result* results, void* ws,
+                                          int64_t ws_bytes, void* stream) {
+    const char* who = "die_forward_env_step_batch";
+    DIE_REQUIRE(m && a && g && d && b && results && ws, "%s: null argument", who);
+    DIE_REQUIRE(b->replicas >= 1 && b->replicas <= DIE_MAX_REPLICAS, "%s: 1..%d replicas", who, DIE_MAX_REPLICAS);
+    DIE_REQUIRE(ws_bytes >= die_batch_workspace_bytes(b->replicas), "%s: workspace too small", who);
+    DIE_REQUIRE(m->gW <= 0 && !m->sense_mask && !d->has_dead_slots && !d->agents_die && !d->staged,
+                "%s: periodic single-tile replicas with every slot alive (no agents_die, no sense mask)", who);
+    DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "%s: chem_next must be a second plane", who);
+    DIE_REQUIRE(b->plane_stride >= (int64_t)m->W * m->H && b->agent_stride >= a->N, "%s: strides smaller than a replica", who);
+    if (!fused_step_applies(m, d)) {
+        die_set_error("%s: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4", who);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    FwdArgs f;
+    int rc = die_fill_fwd_args(f, m, a, g, act, who);
+    if (rc != DIE_OK) return rc;
+    // fill_args checks the per-replica workspace of the single-world step; here only the partial arrays are used
+    DIE_REQUIRE(m->epoch >= 1 && m->epoch <= DIE_OWNER_EPOCH_MAX && m->owner && a->alive && a->agent_food, "%s: bad medium / agents", who);
+    if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
+        die_set_error("%s: boundary %d is not representable in Q0.32", who, d->boundary);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    DIE_REQUIRE(d->cost == DIE_COST_LINEAR || d->cost == DIE_COST_ZERO, "%s: bad cost operator %d", who, d->cost);
+    StepArgs k = {};
+    k.g = die_geo_of(m); k.epoch = m->epoch; k.N = a->N; k.do_move = 1; k.do_claim = 1; k.tile_w = k.tile_h = k.tiles_y = 1;
+    k.owner = (unsigned long long*)m->owner; k.food = m->food; k.chem = m->chem;
+    k.x = a->x; k.y = a->y; k.slot = a->slot; k.alive = a->alive; k.agent_food = a->agent_food;
+    k.dx = act ? act->dx : nullptr; k.dy = act ? act->dy : nullptr; k.dep = act ? act->deposit : nullptr;
+    k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
+    k.boundary = d->boundary; k.cost = d->cost; k.food_infinite = d->food_infinite;
+    k.part_gain = (long long*)ws;
+    BatchArgs ba;
+    ba.cells = b->plane_stride; ba.agents = b->agent_stride; ba.seed_stride = b->seed_stride;
+    int64_t nmax = 0;
+    for (int r = 0; r < DIE_MAX_REPLICAS; ++r) {
+        ba.n[r] = r < b->replicas ? b->n[r] : 0;
+        DIE_REQUIRE(r >= b->replicas || (b->n[r] >= 1 && b->n[r] <= b->agent_stride), "%s: replica %d has %lld agents", who, r, (long long)b->n[r]);
+        if (ba.n[r] > nmax) nmax = ba.n[r];
+    }
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(step_grid(nmax), b->replicas);
+    if (m->dtype == DIE_F32) {
+        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim_batch<float, DIE_AGENT_PHYSARUM><<<grid, DIE_STEP_BLOCK, 0, s>>>(f, k, ba);
+        else k_forward_move_claim_batch<float, DIE_AGENT_GRADIENT><<<grid, DIE_STEP_BLOCK, 0, s>>>(f, k, ba);
+    } else {
+        if (g->kind == DIE_AGENT_PHYSARUM) k_forward_move_claim_batch<__half, DIE_AGENT_PHYSARUM><<<grid, DIE_STEP_BLOCK, 0, s>>>(f, k, ba);
+        else k_forward_move_claim_batch<__half, DIE_AGENT_GRADIENT><<<grid, DIE_STEP_BLOCK, 0, s>>>(f, k, ba);
+    }
+    DIE_CHECK_LAUNCH(who);
+    // the field sweep of every replica in one launch (gridDim.z), each with its own reduction workgroup
+    const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
+    RowsArgs ra;
+    double wd[2 * DIF_MAXR + 1];
+    gaussian_taps(d->diffuse_sigma, wd);
+    ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.dep = nullptr; ra.food = m->food;
+    ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = 0; ra.rep_cells = b->plane_stride;
+    ra.wrapx = ra.wrapy = 1;
+    ra.part_gain = (const long long*)ws; ra.part_alive = (const long long*)ws + 2 * DIE_MAX_PARTIALS; ra.n_part = (int)grid.x;
+    ra.result = results; ra.alive_const = 0;
+    ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;
+    for (int q = 0; q <= 2 * R; ++q) ra.w[q] = (float)wd[q];
+    rc = m->dtype == DIE_F32 ? launch_rows<float, 1, true>(ra, R, s, b->replicas) : launch_rows<__half, 1, true>(ra, R, s, b->replicas);
+    if (rc != DIE_OK) return rc;
+    DIE_CHECK_LAUNCH(who);
+    return DIE_OK;
+}
+
 static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int halo, bool tile, void* stream,
                                 const char* who, const long long* part_gain, int n_part, die_step_result* result,
                                 long long alive_const, const long long* part_alive, const float* dep_plane) {
@@ -932,7 +1051,7 @@ static int deposit_feed_diffuse(const die_medium* m, const die_dynamics* d, int 
     double wd[2 * DIF_MAXR + 1];
     gaussian_taps(d->diffuse_sigma, wd);
     ra.src = m->chem; ra.dst = m->chem_next; ra.claim = (const unsigned long long*)m->owner; ra.dep = dep_plane; ra.food = m->food;
-    ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo;
+    ra.W = m->W; ra.H = m->H; ra.epoch = m->epoch; ra.food_infinite = d->food_infinite; ra.halo = halo; ra.rep_cells = 0;
     ra.wrapx = tile && m->gW > 0 && m->W == m->gW; ra.wrapy = tile && m->gW > 0 && m->H == m->gH;
     ra.part_gain = part_gain; ra.part_alive = part_alive; ra.n_part = n_part; ra.result = result; ra.alive_const = alive_const;
     ra.keep = (float)(1.0 - (double)d->rate_decay_chem); ra.rate_feed = d->rate_feed;

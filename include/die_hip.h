@@ -207,6 +207,25 @@ int die_forward_env_step(const die_medium* m, const die_agents* a, die_gradient_
                          const die_dynamics* d, die_step_result* result, void* workspace, int64_t workspace_bytes,
                          void* stream);
 
+/* R replicas of one world shape stepped in ONE launch pair (BASELINE configs[4]: batched env replicas; small grids are
+ * launch-bound one at a time).  `m`, `a`, `g`, `act` describe replica 0; every array of replica r starts r strides further
+ * (planes: plane_stride elements, per-agent arrays: agent_stride elements; results[r]); replica r holds n[r] agents (all
+ * alive) and draws from Philox key g->seed + r * seed_stride — so replica r computes exactly what a stand-alone world with
+ * that seed computes.  `act` may be NULL (no action written).  Same restrictions as die_forward_env_step. */
+#define DIE_MAX_REPLICAS 64
+typedef struct die_batch {
+    int32_t replicas;
+    int32_t reserved;
+    int64_t plane_stride;
+    int64_t agent_stride;
+    uint64_t seed_stride;
+    int64_t n[DIE_MAX_REPLICAS];
+} die_batch;
+int64_t die_batch_workspace_bytes(int32_t replicas);
+int die_forward_env_step_batch(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
+                               const die_dynamics* d, const die_batch* b, die_step_result* results, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
 /* First kernel of die_forward_env_step alone (forward + move + claim + feeding of alive slots). */
 int die_forward_move_claim(const die_medium* m, const die_agents* a, die_gradient_agent* g, const die_action* act,
                            const die_dynamics* d, void* workspace, int64_t workspace_bytes, void* stream);

@@ -1242,3 +1242,33 @@ def test_gradient_agent_render_is_the_gradient_field(die):
     assert bad.mean() < 1e-4                                   # cells whose norm sits on grad_clip in fp32 vs float64
     env.step(action)
     assert np.array_equal(ag.render()[0], img)                 # the fused step left the plane forward() saw untouched
+
+
+# ------------------------------------------------------------------------------------ batched replicas
+@pytest.mark.parametrize('W,H,R,f16', [(64, 48, 5, False), (256, 128, 3, True)])
+def test_batched_replicas_equal_stand_alone_runs(die, W, H, R, f16):
+    """die_forward_env_step_batch: R replicas in one launch pair.  Replica r must be, bit for bit, the stand-alone
+    Env(seed + r) driven by PhysarumAgent(seed + r): fields, agents, headings, rewards — across an epoch wrap of the
+    claim plane (33 steps)."""
+    from die_amd.batch import BatchedEnv, BatchedPhysarumAgent
+    dt = torch.float16 if f16 else torch.float32
+    kw = dict(scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+    steps = 33
+    benv = BatchedEnv((W, H), die.Dynamics(init_agent_ratio=0.15), replicas=R, seed=40, field_dtype=dt)
+    bag = BatchedPhysarumAgent(benv, seed=7, **kw)
+    res = benv.run(bag, steps)
+    rew, alive = BatchedEnv.read_results(res)
+    assert len(set(benv.n)) > 1                                   # replicas of different sizes share the launch
+    for r in range(R):
+        env = die.Env((W, H), die.Dynamics(init_agent_ratio=0.15), seed=40 + r, max_agents='alive', field_dtype=dt)
+        ag = die.PhysarumAgent(max_agents=env.agents.N, seed=7 + r, **kw)
+        obs = env._get_current_obs
+        want = []
+        for _ in range(steps):
+            obs, rw, _, _, info = env.step(ag.forward(obs))
+            want.append((rw, info['num_agents']))
+        m, a = benv.replica_numpy(r)
+        assert np.array_equal(m, env.medium.to_numpy()), r
+        assert np.array_equal(a, env.agents.to_numpy()), r
+        assert np.array_equal(bag.direction_rads_numpy(r), ag.direction_rads_numpy()), r
+        assert np.array_equal(rew[:, r], np.array([w[0] for w in want])) and np.array_equal(alive[:, r], np.array([w[1] for w in want]))
