@@ -3,7 +3,7 @@
 cd $(dirname $0)/..
 N=$1; shift
 objs=""
-for f in die_agents die_env die_init die_sort die_pack die_ghost die_render die_pic; do
+for f in die_agents die_env die_init die_sort die_pack die_ghost die_render die_pic die_nca; do
   /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -ffp-contract=on "$@" -c die_amd/csrc/$f.hip -o scratch/libs/$f.$N.o &
   objs="$objs scratch/libs/$f.$N.o"
 done

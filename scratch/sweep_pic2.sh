@@ -5,7 +5,7 @@ for cfg in "hip 512" "hip 384" "nofood 512" "nofood 384" "nofood 448" "nofood 32
   set -- $cfg
   lib=$R/die_amd/libdie_hip.so; [ $1 != hip ] && lib=$R/scratch/libs/libdie_$1.so
   d=$R/gpurun_out/sw2_$1_$2; rm -rf $d
-  DIE_AMD_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --kernel-reps 1 --pic-threads $2 > $d.json 2> $d.err || { tail -5 $d.err; exit 1; }
+  DIE_AMD_LIB=$lib timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --kernel-reps 1 --pic-threads $2 > $d.json 2> $d.err || { tail -5 $d.err; exit 1; }
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   echo "== $1 threads $2: $(python3 -c "import json;d=json.load(open('$d.json'));print(d['value'], d['step_ms']['median'])")"
   python3 - $f <<'PY'

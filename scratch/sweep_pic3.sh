@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   lib=$R/scratch/libs/libdie_$v.so
   d=$R/gpurun_out/sw3_$v; rm -rf $d
-  DIE_AMD_LIB=$lib rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --kernel-reps 1 > $d.json 2> $d.err || { tail -5 $d.err; }
+  DIE_AMD_LIB=$lib timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --steps 60 --warmup 10 --no-cpu-baseline --kernel-reps 1 > $d.json 2> $d.err || { tail -5 $d.err; }
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   echo "== $v"
   python3 - $f <<'PY'
