@@ -63,7 +63,7 @@ __device__ __forceinline__ double renorm_rad(double r) {
     // is always representable); a quotient misjudged by the rounding of a / b shows as a wrong sign or size and is
     // put right — the library fmod's general loop is 10 µs of the agent kernel at 2.5 M agents
     const double a = r - DIE_PI_D, b = -DIE_2PI_D;
-    double m = fma(-trunc(a / b), b, a);
+    double m = fma(-trunc(a * (-1.0 / DIE_2PI_D)), b, a);        // (a quotient estimate: no float64 division)
     if (m != 0.0 && (m < 0.0) != (a < 0.0)) m += a < 0.0 ? -DIE_2PI_D : DIE_2PI_D;
     if (fabs(m) >= DIE_2PI_D) m -= a < 0.0 ? -DIE_2PI_D : DIE_2PI_D;
     // np.remainder: the result takes the divisor's sign

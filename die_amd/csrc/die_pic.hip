@@ -128,6 +128,7 @@ __device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int g
 }
 
 #define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
+static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
 
 // Diagnostic build only (-DPIC_STAMPS; scratch/pic_stamps.py): s_memtime at the phase boundaries of K1, written by lane 0
 // of wave 0 behind the error word (the caller allocates 1 + 8·tiles words).  No stamp executes in the shipped kernel.

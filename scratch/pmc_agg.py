@@ -17,4 +17,10 @@ for d in sys.argv[1:]:
                 out[k][c] = round(sum(per.values()) / len(per), 1)
                 out[k]['launches'] = len(per)
 keep = {k: v for k, v in out.items() if any(s in k for s in ('forward_move', 'diffuse_rows', 'k_reduce', 'k_pic_'))}
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+try:
+    import bench
+    keep['kernel_source_sha'] = bench.kernel_source_sha()       # which build of die_amd/csrc these counters belong to
+except Exception as e:
+    keep['kernel_source_sha'] = None
 print(json.dumps(keep, indent=1))
