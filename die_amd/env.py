@@ -78,6 +78,8 @@ class Dynamics:
 
 
 class Env(_EnvBase):
+    PIC_MIN_CELLS = 1 << 22          # worlds at least this large take the tile-binned step when it applies
+
     def __init__(self, field_size: Tuple[int, int], dynamics: Optional[Dynamics] = None, *,
                  max_agents: Union[None, int, str] = None, seed: Optional[int] = None,
                  field_dtype: torch.dtype = torch.float32, device: Union[str, torch.device, None] = None,
@@ -300,7 +302,9 @@ class Env(_EnvBase):
         reach = abs(ag._scale) * (max(W, H) - 1)                 # cells per step, at most
         if self._pic_tile is None:
             from .pic import pick_tile
-            self._pic_tile = pick_tile(W, H, reach) or False
+            # small worlds are bound by launches and host calls, and the binned step has one launch more than the classic
+            # one (measured: 256² 47.6 vs 29 µs per step, 1024² 69.6 vs 41, 2048² 71 vs 75): binned from 2048² upwards
+            self._pic_tile = (pick_tile(W, H, reach) if W * H >= self.PIC_MIN_CELLS else None) or False
         return bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1
 
     def _pic_step(self, action, result) -> bool:

@@ -1172,6 +1172,7 @@ def test_neural_automata_on_f16_fields_and_after_binned_steps(die):
     rs = np.random.RandomState(5)
     medium, agents = random_state(W, H, N, N, rs)
     env = die.Env.from_numpy(medium, agents, field_dtype=torch.float16)
+    env._pic_tile = (4, 5)                                       # (worlds this small take the classic step by default)
     phys = die.PhysarumAgent(max_agents=N, seed=1, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
     obs = env._get_current_obs
     for _ in range(3):
