@@ -28,6 +28,27 @@
 // path: die_agents_mark_owner materialises it when somebody asks (DeviceMedium.occupied / owner_slots / render).
 #include "die_forward.h"
 
+#ifndef PIC_K2_FEED
+#define PIC_K2_FEED 1
+#endif
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+};
+template <> struct Vec4<__half> {
+    static __device__ __forceinline__ void ld(const __half* p, float v[4]) {
+        const uint2 t = *(const uint2*)p;
+        const __half2 a = *(const __half2*)&t.x, b = *(const __half2*)&t.y;
+        v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+    }
+    static __device__ __forceinline__ void st(__half* p, const float v[4]) {
+        const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+        uint2 t; t.x = *(const uint32_t*)&a; t.y = *(const uint32_t*)&b;
+        *(uint2*)p = t;
+    }
+};
+
 #ifndef PIC_K1_BLOCK
 #define PIC_K1_BLOCK 512       // ≈ 614 agents stand on a 64×64 tile at ratio 0.15: one or two trips of the loop
 #endif
@@ -339,7 +360,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f,
 
 // K2.  blockIdx.x == number of tiles: the scan workgroup (sizes and offsets of the layout the NEXT step writes:
 // n = s + inc of the layout just written, exclusive scan; its arrival counters are cleared for that step).
-template <int XS, int YS>
+// FEED: the tile's half of _agent_feed (core/env.py:222-228), food −= rate·food on the occupied cells, is done here — K2 is
+// bound by latency and has memory bandwidth to spare, the field sweep is bound by bandwidth (PIC_K2_FEED, measured below).
+template <typename T, int XS, int YS, bool FEED>
 __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* dep_plane) {
     constexpr int TX = 1 << XS, TY = 1 << YS;
     __shared__ __align__(16) unsigned long long s_claim[TX * TY];
@@ -371,6 +394,18 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
     }
     const int tile = blockIdx.x;
     const PicMeta mt = pic_meta_load(p.out, tile, p.ntx, p.nty);
+    // FEED: this thread's 4-cell groups of the food tile, requested now, needed after the claims are in
+    constexpr int V = 16 / (int)sizeof(T), FG = (TX * TY / 4 + PIC_K2_BLOCK - 1) / PIC_K2_BLOCK;
+    float fd[FG][4];
+    if (FEED) {
+        T* food = (T*)p.food;
+#pragma unroll
+        for (int q = 0; q < FG; ++q) {
+            const int i = ((int)threadIdx.x + q * PIC_K2_BLOCK) * 4;
+            if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)((blockIdx.x / p.nty) * TX + row) * p.g.H + (blockIdx.x % p.nty) * TY + col, fd[q]); }
+        }
+        (void)V;
+    }
     for (int i = threadIdx.x; i < TX * TY / 2; i += PIC_K2_BLOCK) ((ulonglong2*)s_claim)[i] = make_ulonglong2(0ull, 0ull);
     pic_ranges_finish(mt, s_base, s_pre);                          // (its barriers also cover the zeroing)
     const uint32_t total = s_pre[9], own = s_pre[1];
@@ -387,14 +422,23 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
     }
     __syncthreads();
     static_assert(TY % 4 == 0, "16-byte stores");
-    for (int i = threadIdx.x * 4; i < TX * TY; i += PIC_K2_BLOCK * 4) {
+#pragma unroll
+    for (int g = 0; g < FG; ++g) {
+        const int i = ((int)threadIdx.x + g * PIC_K2_BLOCK) * 4;
+        if (i >= TX * TY) break;
         const int row = i / TY, col = i - row * TY;
         const ulonglong2 c01 = *(const ulonglong2*)&s_claim[i], c23 = *(const ulonglong2*)&s_claim[i + 2];
         const unsigned long long c[4] = {c01.x, c01.y, c23.x, c23.y};
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) o[q] = c[q] ? (uint32_t)c[q] : DIE_DEP_EMPTY;
-        *(uint4*)(dep_plane + (int64_t)(tx * TX + row) * p.g.H + ty * TY + col) = make_uint4(o[0], o[1], o[2], o[3]);
+        const int64_t off = (int64_t)(tx * TX + row) * p.g.H + ty * TY + col;
+        *(uint4*)(dep_plane + off) = make_uint4(o[0], o[1], o[2], o[3]);
+        if (FEED && (c[0] | c[1] | c[2] | c[3])) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
+            Vec4<T>::st((T*)p.food + off, fd[g]);
+        }
     }
 }
 
@@ -543,8 +587,14 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
 }
 
 template <int XS, int YS>
-static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, hipStream_t s) {
-    k_pic_resolve<XS, YS><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32, bool feed, hipStream_t s) {
+    if (f32) {
+        if (feed) k_pic_resolve<float, XS, YS, true><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+        else k_pic_resolve<float, XS, YS, false><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+    } else {
+        if (feed) k_pic_resolve<__half, XS, YS, true><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+        else k_pic_resolve<__half, XS, YS, false><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+    }
 }
 
 template <typename T, bool STAGE>
@@ -601,6 +651,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.margin = stage ? P : 0;
     const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
+    const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
     DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK, "die_pic_forward_env_step: k1_threads %d", block);
     if (stages & 1) {
@@ -613,14 +664,17 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
         }
     }
     if (stages & 2) {
-        if (p->tile_xs == 6 && p->tile_ys == 6) launch_resolve<6, 6>(k, p->dep_plane, NT, s);
-        else if (p->tile_xs == 5 && p->tile_ys == 7) launch_resolve<5, 7>(k, p->dep_plane, NT, s);
-        else if (p->tile_xs == 5 && p->tile_ys == 6) launch_resolve<5, 6>(k, p->dep_plane, NT, s);
-        else launch_resolve<4, 5>(k, p->dep_plane, NT, s);
+        const bool f32 = m->dtype == DIE_F32;
+        if (p->tile_xs == 6 && p->tile_ys == 6) launch_resolve<6, 6>(k, p->dep_plane, NT, f32, feed_in_k2, s);
+        else if (p->tile_xs == 5 && p->tile_ys == 7) launch_resolve<5, 7>(k, p->dep_plane, NT, f32, feed_in_k2, s);
+        else if (p->tile_xs == 5 && p->tile_ys == 6) launch_resolve<5, 6>(k, p->dep_plane, NT, f32, feed_in_k2, s);
+        else launch_resolve<4, 5>(k, p->dep_plane, NT, f32, feed_in_k2, s);
     }
     DIE_CHECK_LAUNCH("die_pic_forward_env_step");
     if (!(stages & 4)) return DIE_OK;
-    return die_sweep_dep_plane(m, d, p->dep_plane, (const long long*)p->part_gain, NT, result, p->N, stream);
+    die_dynamics dsweep = *d;
+    if (feed_in_k2) dsweep.food_infinite = 1;               // K2 has fed the occupied cells: the sweep leaves the food alone
+    return die_sweep_dep_plane(m, &dsweep, p->dep_plane, (const long long*)p->part_gain, NT, result, p->N, stream);
 }
 
 extern "C" int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream) {
