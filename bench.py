@@ -88,8 +88,8 @@ def algorithmic_bytes(C, K):
         'k_diffuse_rows_fused': 8 * C + 20 * K,   # chem R + W per cell; per agent chem RMW 8 + food RMW 8 + mark 4
         # tile-binned step: the same contract split over its three launches (the claim of the contract is K2's)
         'k_pic_forward_move': 68 * K,     # state R+W 32, action W 12, 6 gathers 24
-        'k_pic_resolve': 4 * K,           # the ownership claim
-        'k_diffuse_rows_dep': 8 * C + 20 * K,
+        'k_pic_resolve': 12 * K,          # the ownership claim 4 + food RMW of the occupied cell 8
+        'k_diffuse_rows_dep': 8 * C + 8 * K,      # chem R + W per cell; per agent chem RMW 8
         'step': 12 * C + 104 * K,
     }
 
@@ -98,23 +98,31 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.js
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
-             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true>', 'k_pic_resolve': 'void k_pic_resolve<6, 6>',
+             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
 WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve')
+# bytes per agent that the tile-binned kernels read as 4-byte-per-lane streams (counted in full by FETCH_SIZE; only the
+# 16-byte-per-lane tile loads are under-counted): K1 x, y, slot, heading hi/lo, agent_food; K2 x, y, slot, deposit
+NARROW_STREAM_BYTES_PER_AGENT = {'k_pic_forward_move': 24, 'k_pic_resolve': 16}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, K=0):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
     (profiles/README.md): (FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE under-counts wide coalesced streams by 2x on gfx950
-    (applied to the kernels whose reads are 16-byte-per-lane streams: the sweep and the tile-binned kernels).  The file carries the sha of the kernel sources it was taken from: when the
-    sources have changed since, the figure would be stale and is reported as null."""
+    (MI355X_MICROARCH.md): the 16-byte-per-lane loads of the sweep and of the tile staging are doubled, the 4-byte-per-lane
+    agent streams of the tile-binned kernels (NARROW_STREAM_BYTES_PER_AGENT x K) are counted in full and left as they are.
+    The file carries the sha of the kernel sources it was taken from: when the sources have changed since, the figure
+    would be stale and is reported as null."""
     try:
         doc = json.load(open(PMC_FILE))
         if doc.get('kernel_source_sha') != kernel_source_sha():
             return None, f'{os.path.relpath(PMC_FILE, ROOT)} was taken from another build of the kernels (sha {doc.get("kernel_source_sha")}): not reported'
         c = doc[PMC_NAMES[kernel]]
-        fetch = c['FETCH_SIZE'] * (2 if kernel in WIDE_STREAM_KERNELS else 1)
-        return int((fetch + c['WRITE_SIZE']) * 1024), (f'{os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command, '
+        fetch = c['FETCH_SIZE'] * 1024
+        if kernel in WIDE_STREAM_KERNELS:
+            narrow = NARROW_STREAM_BYTES_PER_AGENT.get(kernel, 0) * K
+            fetch = 2 * (fetch - narrow) + narrow if fetch > narrow else 2 * fetch
+        return int(fetch + c['WRITE_SIZE'] * 1024), (f'{os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command, '
                                                       f'kernel sources sha {doc["kernel_source_sha"]})')
     except Exception as e:
         return None, f'unavailable: {type(e).__name__}'
@@ -429,7 +437,7 @@ def main():
         kt = time_kernels(env, agent, args.kernel_reps)
         dom = max(kt, key=kt.get)
         ach = B[dom] / (kt[dom] * 1e-6) / 1e9
-        traffic, traffic_src = pmc_traffic(dom)
+        traffic, traffic_src = pmc_traffic(dom, K)
         line['roofline'] = {
             'bound': 'hbm', 'kernel': dom, 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
             'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': traffic, 'traffic_source': traffic_src,

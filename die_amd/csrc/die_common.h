@@ -42,11 +42,15 @@ __device__ __forceinline__ void die_st(__half* p, int64_t i, float v) { p[i] = _
 // ---- Q0.32 fixed-point coordinates -------------------------------------------------------
 // nearest label of linspace(0, 1, n) to X / 2^32, P may lie outside [0, 2^32) (probe offsets):
 // clamp like pandas get_indexer(method='nearest') does (core/utils.py:39-54).
+__device__ __forceinline__ int die_cell_u(uint32_t X, int n) {       // X in [0, 2^32): one 32×32→64 multiply-add, never clamps
+    return (int)(((uint64_t)X * (uint32_t)(n - 1) + 0x80000000ull) >> 32);
+}
 __device__ __forceinline__ int die_cell(int64_t P, int n) {
-    int64_t c = (P * (int64_t)(n - 1) + (int64_t)0x80000000LL) >> 32;   // arithmetic shift == floor
-    c = c < 0 ? 0 : c;
-    c = c > (int64_t)(n - 1) ? (int64_t)(n - 1) : c;
-    return (int)c;
+    // (P·(n−1) + 2^31) >> 32 clamped to [0, n−1]: below 0 the quotient is ≤ 0, from 2^32 on it is ≥ n−1, so only the low
+    // word needs the multiply (a zero-extended coordinate folds to die_cell_u at compile time)
+    const int hi = (int)(P >> 32);
+    const int c = die_cell_u((uint32_t)P, n);
+    return hi == 0 ? c : (hi < 0 ? 0 : n - 1);
 }
 
 // float displacement (fraction of the unit square) → Q0.32 increment

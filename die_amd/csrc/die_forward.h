@@ -168,7 +168,6 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     bool heading_from_vector = true;
     if (KIND == DIE_AGENT_PHYSARUM) {
         // _discrete_turn / _choose_turn (gradient.py:168-208), in float64 like the reference
-        const float dr = sqrtf(ux * ux + uy * uy);
         const double drads = die_np_angle64(ux, uy);
         const double delta = renorm_rad(d64 - drads);
         const double atol = a.turn_rad * a.rtol;
@@ -187,7 +186,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
         const float d2 = (float)d2_64;
         float s2, c2;
         die_sincos(d2, &s2, &c2);
-        const float r = a.normalized ? 1.f : dr;
+        const float r = a.normalized ? 1.f : sqrtf(ux * ux + uy * uy);
         ux = r * c2 - 0.f * s2;                            // polar2xy: (r + 0j)·(cos + i·sin), zero signs included
         uy = r * s2 + 0.f * c2;
         dep_mask = (und_grad || und_turn) ? 0.1f : 1.0f;   // clip(mask, .1, 1) (gradient.py:210-214)

@@ -72,6 +72,7 @@ struct PicArgs {
     die_geo g;
     int ntx, nty, xs, ys;           // tiles per axis, log2 of the tile shape
     int margin;                     // K1 stages chem of the tile ± margin cells (a multiple of the 16-byte vector width)
+    uint32_t inv_cv, inv_fv;        // ceil(2^20 / 16-byte vectors per staged row) of the chem / food tile: i / vpr == (i·inv) >> 20
     PicLayout in, out;
     float* dep;                     // N: deposit of every agent, `out` order (K1 → K2)
     float *adx, *ady, *adep;        // the action handed back to the caller, `in` order
@@ -93,14 +94,15 @@ __device__ __forceinline__ int pic_tile_of(const PicArgs& p, uint32_t X, uint32_
 // Two halves, so that the (dependent) loads of the per-tile words are in flight while the caller stages its tile.
 struct PicMeta { uint32_t base, len; };
 
-__device__ __forceinline__ PicMeta pic_meta_load(const PicLayout& L, int tile, int ntx, int nty) {
+__device__ __forceinline__ int pic_wrap(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }     // v in [−n, 2n)
+
+__device__ __forceinline__ PicMeta pic_meta_load(const PicLayout& L, int tx, int ty, int ntx, int nty) {
     PicMeta mt = {0u, 0u};
     if (threadIdx.x < 9) {
-        const int tx = tile / nty, ty = tile - tx * nty;
         const int q = threadIdx.x;            // 0: (0, 0); 1..8: the ring
         const int k = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
         const int dx = k / 3 - 1, dy = k % 3 - 1;
-        const int nx = (tx + dx + ntx) % ntx, ny = (ty + dy + nty) % nty;
+        const int nx = pic_wrap(tx + dx, ntx), ny = pic_wrap(ty + dy, nty);
         const int t = nx * nty + ny;
         const uint32_t o = L.off[t], s = L.s[t], n = L.n[t];
         mt.base = q == 0 ? o : o + s;
@@ -124,7 +126,7 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
 // copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses, four loads in flight per thread;
 // rows / columns outside the world are skipped (nothing ever reads them: probes clamp at the world's edge)
 template <typename T>
-__device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int gy0, int rows, int vpr, int W, int H) {
+__device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int gy0, int rows, int vpr, uint32_t inv_vpr, int W, int H) {
     constexpr int V = 16 / (int)sizeof(T);
     const int BLOCK = blockDim.x;
     const int nvec = rows * vpr;
@@ -135,9 +137,11 @@ __device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int g
             const int i = i0 + q * BLOCK;
             v[q] = make_uint4(0, 0, 0, 0);
             if (i < nvec) {
-                const int row = i / vpr, cv = i - row * vpr;
+                // row = i / vpr without a division (≈ 35 VALU instructions each; the staging index arithmetic was a quarter
+                // of this kernel's instructions): exact for i·vpr < 2^20, which the host checks
+                const int row = (int)(__umul24((uint32_t)i, inv_vpr) >> 20), cv = i - __mul24(row, vpr);
                 const int gx = gx0 + row, gy = gy0 + cv * V;
-                if (gx >= 0 && gx < W && gy >= 0 && gy < H) v[q] = *(const uint4*)(plane + (int64_t)gx * H + gy);
+                if (gx >= 0 && gx < W && gy >= 0 && gy < H) v[q] = *(const uint4*)(plane + ((int64_t)gx * H + gy));
             }
         }
 #pragma unroll
@@ -160,23 +164,25 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #define PIC_STAMP(k) do { } while (0)
 #endif
 
+#ifndef PIC_K1_MINW
+#define PIC_K1_MINW 6
+#endif
 template <typename T, int KIND, bool STAGE>
-__global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f, PicArgs p) {
+__global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
     __shared__ uint32_t s_base[9], s_pre[10];
     __shared__ uint32_t s_front, s_back, s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
     __shared__ uint32_t s_list[PIC_LIST_CAP];
     __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
-    const int tile = blockIdx.x;
-    const int tx = tile / p.nty, ty = tile - tx * p.nty;
+    const int tx = blockIdx.y, ty = blockIdx.x, tile = tx * p.nty + ty;      // (a 2-D grid: no division by a run-time value)
     const int TX = 1 << p.xs, TY = 1 << p.ys, x0 = tx << p.xs, y0 = ty << p.ys;
     const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE, nwaves = blockDim.x / DIE_WAVE;
     if (threadIdx.x == 0) { s_front = 0; s_back = 0; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
     if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
     PIC_STAMP(0);
     // 1st round trip: the per-tile words (small arrays, L2-resident)
-    const PicMeta mt = pic_meta_load(p.in, tile, p.ntx, p.nty);
+    const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
     pic_ranges_finish(mt, s_base, s_pre);
     PIC_STAMP(1);
@@ -209,9 +215,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f,
         const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
         T* s_chem = (T*)pic_smem;
         T* s_food = s_chem + rows * pitch;
-        pic_stage<T>(s_chem, (const T*)f.chem, x0 - P, y0 - P, rows, pitch / V, p.g.W, p.g.H);
+        pic_stage<T>(s_chem, (const T*)f.chem, x0 - P, y0 - P, rows, pitch / V, p.inv_cv, p.g.W, p.g.H);
         if (PIC_STAGE_FOOD) {
-            pic_stage<T>(s_food, food, x0, y0, TX, TY / V, p.g.W, p.g.H);
+            pic_stage<T>(s_food, food, x0, y0, TX, TY / V, p.inv_fv, p.g.W, p.g.H);
             tm.food = s_food; tm.fx0 = x0; tm.fy0 = y0; tm.fpitch = TY;
         } else {
             tm.food = food; tm.fx0 = 0; tm.fy0 = 0; tm.fpitch = p.g.H;
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, 6) void k_pic_forward_move(FwdArgs f,
     PIC_STAMP(5);
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
         const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
-        atomicAdd(&p.out.inc[((tx + ddx + p.ntx) % p.ntx) * p.nty + (ty + ddy + p.nty) % p.nty], s_inc[threadIdx.x]);
+        atomicAdd(&p.out.inc[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
     }
     if (threadIdx.x == 0) {
         long long t = 0;
@@ -368,7 +374,8 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
     __shared__ __align__(16) unsigned long long s_claim[TX * TY];
     __shared__ uint32_t s_base[9], s_pre[10];
     const int NT = p.ntx * p.nty;
-    if ((int)blockIdx.x == NT) {
+    if ((int)blockIdx.y == p.ntx) {                                // the extra grid row: its first workgroup scans
+        if (blockIdx.x != 0) return;
         __shared__ uint32_t s_sum[PIC_K2_BLOCK];
         const int per = (NT + PIC_K2_BLOCK - 1) / PIC_K2_BLOCK;
         const int lo = threadIdx.x * per, hi = min(lo + per, NT);
@@ -392,8 +399,8 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
         }
         return;
     }
-    const int tile = blockIdx.x;
-    const PicMeta mt = pic_meta_load(p.out, tile, p.ntx, p.nty);
+    const int tx = blockIdx.y, ty = blockIdx.x;
+    const PicMeta mt = pic_meta_load(p.out, tx, ty, p.ntx, p.nty);
     // FEED: this thread's 4-cell groups of the food tile, requested now, needed after the claims are in
     constexpr int V = 16 / (int)sizeof(T), FG = (TX * TY / 4 + PIC_K2_BLOCK - 1) / PIC_K2_BLOCK;
     float fd[FG][4];
@@ -402,14 +409,13 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
 #pragma unroll
         for (int q = 0; q < FG; ++q) {
             const int i = ((int)threadIdx.x + q * PIC_K2_BLOCK) * 4;
-            if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)((blockIdx.x / p.nty) * TX + row) * p.g.H + (blockIdx.x % p.nty) * TY + col, fd[q]); }
+            if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)(tx * TX + row) * p.g.H + ty * TY + col, fd[q]); }
         }
         (void)V;
     }
     for (int i = threadIdx.x; i < TX * TY / 2; i += PIC_K2_BLOCK) ((ulonglong2*)s_claim)[i] = make_ulonglong2(0ull, 0ull);
     pic_ranges_finish(mt, s_base, s_pre);                          // (its barriers also cover the zeroing)
     const uint32_t total = s_pre[9], own = s_pre[1];
-    const int tx = tile / p.nty, ty = tile - tx * p.nty;
     for (uint32_t idx = threadIdx.x; idx < total; idx += PIC_K2_BLOCK) {
         int r = 0;
         while (idx >= s_pre[r + 1]) ++r;
@@ -589,18 +595,18 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
 template <int XS, int YS>
 static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32, bool feed, hipStream_t s) {
     if (f32) {
-        if (feed) k_pic_resolve<float, XS, YS, true><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
-        else k_pic_resolve<float, XS, YS, false><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+        if (feed) k_pic_resolve<float, XS, YS, true><<<dim3(k.nty, k.ntx + 1), PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+        else k_pic_resolve<float, XS, YS, false><<<dim3(k.nty, k.ntx + 1), PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
     } else {
-        if (feed) k_pic_resolve<__half, XS, YS, true><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
-        else k_pic_resolve<__half, XS, YS, false><<<NT + 1, PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+        if (feed) k_pic_resolve<__half, XS, YS, true><<<dim3(k.nty, k.ntx + 1), PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
+        else k_pic_resolve<__half, XS, YS, false><<<dim3(k.nty, k.ntx + 1), PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
     }
 }
 
 template <typename T, bool STAGE>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
-    if (kind == DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE><<<NT, block, lds, s>>>(f, k);
-    else k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE><<<NT, block, lds, s>>>(f, k);
+    if (kind == DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE><<<dim3(k.nty, k.ntx), block, lds, s>>>(f, k);
+    else k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE><<<dim3(k.nty, k.ntx), block, lds, s>>>(f, k);
 }
 
 extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
@@ -649,6 +655,9 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     P = (P + V - 1) / V * V;
     const bool stage = P <= PIC_MAX_MARGIN;
     k.margin = stage ? P : 0;
+    const int vpr_c = (TY + 2 * P) / V, vpr_f = TY / V;     // 16-byte vectors per staged row
+    k.inv_cv = ((1u << 20) + vpr_c - 1) / vpr_c; k.inv_fv = ((1u << 20) + vpr_f - 1) / vpr_f;
+    DIE_REQUIRE(!stage || (int64_t)(TX + 2 * P) * vpr_c * vpr_c < (1 << 20), "die_pic_forward_env_step: staged tile too large for the row index arithmetic");
     const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
