@@ -123,8 +123,11 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
     __syncthreads();
 }
 
-// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses, four loads in flight per thread;
-// rows / columns outside the world are skipped (nothing ever reads them: probes clamp at the world's edge)
+// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses, four loads in flight per thread.
+// Rows / columns outside the world are never read by anybody (probes clamp at the world's edge): their loads are clamped
+// into the plane instead of being skipped, and the last vector is copied again by the threads past the end — no branch,
+// ≈ 9 VALU instructions per vector (the first cut, with a division for the row and tests around the load, spent a
+// quarter of the kernel's instructions here).
 template <typename T>
 __device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int gy0, int rows, int vpr, uint32_t inv_vpr, int W, int H) {
     constexpr int V = 16 / (int)sizeof(T);
@@ -134,21 +137,14 @@ __device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int g
         uint4 v[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q * BLOCK;
-            v[q] = make_uint4(0, 0, 0, 0);
-            if (i < nvec) {
-                // row = i / vpr without a division (≈ 35 VALU instructions each; the staging index arithmetic was a quarter
-                // of this kernel's instructions): exact for i·vpr < 2^20, which the host checks
-                const int row = (int)(__umul24((uint32_t)i, inv_vpr) >> 20), cv = i - __mul24(row, vpr);
-                const int gx = gx0 + row, gy = gy0 + cv * V;
-                if (gx >= 0 && gx < W && gy >= 0 && gy < H) v[q] = *(const uint4*)(plane + ((int64_t)gx * H + gy));
-            }
+            const int i = min(i0 + q * BLOCK, nvec - 1);
+            // row = i / vpr as a multiply and a shift: exact for i·vpr < 2^20, which the host checks
+            const int row = (int)(__umul24((uint32_t)i, inv_vpr) >> 20), cv = i - __mul24(row, vpr);
+            const int gx = min(max(gx0 + row, 0), W - 1), gy = min(max(gy0 + cv * V, 0), H - V);
+            v[q] = *(const uint4*)(plane + (__mul24(gx, H) + gy));
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = i0 + q * BLOCK;
-            if (i < nvec) ((uint4*)dst)[i] = v[q];
-        }
+        for (int q = 0; q < 4; ++q) ((uint4*)dst)[min(i0 + q * BLOCK, nvec - 1)] = v[q];
     }
 }
 
@@ -657,7 +653,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.margin = stage ? P : 0;
     const int vpr_c = (TY + 2 * P) / V, vpr_f = TY / V;     // 16-byte vectors per staged row
     k.inv_cv = ((1u << 20) + vpr_c - 1) / vpr_c; k.inv_fv = ((1u << 20) + vpr_f - 1) / vpr_f;
-    DIE_REQUIRE(!stage || (int64_t)(TX + 2 * P) * vpr_c * vpr_c < (1 << 20), "die_pic_forward_env_step: staged tile too large for the row index arithmetic");
+    DIE_REQUIRE(!stage || ((int64_t)(TX + 2 * P) * vpr_c * vpr_c < (1 << 20) && m->W < (1 << 23) && m->H < (1 << 23) && (int64_t)m->W * m->H < (1ll << 31)),
+                "die_pic_forward_env_step: staged tile / plane too large for the 24-bit index arithmetic of the staging loop");
     const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
