@@ -11,17 +11,19 @@
 //             segment per tile, [off[t], off[t] + n[t]): first the s[t] agents that stand on tile t ("stayers"), then the
 //             n[t] − s[t] agents that stood on it one step ago and have walked onto a neighbouring tile ("leavers").  The
 //             agents standing on t NOW are its stayers plus those leavers of its 8 neighbours whose cell lies in t.
-//   K1        k_pic_forward_move, one workgroup per tile over exactly that set: forward (4 chem taps, food under the
-//             agent: all inside the tile's neighbourhood, i.e. L1/L2 hits), move, feeding of the agent, reward partial;
-//             the agent is written to the OTHER layout as a stayer (front of the segment) or a leaver (back) — positions
+//   K1        k_pic_forward_move, one workgroup per tile over exactly that set: the chem tile ± the probe reach and the food
+//             tile are copied into LDS with 16-byte loads (no gather ever leaves the CU), then forward (4 chem taps, food
+//             under the agent), move, feeding of the agent, reward partial; the agent is written to the OTHER layout as a stayer (front of the segment) or a leaver (back) — positions
 //             from two LDS counters, one arrival counted per leaver in inc[destination].  Because an agent moves less
 //             than a tile per step, a segment of size |set| always fits: no capacity, no overflow.
 //   K2        k_pic_resolve, one workgroup per tile over the same kind of set in the new layout: 64-bit LDS atomicMax of
 //             (slot + 1) << 32 | deposit bits per cell, then the tile of the deposit plane is written with coalesced
-//             16-byte stores: the winner's deposit, or DIE_DEP_EMPTY.  An extra workgroup turns (s, inc) into the segment
+//             16-byte stores: the winner's deposit, or DIE_DEP_EMPTY, and the food of the occupied cells is reduced
+//             (food −= rate·food, core/env.py:222-228; PIC_K2_FEED).  An extra workgroup turns (s, inc) into the segment
 //             sizes and offsets of the next step (exclusive scan over the tiles).
-//   sweep     k_diffuse_rows<T, R, 2, true> (die_env.hip): deposit + feeding + gaussian + decay, reading 4 bytes per cell
-//             of deposit plane instead of 8 bytes of claims; an extra workgroup reduces the reward partials.
+//   sweep     k_diffuse_rows<T, R, 2, true> (die_env.hip): deposit + gaussian + decay, reading 4 bytes per cell of deposit
+//             plane instead of 8 bytes of claims (and no food at all when K2 has done the feeding); an extra workgroup
+//             reduces the reward partials.
 //
 // Per step the agent arrays are streamed once in and once out by K1 and (x, y, slot, deposit) once by K2; the planes are
 // read through the caches by K1 and streamed by the sweep.  The 'agents' channel (claim plane) is not maintained on this

@@ -5,6 +5,9 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 echo "== driver command"; timeout -k 10 300 python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_driver.json 2> $O/${TAG}_bench_driver.err; cut -c1-400 $O/${TAG}_bench_driver.json
+d=$O/${TAG}_prof_driver; rm -rf $d
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $d.json 2> $d.err
+cp $(find $d -name "*kernel_stats.csv" | head -1) $O/${TAG}_driver_cmd_kernel_stats.csv; head -6 $O/${TAG}_driver_cmd_kernel_stats.csv | cut -c1-160
 echo "== classic path"; timeout -k 10 200 python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-pic > $O/${TAG}_bench_classic.json 2>/dev/null; cut -c1-200 $O/${TAG}_bench_classic.json
 echo "== long run"; timeout -k 10 200 python3 $R/bench.py --steps 200 --warmup 20 --no-cpu-baseline > $O/${TAG}_bench_200.json 2>/dev/null; cut -c1-200 $O/${TAG}_bench_200.json
 for v in pic classic; do

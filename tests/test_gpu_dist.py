@@ -39,10 +39,15 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
     if backend == 'gloo-torch-refresh':          # the ghost refresh written with torch index operations (cross-check path)
         os.environ['DIE_GHOST_REFRESH'] = 'torch'
         backend = 'gloo'
+    dev = 'cuda:0'
     if backend == 'nccl':        # one rank: its periodic self-neighbour messages go through RCCL send/recv
         os.environ['DIE_DIST_SELF_VIA_BACKEND'] = '1'
         torch.cuda.set_device(0)
         dist.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device('cuda:0'))
+    elif backend == 'nccl-multi':  # one rank per physical GPU, RCCL between distinct peers (needs a multi-GPU node)
+        dev = f'cuda:{rank}'
+        torch.cuda.set_device(rank)
+        dist.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device(dev))
     else:
         dist.init_process_group('gloo', rank=rank, world_size=size)
     try:
@@ -51,13 +56,13 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         medium, agents, dir0 = _state(W, H, N, K, 5)
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
         env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H) if wave else None, probe_reach=11,
-                                        device='cuda:0', sort_every=sort_every,
+                                        device=dev, sort_every=sort_every,
                                         overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
                                         field_dtype=torch.float16 if f16 else torch.float32)
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
-        local = torch.zeros(cap, dtype=torch.float32, device='cuda:0')
-        local[:env.agents.N] = torch.from_numpy(dir0.astype(np.float32)).cuda()[env.local_slots()]
+        local = torch.zeros(cap, dtype=torch.float32, device=dev)
+        local[:env.agents.N] = torch.from_numpy(dir0.astype(np.float32)).to(dev)[env.local_slots()]
         agent.set_state_local(env.agents, local)
         obs = env._get_current_obs
         rewards = []
@@ -148,6 +153,26 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
         assert np.array_equal(got['medium'][c], m[c])
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
     assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
+
+
+@pytest.mark.parametrize('ghosts,migrate_every', [(True, 3), (False, 1), (False, 4)])
+def test_two_physical_gpus_over_rccl(tmp_path, ghosts, migrate_every):
+    """The RCCL transport between DISTINCT ranks (persistent P2P op lists, several messages per peer matched by issue
+    order, the chem halo on its own stream): one rank per physical GPU.  The pool's test boxes have one GPU, so this is
+    skipped there — until it has run on a multi-GPU node the multi-GPU path counts as unverified."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs')
+    import torch.multiprocessing as mp
+    W, H, N, K, steps = 256, 192, 7000, 6400, 13
+    out = str(tmp_path / 'dist.npz')
+    mp.spawn(_worker, args=(2, _free_port(), (1, 2), W, H, N, K, steps, 2, True, migrate_every, out, 'nccl-multi', ghosts),
+             nprocs=2, join=True)
+    got = np.load(out)
+    m, a, r = _single_device_run(W, H, N, K, steps)
+    assert np.array_equal(got['agents'], a)
+    for c in range(3):
+        assert np.array_equal(got['medium'][c], m[c])
+    assert np.array_equal(got['rewards'], r)
 
 
 # ---------------------------------------------------------------------------------------------------------
