@@ -157,15 +157,19 @@ def time_kernels(env, agent, reps):
         # between them — every kernel meets the cache state it meets in the timed loop
         names = ('k_pic_forward_move', 'k_pic_resolve', 'k_diffuse_rows_dep')
         n = max(reps, 20)
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(n)]
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
         o = env._get_current_obs
         for e in evs:
             env._pic_events = e
             o, *_ = env.step(agent.forward(o))
+            e[4].record()                 # nothing was enqueued since e[3]: what an empty event interval costs
         env._pic_events = None
         torch.cuda.synchronize()
         for k, name in enumerate(names):
             out[name] = sum(e[k].elapsed_time(e[k + 1]) for e in evs) / n * 1e3
+        # an interval between two events contains the kernel AND the completion / dispatch gap around it (the three
+        # intervals add up to the step): rocprofv3's kernel durations are shorter by about this much per launch
+        out['_empty_event_interval'] = sum(e[3].elapsed_time(e[4]) for e in evs) / n * 1e3
         return out
 
     env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
@@ -435,6 +439,7 @@ def main():
         C = W * H
         B = algorithmic_bytes(C, K)
         kt = time_kernels(env, agent, args.kernel_reps)
+        empty_interval = kt.pop('_empty_event_interval', None)
         dom = max(kt, key=kt.get)
         ach = B[dom] / (kt[dom] * 1e-6) / 1e9
         traffic, traffic_src = pmc_traffic(dom, K)
@@ -445,6 +450,7 @@ def main():
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},
             'copy_ceiling_gbs': round(copy_ceiling_gbs(device), 1),
+            'empty_event_interval_us': None if empty_interval is None else round(empty_interval, 2),
             'step': {'algorithmic_bytes': B['step'],
                      'achieved': round(B['step'] / (dt / args.steps) / 1e9, 1),
                      'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
