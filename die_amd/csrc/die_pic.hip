@@ -125,30 +125,44 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
     __syncthreads();
 }
 
-// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses, four loads in flight per thread.
+// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses.
 // Rows / columns outside the world are never read by anybody (probes clamp at the world's edge): their loads are clamped
 // into the plane instead of being skipped, and the last vector is copied again by the threads past the end — no branch,
 // ≈ 9 VALU instructions per vector (the first cut, with a division for the row and tests around the load, spent a
 // quarter of the kernel's instructions here).
 template <typename T>
-__device__ __forceinline__ void pic_stage(T* dst, const T* plane, int gx0, int gy0, int rows, int vpr, uint32_t inv_vpr, int W, int H) {
-    constexpr int V = 16 / (int)sizeof(T);
-    const int BLOCK = blockDim.x;
-    const int nvec = rows * vpr;
-    for (int i0 = threadIdx.x; i0 < nvec; i0 += BLOCK * 4) {
-        uint4 v[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = min(i0 + q * BLOCK, nvec - 1);
-            // row = i / vpr as a multiply and a shift: exact for i·vpr < 2^20, which the host checks
-            const int row = (int)(__umul24((uint32_t)i, inv_vpr) >> 20), cv = i - __mul24(row, vpr);
-            const int gx = min(max(gx0 + row, 0), W - 1), gy = min(max(gy0 + cv * V, 0), H - V);
-            v[q] = *(const uint4*)(plane + (__mul24(gx, H) + gy));
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) ((uint4*)dst)[min(i0 + q * BLOCK, nvec - 1)] = v[q];
+struct PicStage {
+    const T* plane;
+    int gx0, gy0, vpr, nvec, W, H;
+    uint32_t inv_vpr;
+    __device__ __forceinline__ uint4 load(int i) const {
+        constexpr int V = 16 / (int)sizeof(T);
+        i = min(i, nvec - 1);
+        // row = i / vpr as a multiply and a shift: exact for i·vpr < 2^20, which the host checks
+        const int row = (int)(__umul24((uint32_t)i, inv_vpr) >> 20), cv = i - __mul24(row, vpr);
+        const int gx = min(max(gx0 + row, 0), W - 1), gy = min(max(gy0 + cv * V, 0), H - V);
+        return *(const uint4*)(plane + (__mul24(gx, H) + gy));
     }
-}
+    // the first NB vectors of every thread: requested at the very top of the kernel (issue), written to LDS once the
+    // per-tile words and the agent streams have been requested too (commit) …
+    template <int NB> __device__ __forceinline__ void issue(uint4 (&v)[NB]) const {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) v[q] = load((int)threadIdx.x + q * (int)blockDim.x);
+    }
+    template <int NB> __device__ __forceinline__ void commit(T* dst, const uint4 (&v)[NB]) const {
+#pragma unroll
+        for (int q = 0; q < NB; ++q) ((uint4*)dst)[min((int)threadIdx.x + q * (int)blockDim.x, nvec - 1)] = v[q];
+        // … and whatever a larger tile / a smaller workgroup leaves over, four loads in flight per thread
+        const int BLOCK = blockDim.x;
+        for (int i0 = threadIdx.x + NB * BLOCK; i0 < nvec; i0 += BLOCK * 4) {
+            uint4 w[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[q] = load(i0 + q * BLOCK);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ((uint4*)dst)[min(i0 + q * BLOCK, nvec - 1)] = w[q];
+        }
+    }
+};
 
 #define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
 static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
@@ -179,6 +193,17 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     if (threadIdx.x == 0) { s_front = 0; s_back = 0; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
     if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
     PIC_STAMP(0);
+    // the tiles to stage depend on nothing but the tile index: their loads go out first and overlap both round trips below
+    const T* food = (const T*)p.food;
+    constexpr int SV = 16 / (int)sizeof(T);
+    const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
+    const PicStage<T> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows * (pitch / SV), p.g.W, p.g.H, p.inv_cv};
+    const PicStage<T> st_f = {food, x0, y0, TY / SV, TX * (TY / SV), p.g.W, p.g.H, p.inv_fv};
+    uint4 sc[4], sf[2];
+    if (STAGE) {
+        st_c.issue(sc);
+        if (PIC_STAGE_FOOD) st_f.issue(sf);
+    }
     // 1st round trip: the per-tile words (small arrays, L2-resident)
     const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
@@ -186,8 +211,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     PIC_STAMP(1);
     const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
     const unsigned long long below = (1ull << lane) - 1ull;
-    // 2nd round trip, everything at once: this thread's first candidate arrival, the agent streams of this wave's first
-    // chunk of stayers, and the tiles to stage
+    // 2nd round trip: this thread's first candidate arrival and the agent streams of this wave's first chunk of stayers
     uint32_t cj = 0, cX = 0, cY = 0;
     const bool chas = threadIdx.x < ncand;
     if (chas) {
@@ -206,16 +230,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         const uint32_t j = base0 + pidx;
         pX = p.in.x[j]; pY = p.in.y[j]; pS = p.in.slot[j]; pHh = p.in.hhi[j]; pHl = p.in.hlo[j]; pA = p.in.agent_food[j];
     }
-    const T* food = (const T*)p.food;
     FwdTileMem<T> tm;
     if (STAGE) {
-        constexpr int V = 16 / (int)sizeof(T);
-        const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
         T* s_chem = (T*)pic_smem;
         T* s_food = s_chem + rows * pitch;
-        pic_stage<T>(s_chem, (const T*)f.chem, x0 - P, y0 - P, rows, pitch / V, p.inv_cv, p.g.W, p.g.H);
+        st_c.commit(s_chem, sc);
         if (PIC_STAGE_FOOD) {
-            pic_stage<T>(s_food, food, x0, y0, TX, TY / V, p.inv_fv, p.g.W, p.g.H);
+            st_f.commit(s_food, sf);
             tm.food = s_food; tm.fx0 = x0; tm.fy0 = y0; tm.fpitch = TY;
         } else {
             tm.food = food; tm.fx0 = 0; tm.fy0 = 0; tm.fpitch = p.g.H;
