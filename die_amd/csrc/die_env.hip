@@ -340,6 +340,7 @@ struct RowsArgs {
     int W, H, epoch, food_infinite;
     int64_t rep_cells;                 // batched replicas (gridDim.z > 1): plane stride in cells; partials / results stride per replica
     int halo;                          // tile mode: cells within `halo` of the array border belong to neighbours
+    int rpw;                           // rows per wave (rows_per_wave): DIF_ROWS on large fields, fewer on small ones
     int wrapx, wrapy;                  // tile mode: this axis spans the whole world (one rank along it) and is periodic
     // k_reduce folded in: workgroup (0, 0) first sums the claim pass's `n_part` partial gains (a kernel boundary lies
     // between their producer and this sweep) in k_reduce's order and writes the step result — one launch less per step
@@ -440,8 +441,8 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     const int hx = wx ? 0 : a.halo, hy = wy ? 0 : a.halo;
     const int col = wy ? wrap_idx(yb + 4 * (lane - 1), H)    // 16-byte aligned since H % 4 == 0
                        : min(max(yb + 4 * (lane - 1), 0), H - 4);     // tile: clamp, border ring is don't-care
-    const int x0 = blockIdx.y * DIF_ROWS;
-    const int rows = min(DIF_ROWS, W - x0);
+    const int x0 = blockIdx.y * a.rpw;
+    const int rows = min(a.rpw, W - x0);
 
     float win[2 * R + 1][4];
 #pragma unroll
@@ -531,11 +532,20 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     }
 }
 
+// A wave marches down its rows one dependent load at a time (one row of prefetch): on a large field the other waves of
+// the CU hide that, on a small one the chain IS the kernel (256²: 20 iterations ≈ 21 µs).  Fewer rows per wave there:
+// more, shorter waves (each re-reads 2R halo rows, which costs nothing when the field fits the L2).  Same bits.
+static int rows_per_wave(int W, int H, int replicas) {
+    const int64_t cells = (int64_t)W * H * replicas;
+    return cells >= (1ll << 23) ? DIF_ROWS : cells >= (1ll << 21) ? 8 : cells >= (1ll << 19) ? 4 : 2;
+}
+
 template <typename T, int FUSED, bool WRAP = true>
-static int launch_rows(const RowsArgs& a, int R, hipStream_t s, int replicas = 1) {
+static int launch_rows(RowsArgs a, int R, hipStream_t s, int replicas = 1) {
     const int strips = (a.H + DIF_WCOLS - 1) / DIF_WCOLS;
     constexpr int WPB = DIF_BLOCK / DIE_WAVE;
-    dim3 grid((strips + WPB - 1) / WPB, (a.W + DIF_ROWS - 1) / DIF_ROWS + (FUSED && a.result ? 1 : 0), replicas);
+    a.rpw = rows_per_wave(a.W, a.H, replicas);
+    dim3 grid((strips + WPB - 1) / WPB, (a.W + a.rpw - 1) / a.rpw + (FUSED && a.result ? 1 : 0), replicas);
     switch (R) {
         case 1: k_diffuse_rows<T, 1, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
         case 2: k_diffuse_rows<T, 2, FUSED, WRAP><<<grid, DIF_BLOCK, 0, s>>>(a); break;
