@@ -62,7 +62,7 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-steps', type=int, default=6)
     p.add_argument('--kernel-reps', type=int, default=20)
-    p.add_argument('--sort-every', type=int, default=8)
+    p.add_argument('--sort-every', type=int, default=None, help='classic step: re-sort period (default: Env decides: 8, or never on worlds below 2^19 cells)')
     p.add_argument('--fields', choices=['f32', 'f16'], default='f32', help='dtype of the field channels (configs[4] uses f16)')
     p.add_argument('--migrate-every', type=int, default=8, help='decomposed runs: agents / ghosts cross ranks every M steps (1 = every step)')
     p.add_argument('--dist-mode', choices=['ghost', 'guard'], default='ghost',
@@ -349,7 +349,7 @@ def main():
         # anisotropic in cells (offsets are fractions of the unit square): size them on the longer axis
         agent_kw.update(scale=1.53 / (max(gW, gH) - 1), sense_offset=10.2 / (max(gW, gH) - 1))
         denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
-                       device=device, seed=args.seed, sort_every=args.sort_every,
+                       device=device, seed=args.seed, sort_every=8 if args.sort_every is None else args.sort_every,
                        migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost',
                        ghost_headroom=1.3)     # the synthetic world stays uniform (measured fill 0.5 of 2x over 1200 steps)
         how = (f'ghost agents, halo ({denv.geo.hx}, {denv.geo.hy}) re-seated every {denv.migrate_every} steps' if denv.ghosts else
@@ -376,7 +376,7 @@ def main():
         that lazily created state, first launches and the clock ramp are behind us whatever --warmup says.  Then W warm-up
         steps, then EXACTLY K timed steps between barrier + synchronize pairs, one HIP event after every step."""
         obs = env._get_current_obs
-        period = max(args.sort_every, 1)
+        period = max(args.sort_every if args.sort_every is not None else 8, 1)
         if dist_on:
             period = max(period, env.migrate_every)
         n_pre, t_pre = 0, time.perf_counter()
