@@ -484,6 +484,30 @@ def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile):
         assert np.array_equal(a, b), name
 
 
+def test_tile_binned_step_with_a_gradient_agent(die):
+    """GradientAgent without inertia / noise (normalised gradient: bounded step) takes the binned path too
+    (k_pic_forward_move<T, GRADIENT>): same bits as the classic step."""
+    W, H, N = 128, 192, 7000
+    rs = np.random.RandomState(11)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.3)
+    outs = []
+    for pic in (True, False):
+        env = die.Env.from_numpy(medium, agents, sort_every=2, pic=pic)
+        env._pic_tile = (5, 6) if pic else None
+        ag = die.GradientAgent(max_agents=N, seed=2, scale=0.01, sense_offset=0.03, inertia=0.0, noise_scale=0.0, normalized_grad=True)
+        obs = env._get_current_obs
+        acts = []
+        for i in range(6):
+            action = ag.forward(obs)
+            obs, rew, _, _, info = env.step(action)
+            acts.append(action.to_numpy())
+        if pic:
+            assert env._pic is not None and env._pic.held[0] is env.agents.x, 'the tile-binned path did not run'
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.stack(acts), np.array([rew, info['num_agents']])))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'actions', 'reward'), outs[0], outs[1]):
+        assert np.array_equal(a, b), name
+
+
 def test_tile_binned_step_refuses_long_steps(die):
     """A step longer than a tile cannot use the binned path: the env silently takes the classic one."""
     W, H, N = 128, 96, 3000
