@@ -205,6 +205,39 @@ def main():
         tr.update(fields[k])
         out[f'trace_out{k}'] = tr._trace_field.copy()
 
+    # ---- ConvolutionModel (core/agent/evo.py:45-118): the reference's class body compiled as a whole (its zero-argument
+    # super() needs the class cell) against torch, which IS installed; weights set from seeded numpy arrays
+    import inspect
+    from copy import deepcopy
+    import torch as th
+    from torch import nn
+    sa = _exec(_functions('core/utils.py', ['save_args']), {'inspect': inspect, 'deepcopy': deepcopy})
+    with open(os.path.join(REF, 'core/agent/evo.py')) as f:
+        tree = ast.parse(f.read())
+    cm = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == 'ConvolutionModel')
+    for n in ast.walk(cm):
+        if isinstance(n, ast.FunctionDef):
+            n.returns = None
+            for a in n.args.args + n.args.kwonlyargs:
+                a.annotation = None
+    ns = _exec(ast.Module(body=[cm], type_ignores=[]), {'nn': nn, 'th': th, 'save_args': sa['save_args'],
+                                                        'xavier_uniform': nn.init.xavier_uniform_})
+    Model = ns['ConvolutionModel']
+    for ci, (nobs, ksz, shape) in enumerate([(3, (3,), (9, 7)), (3, (3, 3), (8, 12)), (2, (5, 3), (11, 10)), (3, (1, 7), (13, 9))]):
+        model = Model(num_obs_channels=nobs, num_act_channels=3, kernel_sizes=ksz, requires_grad=False)
+        convs = [k for k in model.kernels if hasattr(k, 'weight')]
+        ws = [rs.uniform(-0.7, 0.7, tuple(k.weight.shape)).astype(np.float32) for k in convs]
+        for k, w in zip(convs, ws):
+            k.weight.copy_(th.from_numpy(w))
+        x = rs.rand(1, nobs, *shape).astype(np.float32)
+        x[0, 0] = (x[0, 0] < 0.3)                          # an 'agents'-like 0/1 channel
+        y = model(th.from_numpy(x.copy())).numpy()
+        out[f'nca{ci}_in'] = x[0]
+        out[f'nca{ci}_out'] = y[0]
+        out[f'nca{ci}_nw'] = np.array(len(ws))
+        for li, w in enumerate(ws):
+            out[f'nca{ci}_w{li}'] = w
+
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, len(out), 'arrays')
 

@@ -1189,6 +1189,36 @@ def test_neural_automata_forward_parity(die, W, H, kernel_sizes):
         env.step(action)
 
 
+def test_conv_stack_against_reference_made_vectors(die, golden_dir):
+    """die_conv2d_circular on the inputs / weights of tests/golden/ref_helpers.npz against the outputs the REFERENCE'S
+    ConvolutionModel produced for them (tests/golden/make_ref_helper_vectors.py): 1e-5."""
+    import ctypes as C
+    import os
+    from die_amd import _lib
+    from die_amd.device_array import stream_ptr
+    G = np.load(os.path.join(golden_dir, 'ref_helpers.npz'))
+    dev = torch.device('cuda:0')
+    for ci in range(4):
+        x = torch.from_numpy(G[f'nca{ci}_in'].astype(np.float32)).to(dev).contiguous()
+        cin, W, H = x.shape
+        planes = [x[c] for c in range(cin)]
+        nw = int(G[f'nca{ci}_nw'])
+        keep = [x]
+        for li in range(nw):
+            w = torch.from_numpy(G[f'nca{ci}_w{li}'].astype(np.float32)).to(dev).contiguous()
+            cout, cin_w, k, _ = w.shape
+            assert cin_w == len(planes)
+            dst = torch.empty((cout, W, H), dtype=torch.float32, device=dev)
+            cin_arr = (_lib.ConvPlane * cin_w)(*[_lib.ConvPlane(t.data_ptr(), _lib.DIE_PLANE_F32, 0) for t in planes])
+            out_arr = (C.c_void_p * cout)(*[dst[o].data_ptr() for o in range(cout)])
+            _lib.check(_lib.lib.die_conv2d_circular(W, H, cin_w, cin_arr, 1, cout, out_arr, k, w.data_ptr(), int(li == nw - 1),
+                                                    stream_ptr(dev)), 'die_conv2d_circular')
+            keep += [w, dst]
+            planes = [dst[o] for o in range(cout)]
+        got = torch.stack(planes).cpu().numpy()
+        assert np.allclose(got, G[f'nca{ci}_out'], rtol=1e-5, atol=1e-5), ci
+
+
 def test_neural_automata_on_f16_fields_and_after_binned_steps(die):
     """fp16 field planes are read directly; after tile-binned steps (claim plane not maintained) the 'agents' channel is
     rebuilt before it is sensed."""

@@ -139,3 +139,17 @@ def test_ref_flow_operator_sequence_and_field_trace(G):
     for k in range(3):
         tr.update(G['trace_fields'][k])
         assert np.array_equal(tr.trace, G[f'trace_out{k}'])
+
+
+def test_ref_convolution_model(G):
+    """ConvolutionModel.forward (core/agent/evo.py:45-118), outputs of the reference's own class body run with torch
+    (float32): the oracle's circular convolution stack + tanh, evaluated in float64, agrees within 1e-5."""
+    for ci in range(4):
+        x = G[f'nca{ci}_in'].astype(np.float64)
+        ws = [G[f'nca{ci}_w{li}'].astype(np.float64) for li in range(int(G[f'nca{ci}_nw']))]
+        y = x
+        for w in ws:
+            y = R.conv2d_circular(y, w)
+        assert np.allclose(np.tanh(y), G[f'nca{ci}_out'], rtol=1e-5, atol=1e-5), ci
+        if x.shape[0] == 3:
+            assert np.allclose(R.nca_sense(x, ws, True), G[f'nca{ci}_out'], rtol=1e-5, atol=1e-5)
