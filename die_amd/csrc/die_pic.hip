@@ -181,6 +181,12 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #endif
 template <typename T, int KIND, bool STAGE>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
+    // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
+    // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
+    // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)
+    f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
+    f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
+    f.g = p.g;                            // one copy of the geometry (a single periodic tile: gW == W)
     extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
     __shared__ uint32_t s_base[9], s_pre[10];
     __shared__ uint32_t s_front, s_back, s_next, s_nlist;
@@ -636,8 +642,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_pic_forward_env_step: chem_next must be a second plane");
     DIE_REQUIRE(!d->has_dead_slots && !d->agents_die && !m->sense_mask && !d->staged,
                 "die_pic_forward_env_step: every slot must be alive (no agents_die), no sense mask");
-    DIE_REQUIRE(g->inertia == 0.f && g->noise_scale == 0.f && g->normalized_grad,
-                "die_pic_forward_env_step: the step length must be bounded by `scale` (normalised gradient, no inertia, no noise)");
+    DIE_REQUIRE(g->inertia == 0.f && g->noise_scale == 0.f && g->normalized_grad && !g->prev_gx && !g->prev_gy && !g->step_base,
+                "die_pic_forward_env_step: the step length must be bounded by `scale` (normalised gradient, no inertia, no noise), no graph replay");
     if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
         die_set_error("die_pic_forward_env_step: boundary %d is not representable in Q0.32", d->boundary);
         return DIE_ERR_UNSUPPORTED;
