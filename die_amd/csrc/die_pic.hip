@@ -74,7 +74,7 @@ struct PicArgs {
     die_geo g;
     int ntx, nty, xs, ys;           // tiles per axis, log2 of the tile shape
     int margin;                     // K1 stages chem of the tile ± margin cells (a multiple of the 16-byte vector width)
-    uint32_t inv_cv, inv_fv;        // ceil(2^20 / 16-byte vectors per staged row) of the chem / food tile: i / vpr == (i·inv) >> 20
+    int cs_c, cs_f;                 // log2 of the lanes that share a staged row of the chem / food tile (2^cs >= 16-byte vectors per row)
     PicLayout in, out;
     float* dep;                     // N: deposit of every agent, `out` order (K1 → K2)
     float *adx, *ady, *adep;        // the action handed back to the caller, `in` order
@@ -125,42 +125,35 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
     __syncthreads();
 }
 
-// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses.
-// Rows / columns outside the world are never read by anybody (probes clamp at the world's edge): their loads are clamped
-// into the plane instead of being skipped, and the last vector is copied again by the threads past the end — no branch,
-// ≈ 9 VALU instructions per vector (the first cut, with a division for the row and tests around the load, spent a
-// quarter of the kernel's instructions here).
+// copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses.  A thread keeps ONE column vector
+// (lane group of 2^cs ≥ vpr lanes per row; surplus lanes copy the last column again) and walks down the rows in steps
+// of blockDim >> cs: per vector one add, two clamps, a multiply-add and the address — the first cut, with a division for
+// the row and tests around every load, spent a quarter of the kernel's instructions here.  Rows / columns outside the
+// world are never read by anybody (probes clamp at the world's edge): their loads are clamped into the plane, no branch.
 template <typename T>
 struct PicStage {
     const T* plane;
-    int gx0, gy0, vpr, nvec, W, H;
-    uint32_t inv_vpr;
-    __device__ __forceinline__ uint4 load(int i) const {
-        constexpr int V = 16 / (int)sizeof(T);
-        i = min(i, nvec - 1);
-        // row = i / vpr as a multiply and a shift: exact for i·vpr < 2^20, which the host checks
-        const int row = (int)(__umul24((uint32_t)i, inv_vpr) >> 20), cv = i - __mul24(row, vpr);
-        const int gx = min(max(gx0 + row, 0), W - 1), gy = min(max(gy0 + cv * V, 0), H - V);
-        return *(const uint4*)(plane + (__mul24(gx, H) + gy));
+    int gx0, gy0, vpr, rows, W, H, cs;
+    __device__ __forceinline__ uint4 load(int row, int gyc) const {
+        const int gx = min(max(gx0 + min(row, rows - 1), 0), W - 1);
+        return *(const uint4*)(plane + (__mul24(gx, H) + gyc));
     }
-    // the first NB vectors of every thread: requested at the very top of the kernel (issue), written to LDS once the
+    __device__ __forceinline__ int column() const { return min((int)threadIdx.x & ((1 << cs) - 1), vpr - 1); }
+    __device__ __forceinline__ int col_cell(int cv) const { return min(max(gy0 + cv * (16 / (int)sizeof(T)), 0), H - 16 / (int)sizeof(T)); }
+    // the first NB rows of every thread: requested at the very top of the kernel (issue), written to LDS once the
     // per-tile words and the agent streams have been requested too (commit) …
     template <int NB> __device__ __forceinline__ void issue(uint4 (&v)[NB]) const {
+        const int gyc = col_cell(column()), r0 = (int)threadIdx.x >> cs, RP = (int)blockDim.x >> cs;
 #pragma unroll
-        for (int q = 0; q < NB; ++q) v[q] = load((int)threadIdx.x + q * (int)blockDim.x);
+        for (int q = 0; q < NB; ++q) v[q] = load(r0 + q * RP, gyc);
     }
     template <int NB> __device__ __forceinline__ void commit(T* dst, const uint4 (&v)[NB]) const {
+        const int cv = column(), r0 = (int)threadIdx.x >> cs, RP = (int)blockDim.x >> cs;
 #pragma unroll
-        for (int q = 0; q < NB; ++q) ((uint4*)dst)[min((int)threadIdx.x + q * (int)blockDim.x, nvec - 1)] = v[q];
-        // … and whatever a larger tile / a smaller workgroup leaves over, four loads in flight per thread
-        const int BLOCK = blockDim.x;
-        for (int i0 = threadIdx.x + NB * BLOCK; i0 < nvec; i0 += BLOCK * 4) {
-            uint4 w[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) w[q] = load(i0 + q * BLOCK);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) ((uint4*)dst)[min(i0 + q * BLOCK, nvec - 1)] = w[q];
-        }
+        for (int q = 0; q < NB; ++q) ((uint4*)dst)[__mul24(min(r0 + q * RP, rows - 1), vpr) + cv] = v[q];
+        // … and whatever a larger tile / a smaller workgroup leaves over
+        const int gyc = col_cell(cv);
+        for (int row = r0 + NB * RP; row < rows; row += RP) ((uint4*)dst)[__mul24(row, vpr) + cv] = load(row, gyc);
     }
 };
 
@@ -203,9 +196,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const T* food = (const T*)p.food;
     constexpr int SV = 16 / (int)sizeof(T);
     const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
-    const PicStage<T> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows * (pitch / SV), p.g.W, p.g.H, p.inv_cv};
-    const PicStage<T> st_f = {food, x0, y0, TY / SV, TX * (TY / SV), p.g.W, p.g.H, p.inv_fv};
-    uint4 sc[4], sf[2];
+    const PicStage<T> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.cs_c};
+    const PicStage<T> st_f = {food, x0, y0, TY / SV, TX, p.g.W, p.g.H, p.cs_f};
+    uint4 sc[6], sf[2];                   // 64×64 tile, margin 12, 512 threads: 88 rows / 16 per pass, 64 rows / 32 per pass
     if (STAGE) {
         st_c.issue(sc);
         if (PIC_STAGE_FOOD) st_f.issue(sf);
@@ -681,14 +674,16 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const bool stage = P <= PIC_MAX_MARGIN;
     k.margin = stage ? P : 0;
     const int vpr_c = (TY + 2 * P) / V, vpr_f = TY / V;     // 16-byte vectors per staged row
-    k.inv_cv = ((1u << 20) + vpr_c - 1) / vpr_c; k.inv_fv = ((1u << 20) + vpr_f - 1) / vpr_f;
-    DIE_REQUIRE(!stage || ((int64_t)(TX + 2 * P) * vpr_c * vpr_c < (1 << 20) && m->W < (1 << 23) && m->H < (1 << 23) && (int64_t)m->W * m->H < (1ll << 31)),
-                "die_pic_forward_env_step: staged tile / plane too large for the 24-bit index arithmetic of the staging loop");
+    k.cs_c = 0; while ((1 << k.cs_c) < vpr_c) ++k.cs_c;
+    k.cs_f = 0; while ((1 << k.cs_f) < vpr_f) ++k.cs_f;
+    DIE_REQUIRE(!stage || (m->W < (1 << 23) && m->H < (1 << 23) && (int64_t)m->W * m->H < (1ll << 31)),
+                "die_pic_forward_env_step: plane too large for the 24-bit index arithmetic of the staging loop");
     const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
-    DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK, "die_pic_forward_env_step: k1_threads %d", block);
+    DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK && (1 << k.cs_c) <= DIE_WAVE && (1 << k.cs_f) <= DIE_WAVE,
+                "die_pic_forward_env_step: k1_threads %d", block);
     if (stages & 1) {
         if (m->dtype == DIE_F32) {
             if (stage) launch_forward_move<float, true>(g->kind, f, k, NT, block, lds, s);
