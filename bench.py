@@ -96,7 +96,7 @@ def algorithmic_bytes(C, K):
 
 PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.json')
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
-             'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false>',
+             'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false, true>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
              'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}

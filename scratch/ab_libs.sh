@@ -11,6 +11,6 @@ for v in "$@"; do
   python3 - $f <<'PY'
 import csv,sys
 for r in csv.DictReader(open(sys.argv[1])):
-    if any(k in r['Name'] for k in ('k_pic_forward_move','k_pic_resolve','k_diffuse_rows<float, 2, 2')): print('    %-60s %8.1f us' % (r['Name'][:60], float(r['AverageNs'])/1e3))
+    if any(k in r['Name'] for k in ('k_pic_forward_move','k_pic_resolve','k_diffuse_rows<float, 2, 2','k_forward_move_claim','k_diffuse_rows<float, 2, 1')): print('    %-60s %8.1f us' % (r['Name'][:60], float(r['AverageNs'])/1e3))
 PY
 done
