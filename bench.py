@@ -71,14 +71,17 @@ def parse():
     p.add_argument('--no-pic', action='store_true', help='classic step (claim plane + bucket sort) instead of the tile-binned one')
     p.add_argument('--pic-tile', default='', help='tuning: log2 tile shape of the tile-binned step, e.g. 6,6')
     p.add_argument('--pic-threads', type=int, default=0, help='tuning: workgroup size of the tile-binned agent kernel')
+    p.add_argument('--eager-actions', action='store_true', help='tile-binned step: store the action of every step (default: it stays in registers and is re-derived when read)')
     p.add_argument('--replicas', type=int, default=0, help='batched env replicas on one GPU (BASELINE configs[4]): R worlds of --size in one launch pair; value = replica-steps/s')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     return p.parse_args()
 
 
-def algorithmic_bytes(C, K):
+def algorithmic_bytes(C, K, action_stored=True):
     """DESIGN.md §5 / SURVEY.md §8(d), fp32 fields: B = 12·C + 104·K per env step; per kernel, what an ideal
-    version of that kernel has to move."""
+    version of that kernel has to move.  `action_stored=False` (tile-binned step with a PhysarumAgent: the action stays
+    in registers and is re-derived only if the caller reads it): the 12 bytes per agent of the action are not claimed."""
+    act = 12 if action_stored else 0
     return {
         # fused forward + move + claim + feed: x,y R+W 16, heading R+W 8, agent_food R+W 8, action W 12,
         # 6 gathers (4 chem taps, food at old and new cell) 24, claim 4
@@ -87,10 +90,10 @@ def algorithmic_bytes(C, K):
         'k_move_claim': 44 * K,           # stand-alone: x,y RW 16 + agent_food RW 8 + action R 12 + food gather 4 + claim 4
         'k_diffuse_rows_fused': 8 * C + 20 * K,   # chem R + W per cell; per agent chem RMW 8 + food RMW 8 + mark 4
         # tile-binned step: the same contract split over its three launches (the claim of the contract is K2's)
-        'k_pic_forward_move': 68 * K,     # state R+W 32, action W 12, 6 gathers 24
+        'k_pic_forward_move': (56 + act) * K,     # state R+W 32, action W 12 (if stored), 6 gathers 24
         'k_pic_resolve': 12 * K,          # the ownership claim 4 + food RMW of the occupied cell 8
         'k_diffuse_rows_dep': 8 * C + 8 * K,      # chem R + W per cell; per agent chem RMW 8
-        'step': 12 * C + 104 * K,
+        'step': 12 * C + (92 + act) * K,
     }
 
 
@@ -98,7 +101,7 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.js
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false, true>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
-             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
+             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
 WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve')
 # bytes per agent that the tile-binned kernels read as 4-byte-per-lane streams (counted in full by FETCH_SIZE; only the
@@ -363,6 +366,8 @@ def main():
                           max_agents='alive', device=device, sync=False, sort_every=args.sort_every,
                           field_dtype=torch.float16 if args.fields == 'f16' else torch.float32, pic=not args.no_pic)
         agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **agent_kw)
+        if args.eager_actions:
+            env._pic_lazy_actions = False
         if args.pic_tile:
             env._pic_tile = tuple(int(v) for v in args.pic_tile.split(','))
         env._pic_k1_threads = args.pic_threads
@@ -437,7 +442,11 @@ def main():
         print(json.dumps(line), flush=True)
     elif rank == 0:
         C = W * H
-        B = algorithmic_bytes(C, K)
+        binned = getattr(env, '_pic', None) is not None and env._pic.held is not None
+        lazy_action = binned and env._pic.lazy_actions
+        B = algorithmic_bytes(C, K, action_stored=not lazy_action)
+        line['config']['step_kind'] = ('tile-binned' if binned else 'classic') + \
+            (', action kept in registers (re-derived bit-identically when read; --eager-actions stores it every step)' if lazy_action else '')
         kt = time_kernels(env, agent, args.kernel_reps)
         empty_interval = kt.pop('_empty_event_interval', None)
         intervals = dict(kt)

@@ -174,12 +174,21 @@ class GradientAgent(Agent):
 
     def _run_forward(self, action):
         """Launch the stand-alone forward kernel for a pending action."""
+        self._flush_lazy()                          # (it rewrites the headings an un-read lazy action is derived from)
         if self._pending is action:
             self._pending = None
         agents, medium = action.agents, action.medium
         m, a, u = medium.c_struct(), agents.c_struct(), action.raw_struct()
         _lib.check(_lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u),
                                                  stream_ptr(agents.device)), 'die_gradient_forward')
+
+    def _flush_lazy(self):
+        """Fill in the action of the last tile-binned step if somebody still holds it un-read (die_amd/pic.py)."""
+        ref = getattr(self, '_lazy_action', None)
+        act = ref() if ref is not None else None
+        self._lazy_action = None
+        if act is not None:
+            act.ensure()
 
     def _forward_consumed(self, action):
         """Env.step ran this action's forward inside die_forward_env_step."""

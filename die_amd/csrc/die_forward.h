@@ -100,6 +100,16 @@ __device__ __forceinline__ double die_np_angle64(float x, float y) {
     return (double)atan2f(im, re);
 }
 
+// polar2xy(r, heading) of _discrete_turn (core/utils.py:158-169): (r + 0j)·(cos + i·sin) with its zero signs, on the
+// float64 heading rounded to fp32.  One function, because die_pic_action_physarum (die_pic.hip) re-derives a PhysarumAgent's
+// action from the stored heading with it and must reproduce the step's bits.
+__device__ __forceinline__ void die_polar2xy_heading(double heading, float r, float* ux, float* uy) {
+    float s2, c2;
+    die_sincos((float)heading, &s2, &c2);
+    *ux = r * c2 - 0.f * s2;
+    *uy = r * s2 + 0.f * c2;
+}
+
 struct FwdOut {
     float dx, dy, dep;
     double heading;
@@ -183,12 +193,8 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
             sgn = delta > atol ? -1.0 : 1.0;  // right (clockwise) / left
         }
         const double d2_64 = renorm_rad(d64 + sgn * a.turn_rad);
-        const float d2 = (float)d2_64;
-        float s2, c2;
-        die_sincos(d2, &s2, &c2);
         const float r = a.normalized ? 1.f : sqrtf(ux * ux + uy * uy);
-        ux = r * c2 - 0.f * s2;                            // polar2xy: (r + 0j)·(cos + i·sin), zero signs included
-        uy = r * s2 + 0.f * c2;
+        die_polar2xy_heading(d2_64, r, &ux, &uy);
         dep_mask = (und_grad || und_turn) ? 0.1f : 1.0f;   // clip(mask, .1, 1) (gradient.py:210-214)
         d_new = d2_64;            // (the reference re-derives it as angle(exp(i·d2)): the same value up to one ulp of libm noise)
         heading_from_vector = !a.normalized;               // |g| may be 0 there: angle(0) = 0

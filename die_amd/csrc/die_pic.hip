@@ -172,7 +172,7 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_K1_MINW
 #define PIC_K1_MINW 6
 #endif
-template <typename T, int KIND, bool STAGE>
+template <typename T, int KIND, bool STAGE, bool ACT>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 hd = __hiloint2double((int)hh, (int)hl);
                 const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
                                        : die_forward_agent<T, KIND, false>(f, X, Y, hd, sid, (int64_t)j);
-                if (p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }
+                if (ACT && p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
                 if (p.boundary == DIE_BOUNDARY_WRAP) {
                     X += (uint32_t)die_q32(o.dx);
@@ -623,8 +623,10 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
 
 template <typename T, bool STAGE>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
-    if (kind == DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE><<<dim3(k.nty, k.ntx), block, lds, s>>>(f, k);
-    else k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE><<<dim3(k.nty, k.ntx), block, lds, s>>>(f, k);
+    const dim3 grid(k.nty, k.ntx);
+    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true><<<grid, block, lds, s>>>(f, k);
+    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true><<<grid, block, lds, s>>>(f, k);
+    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false><<<grid, block, lds, s>>>(f, k);
 }
 
 extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
@@ -705,6 +707,37 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     die_dynamics dsweep = *d;
     if (feed_in_k2) dsweep.food_infinite = 1;               // K2 has fed the occupied cells: the sweep leaves the food alone
     return die_sweep_dep_plane(m, &dsweep, p->dep_plane, (const long long*)p->part_gain, NT, result, p->N, stream);
+}
+
+// The action of the step that WROTE layout `lay`, re-derived from what that step left behind: a normalised PhysarumAgent
+// without momentum moves by scale·polar2xy(1, heading') (die_forward.h: ux += 0 after polar2xy, dx = ux·scale) and its
+// deposit went to p->dep — the same arithmetic on the same inputs, so the same bits as the action K1 would have stored.
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_action_physarum(int64_t N, const uint32_t* hhi, const uint32_t* hlo, const float* dep,
+                                                                  float scale, float* dx, float* dy, float* adep) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < N; n += stride) {
+        float ux, uy;
+        die_polar2xy_heading(__hiloint2double((int)hhi[n], (int)hlo[n]), 1.f, &ux, &uy);
+        ux += 0.f;
+        uy += 0.f;
+        dx[n] = ux * scale;
+        dy[n] = uy * scale;
+        adep[n] = dep[n];
+    }
+}
+
+extern "C" int die_pic_action_physarum(const die_pic* p, int32_t lay, const die_gradient_agent* g, const die_action* act, void* stream) {
+    DIE_REQUIRE(p && g && act && (lay == 0 || lay == 1), "die_pic_action_physarum: null argument");
+    DIE_REQUIRE(g->kind == DIE_AGENT_PHYSARUM && g->normalized_grad && g->inertia == 0.f && g->noise_scale == 0.f,
+                "die_pic_action_physarum: a normalised PhysarumAgent without inertia or noise");
+    const die_pic_layout& L = p->layout[lay];
+    DIE_REQUIRE(p->N > 0 && act->N == p->N && L.heading_hi && L.heading_lo && p->dep && act->dx && act->dy && act->deposit,
+                "die_pic_action_physarum: bad arrays");
+    int64_t grid = (p->N + DIE_BLOCK - 1) / DIE_BLOCK;
+    k_pic_action_physarum<<<(int)(grid < 8192 ? grid : 8192), DIE_BLOCK, 0, (hipStream_t)stream>>>(
+        p->N, L.heading_hi, L.heading_lo, p->dep, g->scale, act->dx, act->dy, act->deposit);
+    DIE_CHECK_LAUNCH("die_pic_action_physarum");
+    return DIE_OK;
 }
 
 extern "C" int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream) {

@@ -277,12 +277,20 @@ class PendingAction(DeviceAction):
     def __init__(self, agent, agents, medium, g_struct, keepalive):
         N = agents.N
         self.N, self.device = N, agents.device
-        self._data = torch.empty((3, agents.capacity), dtype=torch.float32, device=agents.device)
+        self._capacity = agents.capacity
+        self._buf = None                 # (3, capacity) float32, allocated when somebody needs the values
         self.slot = agents.slot
         self.global_slots = agents.global_slots
         self.agent, self.agents, self.medium = agent, agents, medium
         self.g_struct, self._keepalive = g_struct, keepalive
         self.pending = True
+        self._rebuild = None             # set by the tile-binned step when it kept the action in registers (die_amd/pic.py)
+
+    @property
+    def _data(self):
+        if self._buf is None:
+            self._buf = torch.empty((3, self._capacity), dtype=torch.float32, device=self.device)
+        return self._buf
 
     @property
     def data(self):
@@ -301,10 +309,17 @@ class PendingAction(DeviceAction):
         self.g_struct.heading_hi, self.g_struct.heading_lo = hi.data_ptr(), lo.data_ptr()
         self._keepalive = (hi, lo) + tuple(self._keepalive[2:])
 
+    def in_order_of(self, slot):
+        self.ensure()                    # (a lazily rebuilt action also learns its array order there)
+        return super().in_order_of(slot)
+
     def ensure(self):
         if self.pending:
             self.pending = False
             self.agent._run_forward(self)
+        elif self._rebuild is not None:          # consumed by a step that did not store it: re-derive it now
+            rebuild, self._rebuild = self._rebuild, None
+            rebuild(self)
 
     def done(self):
         self.pending = False

@@ -243,6 +243,8 @@ class Env(_EnvBase):
         """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
         result = torch.empty(2, dtype=torch.float64, device=self.device)
         fused = binned = False
+        if self._pic is not None:
+            self._pic.flush_lazy()          # an un-read action of the previous binned step: its inputs are about to change
         if self.dynamics.agents_die and self.dynamics.compat == 'reference':
             self._step_compat(action, result)
             fused = binned = True           # (no re-sorting either: the frozen copy is in this array order)
@@ -327,6 +329,7 @@ class Env(_EnvBase):
         if self._pic is None:
             self._pic = PicState(self, self._pic_tile)
             self._pic.k1_threads = int(getattr(self, '_pic_k1_threads', 0))
+            self._pic.lazy_actions = bool(getattr(self, '_pic_lazy_actions', True))
         if not self._pic.is_current(self, ag):
             self._pic.bin(self, ag)
             action.rebind(self.agents)

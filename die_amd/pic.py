@@ -3,6 +3,7 @@
 order (core/data_init.py:133-150); here the order of the arrays is free (results are keyed by slot id) and this path
 keeps it exactly tile-sorted so that `Env.step` needs no claim plane."""
 import ctypes as C
+import weakref
 from typing import Optional, Tuple
 
 import torch
@@ -42,6 +43,8 @@ class PicState:
         self.cur = 0                 # layout index that holds the agents
         self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
         self.agent = None
+        self.lazy_actions = True     # PhysarumAgent: the step keeps the action in registers, PendingAction re-derives it on demand
+        self._lazy_ref = None        # weak reference to the last such action (it must be filled in before its inputs change)
 
     # ------------------------------------------------------------------
     def _layout(self, tensors, meta) -> _lib.PicLayout:
@@ -76,6 +79,7 @@ class PicState:
 
     def bin(self, env, agent):
         """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset."""
+        self.flush_lazy()
         A = env.agents
         out = self._out_tensors(env)
         cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo)
@@ -86,16 +90,46 @@ class PicState:
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)
 
+    def flush_lazy(self):
+        """The action of the previous step, if somebody still holds it without having read it: fill it in now (the next
+        step overwrites the deposit array it is derived from)."""
+        ref, self._lazy_ref = self._lazy_ref, None
+        act = ref() if ref is not None else None
+        if act is not None:
+            act.ensure()
+
+    def _rebuilder(self, env, agent, out):
+        """die_pic_action_physarum on what the step left in `out` (the layout it wrote) — see include/die_hip.h."""
+        lay, N, dep, dev = self.cur, self.N, self.dep, env.device
+        slot, hh, hl = out[3], out[4], out[5]
+
+        def rebuild(act):
+            L = [_lib.PicLayout(), _lib.PicLayout()]
+            L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0)
+            act.slot = slot                                    # the values come out in the order of the layout the step wrote
+            u = act.raw_struct()
+            _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),
+                       'die_pic_action_physarum')
+        return rebuild
+
     def step(self, env, agent, action, dyn, result, events=None):
         """One step.  `events`: four torch.cuda.Event objects — the three launches are then issued by three calls
-        (die_pic.stages) with an event between them, so that bench.py times each kernel inside real steps."""
+        (die_pic.stages) with an event between them, so that bench.py times each kernel inside real steps.
+
+        A normalised PhysarumAgent's action is a function of what the step leaves behind (heading', deposit array), so the
+        step does not store it (30 MB and 7 % of the agent kernel at 4096²): the PendingAction gets a `_rebuild` hook and
+        is filled in when somebody reads it — or, if it is still referenced then, before the next step."""
+        self.flush_lazy()
         out = self._out_tensors(env)
-        m, u = env.medium.c_struct(need_owner=False), action.raw_struct()
+        lazy = self.lazy_actions and agent._kind == _lib.DIE_AGENT_PHYSARUM and hasattr(action, '_rebuild')
+        m = env.medium.c_struct(need_owner=False)
+        u = None if lazy else C.byref(action.raw_struct())
         for i, stages in enumerate((0,) if events is None else (1, 2, 4)):
             p = self._struct(self.held, out, stages)
             if events is not None:
                 events[i].record()
-            rc = _lib.lib.die_pic_forward_env_step(C.byref(m), C.byref(p), self.cur, C.byref(action.g_struct), C.byref(u), C.byref(dyn),
+            rc = _lib.lib.die_pic_forward_env_step(C.byref(m), C.byref(p), self.cur, C.byref(action.g_struct), u, C.byref(dyn),
                                                    _ptr(result), stream_ptr(env.device))
             if rc != 0:
                 return rc
@@ -103,6 +137,9 @@ class PicState:
             events[3].record()
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)
+        if lazy:
+            action._rebuild = self._rebuilder(env, agent, out)
+            self._lazy_ref = agent._lazy_action = weakref.ref(action)
         return 0
 
     def check(self):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 14
+#define DIE_ABI_VERSION 15
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -410,6 +410,11 @@ int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* headin
  * and |scale| * (max(W, H) - 1) <= tile - 1 (else DIE_ERR_UNSUPPORTED / DIE_ERR_ARG: use die_forward_env_step). */
 int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g, const die_action* act,
                              const die_dynamics* d, die_step_result* result, void* stream);
+/* `act` of die_pic_forward_env_step may be NULL: the action then stays in registers.  For a normalised PhysarumAgent it can
+ * still be produced afterwards — until the next step overwrites p->dep — from what the step left in layout[lay] (the layout it
+ * WROTE): (dx, dy) = scale * polar2xy(1, heading'), deposit = p->dep; same bits as the action the step would have stored, in
+ * the order of layout[lay] (core/agent/gradient.py:110-124: the action PhysarumAgent.forward returns). */
+int die_pic_action_physarum(const die_pic* p, int32_t lay, const die_gradient_agent* g, const die_action* act, void* stream);
 /* Rebuild the 'agents' channel from the agent arrays: atomicMax of (m->epoch, slot) claims (deposit bits 0) for every
  * alive agent.  The caller advances m->epoch (or zeroes the plane) first. */
 int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream);

@@ -508,6 +508,50 @@ def test_tile_binned_step_with_a_gradient_agent(die):
         assert np.array_equal(a, b), name
 
 
+def test_tile_binned_step_actions_read_late_or_never(die):
+    """The binned step keeps a PhysarumAgent's action in registers; the PendingAction is filled in when it is read — right
+    after its step, several steps later (it was still referenced: filled in before its inputs changed), after the world
+    went back to the classic step — with the bits the classic step stores.  Actions nobody reads cost nothing."""
+    W, H, N = 128, 96, 5000
+    rs = np.random.RandomState(23)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.3)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    want = []
+    env = die.Env.from_numpy(medium, agents, sort_every=0, pic=False)
+    ag = die.PhysarumAgent(max_agents=N, seed=5, **kw)
+    ag.set_state(dir0)
+    obs = env._get_current_obs
+    for i in range(9):
+        a = ag.forward(obs)
+        obs, *_ = env.step(a)
+        want.append(a.to_numpy())
+    env = die.Env.from_numpy(medium, agents, sort_every=2)
+    env._pic_tile = (4, 5)
+    ag = die.PhysarumAgent(max_agents=N, seed=5, **kw)
+    ag.set_state(dir0)
+    obs = env._get_current_obs
+    held = []
+    for i in range(9):
+        if i == 6:
+            env._pic_enabled = False                          # classic steps from here on
+        a = ag.forward(obs)
+        obs, *_ = env.step(a)
+        if i < 6:
+            assert env._pic is not None and env._pic.held[0] is env.agents.x
+            assert a._rebuild is not None and a._buf is None, 'the binned step stored the action after all'
+        if i in (0, 3):
+            assert np.array_equal(a.to_numpy(), want[i]), i   # read right after its step
+        elif i in (1, 2, 5):
+            held.append((i, a))                               # kept alive, read later
+        # i == 4: dropped without ever being read
+    last = a
+    for i, b in held:
+        assert np.array_equal(b.to_numpy(), want[i]), i
+    assert np.array_equal(last.to_numpy(), want[8])
+
+
 def test_tile_binned_step_refuses_long_steps(die):
     """A step longer than a tile cannot use the binned path: the env silently takes the classic one."""
     W, H, N = 128, 96, 3000
