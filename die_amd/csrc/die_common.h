@@ -56,6 +56,9 @@ __device__ __forceinline__ int die_cell(int64_t P, int n) {
 // float displacement (fraction of the unit square) → Q0.32 increment
 // v·2^32 is exact in fp32 (a power-of-two scaling), so below 2^31 the nearest integer comes from the 32-bit convert;
 // larger displacements take the float64 route.  Same value either way.
+// the same for |v| < 0.5 (a guarantee of the caller: the tile-binned step bounds both the probe offset and the step length
+// by a tile): no float64 fallback, no branch
+__device__ __forceinline__ int64_t die_q32_small(float v) { return (int64_t)__float2int_rn(v * 4294967296.0f); }
 __device__ __forceinline__ int64_t die_q32(float v) {
     const float t = v * 4294967296.0f;
     if (fabsf(t) < 2147483520.0f) return (int64_t)__float2int_rn(t);

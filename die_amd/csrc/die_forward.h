@@ -121,6 +121,7 @@ struct FwdOut {
 // Where the taps come from: global memory (the planes of FwdArgs) …
 template <typename T, bool EXT>
 struct FwdGlobalMem {
+    static constexpr bool kSmallOffsets = false;
     const T* chem;
     const T* food;
     const uint8_t* mask;
@@ -134,6 +135,7 @@ struct FwdGlobalMem {
 // … or a tile staged in LDS (die_pic.hip): chem with a margin of the probe reach around the tile, food of the tile itself
 template <typename T>
 struct FwdTileMem {
+    static constexpr bool kSmallOffsets = true;       // the staged margin bounds |sense_offset| far below half the world
     const T* chem;          // element (gx, gy) at (gx − cx0)·pitch + (gy − cy0)
     const T* food;          // element (gx, gy) at (gx − fx0)·fpitch + (gy − fy0)
     int cx0, cy0, pitch, fx0, fy0, fpitch;
@@ -150,8 +152,8 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     float sd, cd;
     die_sincos(d, &sd, &cd);
     // probe cell: agents + sense_offset·(cos d, sin d), nearest label, clamped (gradient.py:73-76,105)
-    const int px = die_cell((int64_t)X + die_q32(a.sense_offset * cd), W);
-    const int py = die_cell((int64_t)Y + die_q32(a.sense_offset * sd), H);
+    const int px = die_cell((int64_t)X + (MEM::kSmallOffsets ? die_q32_small(a.sense_offset * cd) : die_q32(a.sense_offset * cd)), W);
+    const int py = die_cell((int64_t)Y + (MEM::kSmallOffsets ? die_q32_small(a.sense_offset * sd) : die_q32(a.sense_offset * sd)), H);
     // np.gradient at the probe cell: central inside, one-sided at the four edges (gradient.py:57)
     const int xm = px > 0 ? px - 1 : 0, xp = px < W - 1 ? px + 1 : W - 1;
     const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;

@@ -304,11 +304,12 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                                        : die_forward_agent<T, KIND, false>(f, X, Y, hd, sid, (int64_t)j);
                 if (ACT && p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
+                // (a step is shorter than a tile — checked on the host — so the fixed-point increment needs no float64 path)
                 if (p.boundary == DIE_BOUNDARY_WRAP) {
-                    X += (uint32_t)die_q32(o.dx);
-                    Y += (uint32_t)die_q32(o.dy);
+                    X += (uint32_t)die_q32_small(o.dx);
+                    Y += (uint32_t)die_q32_small(o.dy);
                 } else {
-                    const int64_t qx = (int64_t)X + die_q32(o.dx), qy = (int64_t)Y + die_q32(o.dy);
+                    const int64_t qx = (int64_t)X + die_q32_small(o.dx), qy = (int64_t)Y + die_q32_small(o.dy);
                     X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
                     Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
                 }
