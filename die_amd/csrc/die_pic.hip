@@ -12,10 +12,13 @@
 //             n[t] − s[t] agents that stood on it one step ago and have walked onto a neighbouring tile ("leavers").  The
 //             agents standing on t NOW are its stayers plus those leavers of its 8 neighbours whose cell lies in t.
 //   K1        k_pic_forward_move, one workgroup per tile over exactly that set: the chem tile ± the probe reach and the food
-//             tile are copied into LDS with 16-byte loads (no gather ever leaves the CU), then forward (4 chem taps, food
-//             under the agent), move, feeding of the agent, reward partial; the agent is written to the OTHER layout as a stayer (front of the segment) or a leaver (back) — positions
-//             from two LDS counters, one arrival counted per leaver in inc[destination].  Because an agent moves less
-//             than a tile per step, a segment of size |set| always fits: no capacity, no overflow.
+//             tile are copied into LDS with 16-byte loads (no gather ever leaves the CU; the loads are issued before
+//             anything else, they depend on the tile index only), then forward (4 chem taps, food under the agent), move,
+//             feeding of the agent, reward partial; the agent is written to the OTHER layout as a stayer (front of the
+//             segment) or a leaver (back) — positions from two LDS counters, one arrival counted per leaver in
+//             inc[destination].  Because an agent moves less than a tile per step, a segment of size |set| always fits:
+//             no capacity, no overflow.  The action is stored only if the caller passed arrays for it (ACT); a
+//             PhysarumAgent's can be re-derived afterwards (die_pic_action_physarum).
 //   K2        k_pic_resolve, one workgroup per tile over the same kind of set in the new layout: 64-bit LDS atomicMax of
 //             (slot + 1) << 32 | deposit bits per cell, then the tile of the deposit plane is written with coalesced
 //             16-byte stores: the winner's deposit, or DIE_DEP_EMPTY, and the food of the occupied cells is reduced
@@ -30,6 +33,8 @@
 // path: die_agents_mark_owner materialises it when somebody asks (DeviceMedium.occupied / owner_slots / render).
 #include "die_forward.h"
 
+// (PIC_K2_FEED, PIC_K1_BLOCK, PIC_K2_BLOCK, PIC_STAGE_FOOD, PIC_K1_MINW: knobs of the A/B builds of scratch/build_variant.sh;
+// the values below are the measured best)
 #ifndef PIC_K2_FEED
 #define PIC_K2_FEED 1
 #endif
