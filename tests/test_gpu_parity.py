@@ -5,6 +5,8 @@ the north-star tolerance of 1e-5 relative (fp32) — the exact rtol/atol is writ
 assert.  Discrete decisions that sit on a float threshold may differ for a vanishing
 fraction of slots; every such slot must be *explained* by an oracle margin below 1e-4.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1200,6 +1202,31 @@ def test_minimal_run_example(die):
     total, env = mod.run_minimal(die.PhysarumAgent(max_agents=64 * 64, scale=0.006, turn_angle=30, sense_offset=0.04, seed=1),
                                  agent_ratio=0.15, field_size=(64, 64), iters=20, seed=1)
     assert np.isfinite(total) and float(env.medium.chem.max()) > 0
+
+
+def test_manual_step_of_the_example_equals_env_step(die):
+    """examples/simple_agents.py `manual_step` (the reference's `_manual_step`, examples/simple_agents.py:14-30, written
+    with the stage entry points) leaves the world exactly as `Env.step` does — also with a food-flow operator."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('simple_agents', os.path.join(root, 'examples', 'simple_agents.py'))
+    ex = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ex)
+    W, H, N, K = 96, 64, 3000, 2200
+    rs = np.random.RandomState(31)
+    medium, agents = random_state(W, H, N, K, rs, collide=0.2)
+    outs = []
+    for manual in (False, True):
+        flow = die.WaveSequence((W, H), dt=0.01).get_flow_operator(scale=0.5, decay=0.5)
+        env = die.Env.from_numpy(medium, agents, die.Dynamics(op_food_flow=flow), sort_every=0)
+        ag = die.PhysarumAgent(max_agents=N, seed=4, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        obs = env._get_current_obs
+        for _ in range(5):
+            action = ag.forward(obs)
+            obs = (ex.manual_step(env, action) if manual else env.step(action))[0]
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a, b)
 
 
 # ------------------------------------------------------------------------------------ NeuralAutomataAgent sensing
