@@ -37,7 +37,16 @@ static inline int die_grid_for(int64_t n, int block = DIE_BLOCK) { return (int)(
 __device__ __forceinline__ float die_ld(const float* p, int64_t i) { return p[i]; }
 __device__ __forceinline__ float die_ld(const __half* p, int64_t i) { return __half2float(p[i]); }
 __device__ __forceinline__ void die_st(float* p, int64_t i, float v) { p[i] = v; }
-__device__ __forceinline__ void die_st(__half* p, int64_t i, float v) { p[i] = __float2half(v); }
+// fp32 → fp16 of a value that has been ROUNDED TO fp32 first.  Without the barrier the compiler folds the arithmetic that
+// produced `v` and the conversion into one mixed-precision instruction (v_fma_mixlo_f16: a single rounding straight to
+// fp16) in some instantiations and not in others — the results then differ in the last fp16 bit whenever the fp32 value is
+// an exact tie between two halves (found by tests/fuzz_cases.py fuzz_binned: f − 0.35·f on fp16 food).
+__device__ __forceinline__ float die_round_f32(float v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ __half die_f2h(float v) { return __float2half(die_round_f32(v)); }
+__device__ __forceinline__ void die_st(__half* p, int64_t i, float v) { p[i] = die_f2h(v); }
 
 // ---- Q0.32 fixed-point coordinates -------------------------------------------------------
 // nearest label of linspace(0, 1, n) to X / 2^32, P may lie outside [0, 2^32) (probe offsets):

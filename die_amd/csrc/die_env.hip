@@ -379,7 +379,7 @@ template <> struct Vec4<__half> {
         v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
     }
     static __device__ __forceinline__ void st(__half* p, const float v[4]) {
-        const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+        const __half2 a = __halves2half2(die_f2h(v[0]), die_f2h(v[1])), b = __halves2half2(die_f2h(v[2]), die_f2h(v[3]));
         uint2 t; t.x = *(const uint32_t*)&a; t.y = *(const uint32_t*)&b;
         *(uint2*)p = t;
     }

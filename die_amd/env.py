@@ -275,6 +275,8 @@ class Env(_EnvBase):
             _lib.check(_lib.lib.die_env_step(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(result),
                                              _ptr(self._workspace), self._workspace.numel(), stream_ptr(self.device)),
                        'die_env_step')
+        if not binned:
+            self._agents_changed()          # a classic step moved the agents in place: the tile order is gone, bin again
         self.medium.swap_chem()
         if self.dynamics.op_food_flow is not _identity_food_flow:
             self._food_flow()
@@ -500,7 +502,14 @@ class Env(_EnvBase):
             k += n
 
     # substeps, for custom update cycles (examples/simple_agents.py:16-30)
+    def _agents_changed(self):
+        """The agent arrays were modified in place by something other than the tile-binned step: its tile order is void."""
+        if self._pic is not None:
+            self._pic.flush_lazy()
+            self._pic.held = None
+
     def _stage(self, fn_name, action):
+        self._agents_changed()
         act = self._as_action(action)
         m, a, u, d = self.medium.c_struct(), self.agents.c_struct(), act.c_struct(), self._c_dynamics()
         _lib.check(getattr(_lib.lib, fn_name)(C.byref(m), C.byref(a), C.byref(u), C.byref(d), _ptr(self._workspace),

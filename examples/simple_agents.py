@@ -31,6 +31,7 @@ def manual_step(env: Env, action):
         _medium_resource_dynamics                        env._food_flow()
         _medium_diffuse_decay                            env._medium_diffuse_decay()
     """
+    env._agents_changed()                # (a tile-binned large world has to be binned again after a hand-made step)
     act = env._as_action(action)
     env.medium.next_epoch()
     m, a, u, d = env.medium.c_struct(), env.agents.c_struct(), act.c_struct(), env._c_dynamics()

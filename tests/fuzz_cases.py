@@ -1,5 +1,5 @@
 """Randomised parity sweeps (GPU vs oracle, and device paths vs each other).  `python -m tests.fuzz_cases
-step|forward|paths|init [cases] [seed]` runs a long sweep; tests/test_gpu_fuzz.py runs short ones."""
+step|forward|paths|init|binned [cases] [seed]` runs a long sweep; tests/test_gpu_fuzz.py runs short ones."""
 import os
 import sys
 
@@ -123,6 +123,76 @@ def fuzz_paths(n_cases=100, seed=0, verbose=True):
     return fails
 
 
+def fuzz_binned(n_cases=60, seed=0, verbose=True):
+    """Tile-binned step against the classic step on random worlds: tile shapes, world shapes (3..6 tiles per axis), agent
+    densities from sparse to several agents per cell, boundaries, rates, fp16 fields, step lengths up to the tile limit,
+    actions read every step / now and then / never, switches between the two paths mid-run.  Everything must be equal bit for
+    bit: fields, agents, headings, actions, rewards."""
+    rs = np.random.RandomState(seed)
+    fails = 0
+    for case in range(n_cases):
+        xs, ys = [(4, 5), (5, 6), (6, 6), (5, 7)][rs.randint(4)]
+        TX, TY = 1 << xs, 1 << ys
+        W, H = TX * int(rs.randint(3, 6)), TY * int(rs.randint(3, 5))
+        N = int(rs.choice([50, 2000, 20000, W * H // 2]))
+        medium, agents = random_state(W, H, N, N, rs, collide=float(rs.choice([0.0, 0.3, 0.9])))
+        f16 = bool(rs.rand() < 0.3)
+        dyn = dict(boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])), food_infinite=bool(rs.rand() < 0.2),
+                   diffuse_sigma=float(rs.choice([0.4, 0.5, 0.8, 1.0])), rate_feed=float(rs.choice([0.1, 0.35])),
+                   rate_decay_chem=float(rs.choice([0.01, 0.2])))
+        reach = float(rs.choice([0.7, 1.53, min(TX, TY) - 1.001]))                    # cells per step
+        probe = float(rs.choice([1.2, 10.2, 21.5]))
+        kw = dict(scale=reach / (max(W, H) - 1), sense_offset=probe / (max(W, H) - 1), sense_angle=float(rs.choice([60, 90, 120])),
+                  deposit=float(rs.choice([1.0, 4.0])))
+        turn = np.radians(30); dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+        read_mode = rs.choice(['every', 'some', 'never'])
+        switch_at = int(rs.randint(2, 7)) if rs.rand() < 0.4 else None
+        outs = []
+        for pic in (True, False):
+            env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=int(rs.choice([0, 2, 3])) if pic else 3, pic=pic,
+                                         field_dtype=torch.float16 if f16 else torch.float32)
+            env._pic_tile = (xs, ys) if pic else None
+            ag = die_amd.PhysarumAgent(max_agents=N, seed=7, **kw)
+            ag.set_state(dir0)
+            obs = env._get_current_obs
+            acts, rewards, held = [], [], []
+            for i in range(8):
+                if pic and switch_at is not None:
+                    env._pic_enabled = not (switch_at <= i < switch_at + 2)      # two classic steps in between
+                a = ag.forward(obs)
+                try:
+                    obs, rew, _, _, info = env.step(a)
+                except RuntimeError as e:
+                    fails += 1
+                    print(f'CASE {case} step {i} pic={pic}: {e}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} dyn={dyn} kw={kw} reach={reach} probe={probe} '
+                          f'switch={switch_at}', flush=True)
+                    acts = None                                 # (no accessor after a bookkeeping error: slot ids may be garbage)
+                    break
+                rewards.append((rew, info['num_agents']))
+                if read_mode == 'every' or (read_mode == 'some' and i % 3 == 0):
+                    acts.append(a.to_numpy())
+                elif read_mode == 'some' and i % 3 == 1:
+                    held.append(a)
+            if acts is None:
+                outs = None
+                break
+            acts += [a.to_numpy() for a in held]
+            if pic and (env._pic is None or (switch_at is None and env._pic.held[0] is not env.agents.x)):
+                fails += 1; print(f'CASE {case}: the binned path did not run (W={W} H={H} tile=({xs},{ys}) reach={reach})', flush=True)
+            outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array(rewards),
+                         np.stack(acts) if acts else np.zeros(0)))
+        for name, a, b in zip(('medium', 'agents', 'heading', 'rewards', 'actions'), *(outs or ((), ()))):
+            if a.shape != b.shape or not np.array_equal(a, b):
+                fails += 1
+                if name == 'medium' and a.shape == b.shape:
+                    name = 'medium ' + str([bool(np.array_equal(a[c], b[c])) for c in range(3)]) + f' max chem diff {np.abs(a[2] - b[2]).max():.3g} food diff {np.abs(a[1] - b[1]).max():.3g}'
+                print(f'CASE {case} {name} differs: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} dyn={dyn} kw={kw} read={read_mode} switch={switch_at}', flush=True)
+                break
+        if verbose and case % 10 == 9:
+            print(f'  binned: {case + 1} cases, {fails} failures', flush=True)
+    return fails
+
+
 def fuzz_init(n_cases=100, seed=0, verbose=True):
     rs = np.random.RandomState(seed)
     fails = 0
@@ -154,5 +224,5 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'step'
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init}[which](n, seed)
+    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init, 'binned': fuzz_binned}[which](n, seed)
     print(f'{which}: {n} cases, {f} failures')

@@ -30,3 +30,7 @@ def test_fuzz_all_device_paths_identical(fuzz):
 
 def test_fuzz_init_vs_oracle(fuzz):
     assert fuzz.fuzz_init(30, seed=104) == 0
+
+
+def test_fuzz_binned_step_vs_classic_step(fuzz):
+    assert fuzz.fuzz_binned(12, seed=105) == 0

@@ -554,6 +554,40 @@ def test_tile_binned_step_actions_read_late_or_never(die):
     assert np.array_equal(last.to_numpy(), want[8])
 
 
+@pytest.mark.parametrize('f16', [False, True])
+def test_tile_binned_step_regressions_found_by_the_fuzzer(die, f16):
+    """tests/fuzz_cases.py fuzz_binned found two bugs, pinned here.  (1) Classic steps in between that do NOT re-sort
+    (sort_every = 0; or a numpy action handed to `step`) move the agents in place: the arrays keep their identity, the
+    tile order is void all the same — the binned step has to bin again.  (2) fp16 fields: `food − rate·food` folded with
+    the fp32 → fp16 conversion into one mixed-precision instruction in one instantiation and not in the other; at an exact
+    tie between two halves (food 0.08697509765625, rate 0.35) the single and the double rounding differ."""
+    W, H, N = 96, 384, 3000
+    rs = np.random.RandomState(77)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.2)
+    medium[1].flat[::7] = 0.08697509765625                       # the tie of (2) on many cells
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    outs = []
+    for pic in (True, False):
+        env = die.Env.from_numpy(medium, agents, die.Dynamics(rate_feed=0.35), sort_every=0, pic=pic,
+                                 field_dtype=torch.float16 if f16 else torch.float32)
+        env._pic_tile = (5, 7) if pic else None
+        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (H - 1), sense_offset=10.2 / (H - 1))
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        for i in range(7):
+            env._pic_enabled = pic and i not in (2, 3)           # two classic steps in place, then binned again
+            a = ag.forward(obs)
+            if i == 5:
+                a = a.to_numpy()                                 # … and one step driven by a host array
+            obs, rew, _, _, info = env.step(a)
+        if pic:
+            assert env._pic is not None and env._pic.held is not None and env._pic.held[0] is env.agents.x
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array([rew, info['num_agents']])))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'reward'), *outs):
+        assert np.array_equal(a, b), name
+
+
 def test_tile_binned_step_refuses_long_steps(die):
     """A step longer than a tile cannot use the binned path: the env silently takes the classic one."""
     W, H, N = 128, 96, 3000
