@@ -35,6 +35,10 @@ class BatchedEnv:
         envs = [Env(field_size, d, seed=self.seed + r, max_agents='alive', field_dtype=field_dtype, device=self.device, sort_every=0,
                     pic=False) for r in range(self.R)]
         self.n = [e.agents.N for e in envs]
+        for r, e in enumerate(envs):
+            if not e._all_alive:            # (only a world seeded with no agent at all: 'alive' keeps one dead placeholder slot)
+                raise NotImplementedError(f'batched replicas: replica {r} (seed {self.seed + r}) has no alive agent; dead slots are '
+                                          'not modelled by the batched step')
         self.Nmax = max(self.n)
         R, W, H, Nm, dev = self.R, self.W, self.H, self.Nmax, self.device
         self.owner = torch.zeros((R, W, H), dtype=torch.int64, device=dev)

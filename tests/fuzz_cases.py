@@ -193,6 +193,50 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
     return fails
 
 
+def fuzz_batched(n_cases=30, seed=0, verbose=True):
+    """Batched replicas (die_forward_env_step_batch) against stand-alone runs: random shapes (incl. fields whose rows are
+    not a multiple of 4 — the batch refuses those cleanly), replica counts, densities, boundaries, rates, fp16."""
+    from die_amd.batch import BatchedEnv, BatchedPhysarumAgent
+    rs = np.random.RandomState(seed)
+    fails = 0
+    for case in range(n_cases):
+        W = int(rs.choice([8, 33, 64, 100, 256])); H = int(rs.choice([8, 12, 64, 200, 252]))
+        R = int(rs.choice([1, 2, 3, 7, 16])); f16 = bool(rs.rand() < 0.3)
+        dyn = dict(init_agent_ratio=float(rs.choice([0.02, 0.15, 0.6])), boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])),
+                   food_infinite=bool(rs.rand() < 0.2), diffuse_sigma=float(rs.choice([0.4, 0.5, 0.8, 1.0])),
+                   rate_feed=float(rs.choice([0.1, 0.35])), rate_decay_chem=float(rs.choice([0.01, 0.2])))
+        kw = dict(scale=float(rs.choice([0.7, 1.53, 3.0])) / (max(W, H) - 1), sense_offset=float(rs.choice([1.2, 10.2])) / (max(W, H) - 1),
+                  sense_angle=float(rs.choice([60, 90, 120])))
+        steps, s0, a0 = int(rs.choice([3, 9])), int(rs.randint(1000)), int(rs.randint(1000))
+        dt = torch.float16 if f16 else torch.float32
+        try:
+            benv = BatchedEnv((W, H), die_amd.Dynamics(**dyn), replicas=R, seed=s0, field_dtype=dt)
+            bag = BatchedPhysarumAgent(benv, seed=a0, **kw)
+            rew, alive = BatchedEnv.read_results(benv.run(bag, steps))
+        except NotImplementedError as e:
+            if verbose: print(f'  case {case}: refused ({str(e)[:80]})', flush=True)
+            continue
+        for r in range(R):
+            env = die_amd.Env((W, H), die_amd.Dynamics(**dyn), seed=s0 + r, max_agents='alive', field_dtype=dt, pic=False)
+            ag = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=a0 + r, **kw)
+            obs = env._get_current_obs
+            want = []
+            for _ in range(steps):
+                obs, rw, _, _, info = env.step(ag.forward(obs))
+                want.append((rw, info['num_agents']))
+            m, a = benv.replica_numpy(r)
+            ok = np.array_equal(m, env.medium.to_numpy()) and np.array_equal(a, env.agents.to_numpy()) and \
+                np.array_equal(bag.direction_rads_numpy(r), ag.direction_rads_numpy()) and \
+                np.array_equal(rew[:, r], np.array([w[0] for w in want])) and np.array_equal(alive[:, r], np.array([w[1] for w in want]))
+            if not ok:
+                fails += 1
+                print(f'CASE {case} replica {r} differs: W={W} H={H} R={R} f16={f16} dyn={dyn} kw={kw} steps={steps}', flush=True)
+                break
+        if verbose and case % 10 == 9:
+            print(f'  batched: {case + 1} cases, {fails} failures', flush=True)
+    return fails
+
+
 def fuzz_init(n_cases=100, seed=0, verbose=True):
     rs = np.random.RandomState(seed)
     fails = 0
@@ -224,5 +268,5 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'step'
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init, 'binned': fuzz_binned}[which](n, seed)
+    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init, 'binned': fuzz_binned, 'batched': fuzz_batched}[which](n, seed)
     print(f'{which}: {n} cases, {f} failures')

@@ -34,3 +34,7 @@ def test_fuzz_init_vs_oracle(fuzz):
 
 def test_fuzz_binned_step_vs_classic_step(fuzz):
     assert fuzz.fuzz_binned(12, seed=105) == 0
+
+
+def test_fuzz_batched_replicas_vs_stand_alone_runs(fuzz):
+    assert fuzz.fuzz_batched(10, seed=106, verbose=False) == 0
