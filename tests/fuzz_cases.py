@@ -237,6 +237,35 @@ def fuzz_batched(n_cases=30, seed=0, verbose=True):
     return fails
 
 
+def fuzz_nca(n_cases=40, seed=0, verbose=True):
+    """NeuralAutomataAgent.forward on the device against the oracle: odd field shapes (rows not a multiple of 4, fields smaller
+    than the kernel), random kernel stacks, fp16 fields, with / without the agents channel."""
+    import torch as th
+    rs = np.random.RandomState(seed)
+    fails = 0
+    for case in range(n_cases):
+        W = int(rs.choice([2, 3, 5, 13, 16, 37, 64, 130])); H = int(rs.choice([2, 4, 7, 9, 30, 64, 66, 257]))
+        ks = tuple(int(k) for k in rs.choice([1, 3, 5, 7], size=int(rs.randint(1, 4))))
+        N = max(W * H // 3, 2); K = max(W * H // 5, 1)
+        medium, agents = random_state(W, H, N, K, rs, collide=0.2)
+        f16 = bool(rs.rand() < 0.3); with_agents = bool(rs.rand() < 0.6)
+        th.manual_seed(int(rs.randint(10 ** 6)))
+        ag = die_amd.NeuralAutomataAgent(scale=0.07, deposit=1.5, with_agent_channel=with_agents, kernel_sizes=ks)
+        ag.model.init_weights()
+        env = die_amd.Env.from_numpy(medium, agents, field_dtype=th.float16 if f16 else th.float32)
+        action = ag.forward(env._get_current_obs)
+        ws = [k.weight.detach().numpy().astype(np.float64) for k in ag.model.conv_layers()]
+        m = env.medium.to_numpy()                                   # (fp16 fields: the oracle sees the rounded values)
+        want = R.nca_forward((agents, m), ws, 0.07, 1.5, with_agents)
+        got = action.to_numpy()
+        if not np.allclose(got, want, rtol=1e-5, atol=2e-5):
+            fails += 1
+            print(f'CASE {case}: W={W} H={H} kernels={ks} f16={f16} agents_channel={with_agents} max err {np.abs(got - want).max():.3g}', flush=True)
+        if verbose and case % 10 == 9:
+            print(f'  nca: {case + 1} cases, {fails} failures', flush=True)
+    return fails
+
+
 def fuzz_init(n_cases=100, seed=0, verbose=True):
     rs = np.random.RandomState(seed)
     fails = 0
@@ -268,5 +297,5 @@ if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'step'
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     seed = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init, 'binned': fuzz_binned, 'batched': fuzz_batched}[which](n, seed)
+    f = {'step': fuzz_step, 'forward': fuzz_forward, 'paths': fuzz_paths, 'init': fuzz_init, 'binned': fuzz_binned, 'batched': fuzz_batched, 'nca': fuzz_nca}[which](n, seed)
     print(f'{which}: {n} cases, {f} failures')

@@ -38,3 +38,7 @@ def test_fuzz_binned_step_vs_classic_step(fuzz):
 
 def test_fuzz_batched_replicas_vs_stand_alone_runs(fuzz):
     assert fuzz.fuzz_batched(10, seed=106, verbose=False) == 0
+
+
+def test_fuzz_neural_automata_sensing_vs_oracle(fuzz):
+    assert fuzz.fuzz_nca(25, seed=107, verbose=False) == 0
