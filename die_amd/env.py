@@ -465,8 +465,7 @@ class Env(_EnvBase):
 
     def _alloc_sort_buffers(self):
         A = self.agents
-        self._shadow = [torch.empty_like(t) for t in (A.x, A.y, A.alive, A.agent_food)] + \
-                       [torch.empty(A.N, dtype=torch.int32, device=self.device)]
+        self._shadow = [torch.empty_like(t) for t in (A.x, A.y, A.alive, A.agent_food)]
         n = _lib.lib.die_sort_workspace_bytes(self.medium.W, self.medium.H, A.N)
         self._sort_ws = torch.empty(n, dtype=torch.uint8, device=self.device)
 
@@ -477,7 +476,10 @@ class Env(_EnvBase):
         A = self.agents
         if self._shadow is None:
             self._alloc_sort_buffers()
-        ox, oy, oalive, ofood, oslot = self._shadow
+        ox, oy, oalive, ofood = self._shadow[:4]
+        # the slot array is NEVER recycled: every action computed so far holds the one that was current then, to un-permute
+        # itself when it is read (found by tests/fuzz_cases.py: an action read two sorts later saw a recycled array)
+        oslot = torch.empty(A.N, dtype=torch.int32, device=self.device)
         owners, tensors = [], []
         for obj in A.attached():
             ts = obj._die_state_tensors(A)
@@ -492,9 +494,7 @@ class Env(_EnvBase):
         _lib.check(_lib.lib.die_agents_sort(C.byref(m), C.byref(a_in), C.byref(a_out), len(tensors), ein, eout,
                                             _ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr(self.device)),
                    'die_agents_sort')
-        old_slot = A.slot
-        self._shadow = [A.x, A.y, A.alive, A.agent_food,
-                        old_slot if old_slot is not None else torch.empty(A.N, dtype=torch.int32, device=self.device)]
+        self._shadow = [A.x, A.y, A.alive, A.agent_food]
         A.x, A.y, A.alive, A.agent_food, A.slot = ox, oy, oalive, ofood, oslot
         k = 0
         for obj, n in owners:

@@ -147,9 +147,16 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
         turn = np.radians(30); dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
         read_mode = rs.choice(['every', 'some', 'never'])
         switch_at = int(rs.randint(2, 7)) if rs.rand() < 0.4 else None
+        poke = rs.choice([0, 0, 0, 1, 2, 3, 4], size=8)
+        se = int(rs.choice([0, 2, 3]))
+        only = os.environ.get('FUZZ_ONLY')
+        if only is not None and int(only) != case:
+            continue
+        if only is not None:
+            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se}', flush=True)
         outs = []
         for pic in (True, False):
-            env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=int(rs.choice([0, 2, 3])) if pic else 3, pic=pic,
+            env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=se if pic else 3, pic=pic,
                                          field_dtype=torch.float16 if f16 else torch.float32)
             env._pic_tile = (xs, ys) if pic else None
             ag = die_amd.PhysarumAgent(max_agents=N, seed=7, **kw)
@@ -169,6 +176,10 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
                     acts = None                                 # (no accessor after a bookkeeping error: slot ids may be garbage)
                     break
                 rewards.append((rew, info['num_agents']))
+                if pic and poke[i] == 1: env.medium.occupied()                   # observers in between: the claim plane is rebuilt,
+                elif pic and poke[i] == 2: env.agents.to_numpy()                 # the arrays read,
+                elif pic and poke[i] == 3: env.sort_agents()                     # re-ordered behind the binned step's back,
+                elif pic and poke[i] == 4: env.render_rgb8()                     # a frame rendered
                 if read_mode == 'every' or (read_mode == 'some' and i % 3 == 0):
                     acts.append(a.to_numpy())
                 elif read_mode == 'some' and i % 3 == 1:
@@ -177,13 +188,15 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
                 outs = None
                 break
             acts += [a.to_numpy() for a in held]
-            if pic and (env._pic is None or (switch_at is None and env._pic.held[0] is not env.agents.x)):
+            if pic and (env._pic is None or (switch_at is None and poke[7] != 3 and env._pic.held[0] is not env.agents.x)):
                 fails += 1; print(f'CASE {case}: the binned path did not run (W={W} H={H} tile=({xs},{ys}) reach={reach})', flush=True)
             outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array(rewards),
                          np.stack(acts) if acts else np.zeros(0)))
         for name, a, b in zip(('medium', 'agents', 'heading', 'rewards', 'actions'), *(outs or ((), ()))):
             if a.shape != b.shape or not np.array_equal(a, b):
                 fails += 1
+                if name == 'actions' and a.shape == b.shape:
+                    name = 'actions ' + str([bool(np.array_equal(a[k], b[k])) for k in range(a.shape[0])])
                 if name == 'medium' and a.shape == b.shape:
                     name = 'medium ' + str([bool(np.array_equal(a[c], b[c])) for c in range(3)]) + f' max chem diff {np.abs(a[2] - b[2]).max():.3g} food diff {np.abs(a[1] - b[1]).max():.3g}'
                 print(f'CASE {case} {name} differs: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} dyn={dyn} kw={kw} read={read_mode} switch={switch_at}', flush=True)

@@ -588,6 +588,26 @@ def test_tile_binned_step_regressions_found_by_the_fuzzer(die, f16):
         assert np.array_equal(a, b), name
 
 
+def test_actions_read_after_later_sorts_keep_their_order(die):
+    """An action un-permutes itself with the slot array that was current when it was computed; `sort_agents` used to recycle
+    that array as the output buffer of the sort after next (found by tests/fuzz_cases.py): slot arrays are never reused now."""
+    W, H, N = 64, 64, 3000
+    rs = np.random.RandomState(3)
+    medium, agents = random_state(W, H, N, N, rs)
+    env = die.Env.from_numpy(medium, agents, sort_every=1)
+    ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    obs = env._get_current_obs
+    held, want = [], []
+    for i in range(6):
+        a = ag.forward(obs)
+        a.ensure()                                   # computed now, in the current array order …
+        held.append(a)
+        want.append(a.to_numpy().copy())
+        obs, *_ = env.step(a)                        # … every step re-sorts the arrays
+    for a, w in zip(held, want):
+        assert np.array_equal(a.to_numpy(), w)       # … and read again five sorts later
+
+
 def test_tile_binned_step_refuses_long_steps(die):
     """A step longer than a tile cannot use the binned path: the env silently takes the classic one."""
     W, H, N = 128, 96, 3000
