@@ -47,6 +47,11 @@ __device__ __forceinline__ float die_round_f32(float v) {
 }
 __device__ __forceinline__ __half die_f2h(float v) { return __float2half(die_round_f32(v)); }
 __device__ __forceinline__ void die_st(__half* p, int64_t i, float v) { p[i] = die_f2h(v); }
+// what a value becomes when it is stored in a plane of T and read back (the staged step stores chem + deposit before it
+// diffuses; the fused sweeps keep the sum in registers and have to round it the same way to give the same bits)
+template <typename T> __device__ __forceinline__ float die_as_stored(float v);
+template <> __device__ __forceinline__ float die_as_stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float die_as_stored<__half>(float v) { return __half2float(die_f2h(v)); }
 
 // ---- Q0.32 fixed-point coordinates -------------------------------------------------------
 // nearest label of linspace(0, 1, n) to X / 2^32, P may lie outside [0, 2^32) (probe offsets):

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     occ[j] = die_claim_occupied(c[j], a.epoch);
-                    if (occ[j]) v[j] += die_claim_deposit(c[j]);     // chem[cell] + deposit of the last writer
+                    if (occ[j]) v[j] = die_as_stored<T>(v[j] + die_claim_deposit(c[j]));     // chem[cell] + deposit of the last writer
                     any |= occ[j];
                 }
             } else {
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     occ[j] = d[j] != DIE_DEP_EMPTY;
-                    if (occ[j]) v[j] += __uint_as_float(d[j]);
+                    if (occ[j]) v[j] = die_as_stored<T>(v[j] + __uint_as_float(d[j]));
                     any |= occ[j];
                 }
             }

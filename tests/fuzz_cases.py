@@ -103,23 +103,27 @@ def fuzz_paths(n_cases=100, seed=0, verbose=True):
         dyn = dict(boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])), agents_die=bool(rs.rand() < 0.3), food_infinite=bool(rs.rand() < 0.2),
                    diffuse_sigma=float(rs.choice([0.5, 0.8])))
         phys = rs.rand() < 0.7
+        f16 = bool(rs.rand() < 0.3)
         turn = np.radians(30); dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn); prev = f32(rs.normal(0, .4, (2, N)))
         outs = []
         for variant in ('default', 'staged', 'eager', 'sorted'):
             env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=1 if variant == 'sorted' else 0,
-                                         staged=variant == 'staged')
+                                         staged=variant == 'staged', field_dtype=torch.float16 if f16 else torch.float32)
             if phys: ag = die_amd.PhysarumAgent(max_agents=N, seed=3, scale=2.0 / max(W, H), sense_offset=0.05)
             else: ag = die_amd.GradientAgent(max_agents=N, seed=3, scale=0.01, sense_offset=0.03, inertia=0.8, noise_scale=0.02)
             ag.set_state(dir0, None if phys else prev)
             ag.lazy = variant != 'eager'
             obs = env._get_current_obs
+            held = []
             for _ in range(4):
-                obs, *_ = env.step(ag.forward(obs))
-            outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy()))
+                a = ag.forward(obs)
+                held.append(a)
+                obs, *_ = env.step(a)
+            outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.stack([a.to_numpy() for a in held])))
         for v, o in zip(('staged', 'eager', 'sorted'), outs[1:]):
             for a, b in zip(outs[0], o):
                 if not np.array_equal(a, b):
-                    fails += 1; print(f'CASE {case} variant {v} differs: W={W} H={H} N={N} K={K} phys={phys} dyn={dyn}', flush=True); break
+                    fails += 1; print(f'CASE {case} variant {v} differs: W={W} H={H} N={N} K={K} phys={phys} f16={f16} dyn={dyn}', flush=True); break
     return fails
 
 
@@ -149,23 +153,33 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
         switch_at = int(rs.randint(2, 7)) if rs.rand() < 0.4 else None
         poke = rs.choice([0, 0, 0, 1, 2, 3, 4], size=8)
         se = int(rs.choice([0, 2, 3]))
+        gradient = bool(rs.rand() < 0.25)            # GradientAgent without momentum: the binned step stores its action
+        two_agents = bool(rs.rand() < 0.2)           # two agent objects take turns on one env (each with its own headings)
         only = os.environ.get('FUZZ_ONLY')
         if only is not None and int(only) != case:
             continue
         if only is not None:
-            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se}', flush=True)
+            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se} gradient={gradient} two={two_agents}', flush=True)
         outs = []
         for pic in (True, False):
             env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=se if pic else 3, pic=pic,
                                          field_dtype=torch.float16 if f16 else torch.float32)
             env._pic_tile = (xs, ys) if pic else None
-            ag = die_amd.PhysarumAgent(max_agents=N, seed=7, **kw)
-            ag.set_state(dir0)
+            def make(sd):
+                if gradient:
+                    g = die_amd.GradientAgent(max_agents=N, seed=sd, scale=kw['scale'], sense_offset=kw['sense_offset'], deposit=kw['deposit'],
+                                              inertia=0.0, noise_scale=0.0, normalized_grad=True)
+                else:
+                    g = die_amd.PhysarumAgent(max_agents=N, seed=sd, **kw)
+                g.set_state(dir0)
+                return g
+            ags = [make(7), make(8)] if two_agents else [make(7)]
             obs = env._get_current_obs
             acts, rewards, held = [], [], []
             for i in range(8):
                 if pic and switch_at is not None:
                     env._pic_enabled = not (switch_at <= i < switch_at + 2)      # two classic steps in between
+                ag = ags[(i // 2) % len(ags)]
                 a = ag.forward(obs)
                 try:
                     obs, rew, _, _, info = env.step(a)
@@ -190,7 +204,7 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
             acts += [a.to_numpy() for a in held]
             if pic and (env._pic is None or (switch_at is None and poke[7] != 3 and env._pic.held[0] is not env.agents.x)):
                 fails += 1; print(f'CASE {case}: the binned path did not run (W={W} H={H} tile=({xs},{ys}) reach={reach})', flush=True)
-            outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array(rewards),
+            outs.append((env.medium.to_numpy(), env.agents.to_numpy(), np.stack([g.direction_rads_numpy() for g in ags]), np.array(rewards),
                          np.stack(acts) if acts else np.zeros(0)))
         for name, a, b in zip(('medium', 'agents', 'heading', 'rewards', 'actions'), *(outs or ((), ()))):
             if a.shape != b.shape or not np.array_equal(a, b):
@@ -199,7 +213,7 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
                     name = 'actions ' + str([bool(np.array_equal(a[k], b[k])) for k in range(a.shape[0])])
                 if name == 'medium' and a.shape == b.shape:
                     name = 'medium ' + str([bool(np.array_equal(a[c], b[c])) for c in range(3)]) + f' max chem diff {np.abs(a[2] - b[2]).max():.3g} food diff {np.abs(a[1] - b[1]).max():.3g}'
-                print(f'CASE {case} {name} differs: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} dyn={dyn} kw={kw} read={read_mode} switch={switch_at}', flush=True)
+                print(f'CASE {case} {name} differs: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} gradient={gradient} two={two_agents} dyn={dyn} kw={kw} read={read_mode} switch={switch_at}', flush=True)
                 break
         if verbose and case % 10 == 9:
             print(f'  binned: {case + 1} cases, {fails} failures', flush=True)
