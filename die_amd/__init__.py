@@ -8,10 +8,10 @@ importing this package fails if that library is missing — there is no CPU fall
 from . import _lib
 from .agent import Agent, BrownianAgent, ConstAgent, ConvolutionModel, GradientAgent, NeuralAutomataAgent, PhysarumAgent
 from .base_types import DataChannels
-from .data_init import DataInitializer, WaveSequence
+from .data_init import DataInitializer, FieldSequence, PerlinNoiseSequence, WaveSequence
 from .device_array import DeviceAction, DeviceAgents, DeviceMedium
 from .env import BoundaryCondition, Dynamics, Env, linear_action_cost, zero_cost
 
-__all__ = ['WaveSequence', 'Env', 'Dynamics', 'BoundaryCondition', 'linear_action_cost', 'zero_cost', 'Agent', 'PhysarumAgent',
+__all__ = ['WaveSequence', 'PerlinNoiseSequence', 'FieldSequence', 'Env', 'Dynamics', 'BoundaryCondition', 'linear_action_cost', 'zero_cost', 'Agent', 'PhysarumAgent',
            'GradientAgent', 'BrownianAgent', 'ConstAgent', 'NeuralAutomataAgent', 'ConvolutionModel', 'DataInitializer', 'DataChannels', 'DeviceMedium',
            'DeviceAgents', 'DeviceAction']

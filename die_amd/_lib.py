@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 
 class Medium(C.Structure):
@@ -144,6 +144,7 @@ _SIGNATURES = {
                                  C.c_uint32, C.c_void_p]),
     'die_medium_from_fields': (C.c_int, [_P(Medium), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
     'die_food_flow_wave': (C.c_int, [_P(Medium), C.c_double, C.c_double, C.c_double, C.c_void_p]),
+    'die_food_flow_perlin': (C.c_int, [_P(Medium), C.c_double, C.c_int32, C.c_double, C.c_double, C.c_uint64, C.c_void_p]),
     'die_sense_mask': (C.c_int, [_P(Medium), C.c_float, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'die_render_frames': (C.c_int, [_P(Medium), C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),

@@ -277,6 +277,38 @@ extern "C" int die_food_flow_wave(const die_medium* m, double t, double scale, d
 }
 
 
+// PerlinNoiseSequence.__getitem__ (core/data_init.py:55-69) inside FieldSequence.get_flow_operator (:29-38):
+// food ← scale · round(noise((x, y, t)), 3) + (1 − decay) · food with x, y the linspace(0, 1, n) labels of the world cell and
+// `noise` the 3-D gradient noise at (x, y, t) · octaves.
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_food_flow_perlin(T* food, die_geo g, double t, double octaves, double scale, double keep, uint64_t seed) {
+    const int64_t total = (int64_t)g.W * g.H;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int li = (int)(i / g.H), lj = (int)(i - (int64_t)li * g.H);
+        int gi = (li + g.ox) % g.gW, gj = (lj + g.oy) % g.gH;
+        gi = gi < 0 ? gi + g.gW : gi;
+        gj = gj < 0 ? gj + g.gH : gj;
+        const double x = (double)gi / (double)(g.gW - 1), y = (double)gj / (double)(g.gH - 1);
+        const double z = rint(die_perlin3(seed, x * octaves, y * octaves, t * octaves) * 1000.0) / 1000.0;
+        die_st(food, i, (float)(scale * z + keep * (double)die_ld(food, i)));
+    }
+}
+
+extern "C" int die_food_flow_perlin(const die_medium* m, double t, int32_t octaves, double scale, double decay, uint64_t seed, void* stream) {
+    DIE_REQUIRE(m && m->food && m->W >= 1 && m->H >= 1, "die_food_flow_perlin: bad medium");
+    DIE_REQUIRE(m->dtype == DIE_F32 || m->dtype == DIE_F16, "die_food_flow_perlin: bad field dtype %d", m->dtype);
+    DIE_REQUIRE(octaves >= 1, "die_food_flow_perlin: octaves %d", octaves);
+    const die_geo g = die_geo_of(m);
+    DIE_REQUIRE(g.gW >= 2 && g.gH >= 2, "die_food_flow_perlin: the world must be at least 2x2");
+    const int64_t total = (int64_t)m->W * m->H;
+    const int grid = init_grid(total);
+    if (m->dtype == DIE_F32) k_food_flow_perlin<float><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((float*)m->food, g, t, (double)octaves, scale, 1.0 - decay, seed);
+    else k_food_flow_perlin<__half><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>((__half*)m->food, g, t, (double)octaves, scale, 1.0 - decay, seed);
+    DIE_CHECK_LAUNCH("die_food_flow_perlin");
+    return DIE_OK;
+}
+
 // ---- DataInitializer builder steps on plain fp32 arrays (core/data_init.py:171-253) --------------------------------
 // with_const (:214-216), with_noise / get_random (:168-169,218-220), with_agents (:222-226), with_food_perlin / with_chem
 // (:228-236) fill one channel; build / build_agents (:238-253) multiply by the static mask and hand the channels over.

@@ -63,3 +63,34 @@ __device__ inline double die_perlin2(uint64_t seed, double x, double y) {
     const double a = d00 + u * (d10 - d00), b = d01 + u * (d11 - d01);
     return a + v * (b - a);
 }
+
+// 3-D gradient noise for PerlinNoiseSequence (core/data_init.py:55-69: noise((x, y, t))): a unit gradient on every lattice
+// point of the integer grid — uniform on the sphere: z = 2·u1 − 1, azimuth 2π·u2 from one Philox draw keyed by the point
+// (step word 1 keeps it apart from the 2-D lattice) — the eight corner dot products blended with the quintic fade.
+// oracle/cpu_ref.py perlin3 is the same function in numpy.
+__device__ inline double die_perlin_dot3(uint64_t seed, int64_t i, int64_t j, int64_t k, double dx, double dy, double dz) {
+    const uint64_t key = (uint64_t)(i & 0xFFFFF) | ((uint64_t)(j & 0xFFFFF) << 20) | ((uint64_t)(k & 0xFFFFF) << 40);
+    const die_u32x4 r = die_draw(seed, 1u, key, DIE_STREAM_INIT_FOOD);
+    const double gz = 2.0 * ((double)r.v[0] * (1.0 / 4294967296.0)) - 1.0;
+    const double gr = sqrt(fmax(1.0 - gz * gz, 0.0));
+    const double th = 6.283185307179586476925 * ((double)r.v[1] * (1.0 / 4294967296.0));
+    return gr * cos(th) * dx + gr * sin(th) * dy + gz * dz;
+}
+__device__ inline double die_fade5(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }
+__device__ inline double die_perlin3(uint64_t seed, double x, double y, double z) {
+    const double fx0 = floor(x), fy0 = floor(y), fz0 = floor(z);
+    const int64_t i = (int64_t)fx0, j = (int64_t)fy0, k = (int64_t)fz0;
+    const double tx = x - fx0, ty = y - fy0, tz = z - fz0;
+    const double u = die_fade5(tx), v = die_fade5(ty), w = die_fade5(tz);
+    double plane[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const double dz = tz - (double)c;
+        const double d00 = die_perlin_dot3(seed, i, j, k + c, tx, ty, dz), d10 = die_perlin_dot3(seed, i + 1, j, k + c, tx - 1.0, ty, dz);
+        const double d01 = die_perlin_dot3(seed, i, j + 1, k + c, tx, ty - 1.0, dz), d11 = die_perlin_dot3(seed, i + 1, j + 1, k + c, tx - 1.0, ty - 1.0, dz);
+        const double a = d00 + u * (d10 - d00), b = d01 + u * (d11 - d01);
+        plane[c] = a + v * (b - a);
+    }
+    return plane[0] + w * (plane[1] - plane[0]);
+}
+

@@ -55,11 +55,12 @@ def food_spec_from_seed(seed: int, n_waves: int = 6, max_freq: int = 5, scale: f
     return spec
 
 
-class WaveFoodFlow:
-    """The operator returned by `WaveSequence.get_flow_operator` (core/data_init.py:29-38): called by `Env.step` as
-    `op_food_flow`; recognised there and applied on the device (`die_food_flow_wave`) without a host round trip."""
+class DeviceFoodFlow:
+    """The operator returned by `FieldSequence.get_flow_operator` (core/data_init.py:29-38) for the sequences whose field is
+    evaluated on the device (WaveSequence, PerlinNoiseSequence): called by `Env.step` as `op_food_flow`; recognised there
+    and applied in HBM without a host round trip."""
 
-    def __init__(self, seq: 'WaveSequence', scale: float, decay: float):
+    def __init__(self, seq: 'FieldSequence', scale: float, decay: float):
         self.seq, self.scale, self.decay = seq, float(scale), float(decay)
         self._k = 0
 
@@ -69,10 +70,7 @@ class WaveFoodFlow:
         return t
 
     def apply(self, medium: DeviceMedium):
-        from .device_array import stream_ptr
-        m = medium.c_struct()
-        _lib.check(_lib.lib.die_food_flow_wave(C.byref(m), self.next_t(), self.scale, self.decay, stream_ptr(medium.device)),
-                   'die_food_flow_wave')
+        self.seq._flow(medium, self.next_t(), self.scale, self.decay)
 
     def __call__(self, current):
         """Host arrays (the reference's calling convention): same arithmetic, evaluated on the device."""
@@ -84,16 +82,30 @@ class WaveFoodFlow:
         return m.food.to(torch.float64).cpu().numpy()
 
 
-class WaveSequence:
-    """core/data_init.py:15-89 (FieldSequence + WaveSequence): a time sequence of running-wave fields."""
+WaveFoodFlow = DeviceFoodFlow          # (round-1 name)
+
+
+class FieldSequence:
+    """core/data_init.py:16-52: a time sequence of fields over arange(*t_bounds, dt), cycled by `__iter__`;
+    `get_flow_operator(scale, decay)` gives food ← scale·next(field) + (1 − decay)·food.  Subclasses that define `_flow`
+    (the same update as one kernel on a DeviceMedium) run inside `Env.step` on the device; a subclass that only defines
+    `__getitem__` (numpy) works too, through the host round trip `Env` gives any Python operator."""
 
     def __init__(self, field_size: Sequence[int], dt: float = 0.01, t_bounds: Tuple[float, float] = (0, 10)):
         self._size = tuple(int(v) for v in field_size)
         self._tbounds = t_bounds
         self._ts = np.arange(*t_bounds, dt)
 
-    def get_flow_operator(self, scale: float = 1.0, decay: float = 0.0) -> WaveFoodFlow:
-        return WaveFoodFlow(self, scale, decay)
+    _flow = None
+
+    def get_flow_operator(self, scale: float = 1.0, decay: float = 0.0):
+        if self._flow is not None:
+            return DeviceFoodFlow(self, scale, decay)
+        it = iter(self)
+
+        def food_flow(current):
+            return scale * next(it) + (1 - decay) * current
+        return food_flow
 
     def __iter__(self):
         from itertools import cycle
@@ -108,12 +120,34 @@ class WaveSequence:
         return t0 <= t < t_end
 
     def __getitem__(self, t: float) -> np.ndarray:
-        from .device_array import stream_ptr
-        dev = torch.device('cuda', torch.cuda.current_device())
+        if self._flow is None:
+            raise NotImplementedError
+        dev = torch.device('cuda', torch.cuda.current_device())         # the field itself: the update applied to zeros
         m = DeviceMedium(self._size, dev, torch.float32)
         m.food.zero_()
-        _lib.check(_lib.lib.die_food_flow_wave(C.byref(m.c_struct()), float(t), 1.0, 0.0, stream_ptr(dev)), 'die_food_flow_wave')
+        self._flow(m, float(t), 1.0, 0.0)
         return m.food.to(torch.float64).cpu().numpy()
+
+
+class WaveSequence(FieldSequence):
+    """core/data_init.py:71-89: running waves + moving islands (`die_food_flow_wave`)."""
+
+    def _flow(self, medium: DeviceMedium, t: float, scale: float, decay: float):
+        _lib.check(_lib.lib.die_food_flow_wave(C.byref(medium.c_struct()), t, scale, decay, stream_ptr(medium.device)), 'die_food_flow_wave')
+
+
+class PerlinNoiseSequence(FieldSequence):
+    """core/data_init.py:55-69: `PerlinNoise(octaves)((x, y, t))` on the cell labels, `.round(3)` (`die_food_flow_perlin`).
+    The un-vendored `perlin_noise` package is seeded from the global RNG; here the lattice gradients come from `seed`."""
+
+    def __init__(self, field_size: Sequence[int], dt: float = 0.01, t_bounds: Tuple[float, float] = (0, 1), octaves: int = 8,
+                 seed: int = 0):
+        super().__init__(field_size, dt, t_bounds)
+        self._octaves, self._seed = int(octaves), int(seed)
+
+    def _flow(self, medium: DeviceMedium, t: float, scale: float, decay: float):
+        _lib.check(_lib.lib.die_food_flow_perlin(C.byref(medium.c_struct()), t, self._octaves, scale, decay,
+                                                 self._seed & 0xFFFFFFFFFFFFFFFF, stream_ptr(medium.device)), 'die_food_flow_perlin')
 
 
 class DataInitializer:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 15
+#define DIE_ABI_VERSION 16
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -340,6 +340,9 @@ int die_medium_from_fields(const die_medium* m, const float* agents, const float
  * (core/data_init.py:29-38): food <- scale * z(x, y, t) + (1 - decay) * food, z = WaveSequence.__getitem__(t)
  * (core/data_init.py:71-89) evaluated at the world cell of every local element; float64 arithmetic. */
 int die_food_flow_wave(const die_medium* medium, double t, double scale, double decay, void* stream);
+/* The same with PerlinNoiseSequence.__getitem__(t) (core/data_init.py:55-69) as the field: round(noise((x, y, t)), 3), `noise` =
+ * 3-D gradient noise at (x, y, t) * octaves on the linspace(0, 1, n) labels, lattice gradients from Philox(seed, point). */
+int die_food_flow_perlin(const die_medium* medium, double t, int32_t octaves, double scale, double decay, uint64_t seed, void* stream);
 
 /* Env._get_sense_mask (core/env.py:276-290): mask = ceil(round(gaussian(agents channel, sigma, mode 'nearest',
  * truncate 4), decimals)) as W*H bytes (the reference uses sigma 2.0, 3 decimals); float64 accumulation, axis 0

@@ -583,6 +583,78 @@ def nca_forward(obs, weights, scale=0.1, deposit=1.0, with_agent_channel=True) -
     return sense[:, ix, iy] * np.array([scale, scale, deposit])[:, None]
 
 
+def perlin3(seed: int, x, y, z) -> np.ndarray:
+    """3-D gradient noise, the twin of die_perlin3 (die_amd/csrc/die_rng.h): what `PerlinNoise(octaves)((x, y, t))` of
+    core/data_init.py:55-69 is built from.  Lattice gradients uniform on the sphere (z = 2·u1 − 1, azimuth 2π·u2) from
+    Philox(seed, step word 1, lattice point); eight corner dot products, quintic fade."""
+    x, y, z = np.broadcast_arrays(np.asarray(x, dtype=np.float64), np.asarray(y, dtype=np.float64), np.asarray(z, dtype=np.float64))
+    fx0, fy0, fz0 = np.floor(x), np.floor(y), np.floor(z)
+    i, j, k = fx0.astype(np.int64), fy0.astype(np.int64), fz0.astype(np.int64)
+    tx, ty, tz = x - fx0, y - fy0, z - fz0
+
+    def dot(ii, jj, kk, dx, dy, dz):
+        key = ((ii & 0xFFFFF).astype(np.uint64) | ((jj & 0xFFFFF).astype(np.uint64) << np.uint64(20)) |
+               ((kk & 0xFFFFF).astype(np.uint64) << np.uint64(40))).ravel()
+        r = orng._draw(seed, 1, key, orng.STREAM_INIT_FOOD)
+        gz = 2.0 * (r[0].astype(np.float64) * (1.0 / 4294967296.0)).reshape(dx.shape) - 1.0
+        gr = np.sqrt(np.maximum(1.0 - gz * gz, 0.0))
+        th = 6.283185307179586476925 * (r[1].astype(np.float64) * (1.0 / 4294967296.0)).reshape(dx.shape)
+        return gr * np.cos(th) * dx + gr * np.sin(th) * dy + gz * dz
+
+    fade = lambda t: t * t * t * (t * (t * 6.0 - 15.0) + 10.0)
+    u, v, w = fade(tx), fade(ty), fade(tz)
+    planes = []
+    for c in (0, 1):
+        dz = tz - float(c)
+        d00, d10 = dot(i, j, k + c, tx, ty, dz), dot(i + 1, j, k + c, tx - 1.0, ty, dz)
+        d01, d11 = dot(i, j + 1, k + c, tx, ty - 1.0, dz), dot(i + 1, j + 1, k + c, tx - 1.0, ty - 1.0, dz)
+        a, b = d00 + u * (d10 - d00), d01 + u * (d11 - d01)
+        planes.append(a + v * (b - a))
+    return planes[0] + w * (planes[1] - planes[0])
+
+
+def perlin3_field(W: int, H: int, t: float, octaves: int, seed: int) -> np.ndarray:
+    """PerlinNoiseSequence.__getitem__ (core/data_init.py:64-69): noise((x, y, t)) on the linspace(0, 1, n) labels, `.round(3)`."""
+    xs = np.linspace(0, 1, W)[:, None] * np.ones((1, H))
+    ys = np.ones((W, 1)) * np.linspace(0, 1, H)[None, :]
+    return np.round(perlin3(seed, xs * octaves, ys * octaves, np.full((W, H), t * octaves)), 3)
+
+
+class RefFieldSequence:
+    """FieldSequence (core/data_init.py:16-52): `__iter__` cycles over arange(*t_bounds, dt) yielding self[t];
+    `get_flow_operator` (:29-38) returns food_flow(current) = scale·next(it) + (1 − decay)·current."""
+
+    def __init__(self, field_size, dt: float = 0.01, t_bounds=(0, 10)):
+        self._size = tuple(field_size)
+        self._ts = np.arange(*t_bounds, dt)
+
+    def __getitem__(self, t):
+        raise NotImplementedError
+
+    def __iter__(self):
+        from itertools import cycle
+        for t in cycle(self._ts):
+            yield self[t]
+
+    def get_flow_operator(self, scale: float = 1.0, decay: float = 0.0):
+        it = iter(self)
+
+        def food_flow(current):
+            return scale * next(it) + (1 - decay) * current
+        return food_flow
+
+
+class RefPerlinNoiseSequence(RefFieldSequence):
+    """core/data_init.py:55-69 (t_bounds (0, 1), octaves 8) with the seeded noise above."""
+
+    def __init__(self, field_size, dt: float = 0.01, t_bounds=(0, 1), octaves: int = 8, seed: int = 0):
+        super().__init__(field_size, dt, t_bounds)
+        self._octaves, self._seed = int(octaves), int(seed)
+
+    def __getitem__(self, t):
+        return perlin3_field(self._size[0], self._size[1], float(t), self._octaves, self._seed)
+
+
 class RefWaveSequence:
     """FieldSequence / WaveSequence (core/data_init.py:15-89): `__iter__` cycles over arange(*t_bounds, dt) yielding
     wave_field(t); `get_flow_operator` (:29-38) returns food_flow(current) = scale·next(it) + (1 − decay)·current."""

@@ -1153,6 +1153,42 @@ def test_wave_sequence_food_flow_on_device(die, W, H):
     assert np.abs(op(f0) - (2.0 * R.wave_field(W, H, 0.0) + 0.75 * f0)).max() < 1e-6
 
 
+@pytest.mark.parametrize('W,H', [(64, 48), (37, 91)])
+def test_perlin_noise_sequence_food_flow_on_device(die, W, H):
+    """PerlinNoiseSequence (core/data_init.py:55-69) as a FieldSequence whose flow operator runs on the device
+    (die_food_flow_perlin): the field itself and an env run with it as Dynamics.op_food_flow, against the oracle's perlin3
+    (values are rounded to 3 decimals: a value within 1e-9 of a .0005 tie may land on the other side — at most a few cells)."""
+    seq = die.PerlinNoiseSequence((W, H), dt=0.05, octaves=8, seed=11)
+    assert len(seq) == 20 and 0.5 in seq and 1.0 not in seq
+    for t in (0.0, 0.35, 0.95):
+        d = np.abs(seq[t] - R.perlin3_field(W, H, t, 8, 11))
+        assert (d > 1e-6).mean() <= 2e-3 and d.max() <= 1.001e-3
+    N, K = 500, 400
+    rs = np.random.RandomState(3)
+    medium, agents = random_state(W, H, N, K, rs)
+    rseq = R.RefPerlinNoiseSequence((W, H), dt=0.05, t_bounds=(0, 1), octaves=8, seed=11)
+    dyn = die.Dynamics(op_food_flow=seq.get_flow_operator(scale=0.5, decay=0.5))
+    rdyn = R.RefDynamics(op_food_flow=rseq.get_flow_operator(scale=0.5, decay=0.5), rate_feed=float(np.float32(0.1)),
+                         rate_decay_chem=float(np.float32(0.1)))
+    env, ref = die.Env.from_numpy(medium, agents, dyn), R.RefEnv(medium, agents, rdyn)
+    for _ in range(4):
+        action = quantised_action(N, rs, 2.0 / W)
+        env.step(action)
+        ref.step(action)
+    m = env.medium.to_numpy()
+    d = np.abs(m[1] - ref.medium[1])
+    assert (d > 2e-6).mean() <= 5e-3 and d.max() <= 1.1e-3              # (rounding ties of the noise, halved per step)
+    assert np.array_equal(m[0], ref.medium[0])
+    # a FieldSequence that only knows numpy goes through the host round trip
+    class Ramp(die.FieldSequence):
+        def __getitem__(self, t):
+            return np.full(self._size, float(t))
+    env2 = die.Env.from_numpy(medium, agents, die.Dynamics(op_food_flow=Ramp((W, H), dt=0.5, t_bounds=(1, 2)).get_flow_operator(1.0, 1.0)))
+    env2.step(quantised_action(N, rs, 2.0 / W))
+    f1 = env2.medium.to_numpy()[1]
+    assert np.allclose(f1, 1.0, atol=1e-6)                               # food <- 1·field(t = 1) + 0·food (the flow comes after feeding)
+
+
 def test_sense_mask_parity(die):
     """Dynamics.apply_sense_mask (core/env.py:276-295): the agents only see the medium within the blurred
     neighbourhood of the agents channel.  Mask plane bit for bit against the oracle (scipy gaussian, mode 'nearest',

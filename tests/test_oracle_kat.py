@@ -172,6 +172,27 @@ def test_perlin_noise_properties():
     assert (R.perlin_field(64, 48, 8, 1234, threshold=0.1) <= 0.1).all()
 
 
+def test_perlin3_noise_properties_and_sequence():
+    """oracle.perlin3 (PerlinNoiseSequence, core/data_init.py:55-69): 0 on lattice points, bounded, continuous, fixed by the
+    seed; the sequence cycles over arange(*t_bounds, dt) and its flow operator is scale·field + (1 − decay)·current."""
+    xs = np.arange(0, 5, dtype=np.float64)
+    assert np.array_equal(R.perlin3(5, xs, xs[::-1], xs), np.zeros(5))
+    t = np.linspace(0, 6, 3001)
+    f = R.perlin3(5, t, 0.37 + 0 * t, 1.2 + 0 * t)
+    assert 0.2 < np.abs(f).max() <= 1.0 and np.abs(np.diff(f)).max() < 0.01
+    assert np.array_equal(f, R.perlin3(5, t, 0.37 + 0 * t, 1.2 + 0 * t)) and not np.array_equal(f, R.perlin3(6, t, 0.37 + 0 * t, 1.2 + 0 * t))
+    # a slice at integer t·octaves is a different 2-D noise for every lattice plane, continuous in t
+    a, b = R.perlin3_field(16, 12, 0.25, 8, 3), R.perlin3_field(16, 12, 0.2501, 8, 3)
+    assert np.array_equal(a, np.round(a, 3)) and np.abs(a - b).max() <= 0.003 and np.abs(a).max() > 0.1
+    seq = R.RefPerlinNoiseSequence((16, 12), dt=0.25, t_bounds=(0, 0.75), octaves=8, seed=3)
+    flow = seq.get_flow_operator(scale=0.5, decay=0.25)
+    cur = np.full((16, 12), 0.4)
+    for k in range(4):                                                   # the fourth call wraps around to t = 0
+        want = 0.5 * R.perlin3_field(16, 12, [0.0, 0.25, 0.5, 0.0][k], 8, 3) + 0.75 * cur
+        cur = flow(cur)
+        assert np.array_equal(cur, want)
+
+
 def test_step_substep_order_is_observable_through_the_food_flow():
     """core/env.py:101-131: move → deposit + layout → feed → lifecycle → food flow → diffuse/decay.  With a food-flow
     operator that is not the identity the order shows: feeding sees the food BEFORE the flow, the flow acts on the
