@@ -26,9 +26,14 @@ def _state(W, H, N, K, seed):
     return medium, agents, dir0
 
 
-def _wave_dynamics(die_amd, W, H):
-    """'dyn-pred' of examples/simple_agents.py:95-100: food flows in running waves."""
-    return die_amd.Dynamics(op_food_flow=die_amd.WaveSequence((W, H), dt=0.01).get_flow_operator(scale=0.5, decay=0.5))
+def _wave_dynamics(die_amd, W, H, kind=True):
+    """'dyn-pred' of examples/simple_agents.py:95-100: food flows in running waves (`kind='perlin'`: in drifting Perlin noise,
+    core/data_init.py:55-69)."""
+    if kind == 'perlin':
+        seq = die_amd.PerlinNoiseSequence((W, H), dt=0.05, octaves=6, seed=5)
+    else:
+        seq = die_amd.WaveSequence((W, H), dt=0.01)
+    return die_amd.Dynamics(op_food_flow=seq.get_flow_operator(scale=0.5, decay=0.5))
 
 
 def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
@@ -55,7 +60,7 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         from die_amd.dist import DistEnv
         medium, agents, dir0 = _state(W, H, N, K, 5)
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
-        env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H) if wave else None, probe_reach=11,
+        env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H, wave) if wave else None, probe_reach=11,
                                         device=dev, sort_every=sort_every,
                                         overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
                                         field_dtype=torch.float16 if f16 else torch.float32)
@@ -116,7 +121,7 @@ def test_decomposed_run_equals_single_device_run(tmp_path, grid, sort_every, ove
 def _single_device_run(W, H, N, K, steps, wave=False, f16=False):
     import die_amd
     medium, agents, dir0 = _state(W, H, N, K, 5)
-    env = die_amd.Env.from_numpy(medium, agents, _wave_dynamics(die_amd, W, H) if wave else None, sort_every=0,
+    env = die_amd.Env.from_numpy(medium, agents, _wave_dynamics(die_amd, W, H, wave) if wave else None, sort_every=0,
                                  field_dtype=torch.float16 if f16 else torch.float32)
     agent = die_amd.PhysarumAgent(max_agents=N, seed=9, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
     agent.set_state(dir0)
@@ -131,7 +136,7 @@ def _single_device_run(W, H, N, K, steps, wave=False, f16=False):
 @pytest.mark.parametrize('grid,sort_every,refresh_every,backend,wave', [
     ((1, 2), 0, 2, 'gloo', False), ((2, 1), 3, 3, 'gloo', False), ((2, 2), 2, 2, 'gloo', False), ((2, 2), 0, 3, 'gloo', True),
     ((2, 2), 4, 1, 'gloo', False), ((1, 1), 2, 4, 'nccl', True), ((2, 2), 2, 2, 'gloo-torch-refresh', False),
-    ((1, 2), 3, 3, 'gloo-f16', False)])
+    ((1, 2), 3, 3, 'gloo-f16', False), ((2, 2), 2, 3, 'gloo', 'perlin')])
 def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, refresh_every, backend, wave):
     """Communication-avoiding mode: ghosts of the neighbours' border agents are stepped locally, nothing crosses
     ranks for `refresh_every` steps; world state and rewards must equal the single-device run bit for bit
