@@ -15,8 +15,7 @@ st = env._pic.error[2:].cpu().numpy().view(np.uint64).reshape(-1, 8)[:, :6].asty
 d = np.diff(st, axis=1)
 names = ['tile loads issued, per-tile words, ranges', 'agent streams issued, tiles committed to LDS', 'filter arrivals + barrier', 'chunk loop (wave 0)', 'wave sum + final barrier']
 tot = st[:, 5] - st[:, 0]
-print('s_memtime ticks (100 MHz => 10 ns each) per tile workgroup, mean / median / p95')
+print('s_memtime ticks (shader clock) per tile workgroup, mean / median / p95')
 for i, n in enumerate(names):
     print(f'  {n:46s} {d[:, i].mean():8.1f} {np.median(d[:, i]):8.1f} {np.percentile(d[:, i], 95):8.1f}   {100 * d[:, i].sum() / tot.sum():5.1f} %')
 print(f'  {"total":46s} {tot.mean():8.1f} {np.median(tot):8.1f} {np.percentile(tot, 95):8.1f}')
-print('kernel span (first start .. last end):', st[:, 5].max() - st[:, 0].min())
