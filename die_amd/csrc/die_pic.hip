@@ -441,15 +441,31 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
     for (int i = threadIdx.x; i < TX * TY / 2; i += PIC_K2_BLOCK) ((ulonglong2*)s_claim)[i] = make_ulonglong2(0ull, 0ull);
     pic_ranges_finish(mt, s_base, s_pre);                          // (its barriers also cover the zeroing)
     const uint32_t total = s_pre[9], own = s_pre[1];
-    for (uint32_t idx = threadIdx.x; idx < total; idx += PIC_K2_BLOCK) {
-        int r = 0;
-        while (idx >= s_pre[r + 1]) ++r;
-        const uint32_t j = s_base[r] + (idx - s_pre[r]);
-        const uint32_t X = p.out.x[j], Y = p.out.y[j], sid = p.out.slot[j], db = __float_as_uint(p.dep[j]);
-        const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
-        if (idx >= own && ((cx >> XS) != tx || (cy >> YS) != ty)) continue;
-        // highest slot on the cell wins (core/env.py:211), its deposit rides in the low word
-        atomicMax(&s_claim[(cx & (TX - 1)) * TY + (cy & (TY - 1))], ((unsigned long long)(sid + 1u) << 32) | (unsigned long long)db);
+    // two agents per thread and trip (≈ 615 stand on a 64×64 tile, 512 threads): their eight loads are in flight together
+    // instead of one round trip after the other
+    for (uint32_t i0 = threadIdx.x; i0 < total; i0 += 2 * PIC_K2_BLOCK) {
+        uint32_t X[2], Y[2], sid[2], db[2];
+        bool has[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t idx = i0 + u * PIC_K2_BLOCK;
+            has[u] = idx < total;
+            if (has[u]) {
+                int r = 0;
+                while (idx >= s_pre[r + 1]) ++r;
+                const uint32_t j = s_base[r] + (idx - s_pre[r]);
+                X[u] = p.out.x[j]; Y[u] = p.out.y[j]; sid[u] = p.out.slot[j]; db[u] = __float_as_uint(p.dep[j]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (!has[u]) continue;
+            const uint32_t idx = i0 + u * PIC_K2_BLOCK;
+            const int cx = die_cell((int64_t)X[u], p.g.gW), cy = die_cell((int64_t)Y[u], p.g.gH);
+            if (idx >= own && ((cx >> XS) != tx || (cy >> YS) != ty)) continue;
+            // highest slot on the cell wins (core/env.py:211), its deposit rides in the low word
+            atomicMax(&s_claim[(cx & (TX - 1)) * TY + (cy & (TY - 1))], ((unsigned long long)(sid[u] + 1u) << 32) | (unsigned long long)db[u]);
+        }
     }
     __syncthreads();
     static_assert(TY % 4 == 0, "16-byte stores");
