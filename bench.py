@@ -71,6 +71,7 @@ def parse():
     p.add_argument('--no-pic', action='store_true', help='classic step (claim plane + bucket sort) instead of the tile-binned one')
     p.add_argument('--pic-tile', default='', help='tuning: log2 tile shape of the tile-binned step, e.g. 6,6')
     p.add_argument('--pic-threads', type=int, default=0, help='tuning: workgroup size of the tile-binned agent kernel')
+    p.add_argument('--pic-three-launches', action='store_true', help='tile-binned step in its three-launch form (K2 + deposit plane + sweep) instead of one field kernel per tile')
     p.add_argument('--eager-actions', action='store_true', help='tile-binned step: store the action of every step (default: it stays in registers and is re-derived when read)')
     p.add_argument('--replicas', type=int, default=0, help='batched env replicas on one GPU (BASELINE configs[4]): R worlds of --size in one launch pair; value = replica-steps/s')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
@@ -93,6 +94,8 @@ def algorithmic_bytes(C, K, action_stored=True):
         'k_pic_forward_move': (56 + act) * K,     # state R+W 32, action W 12 (if stored), 6 gathers 24
         'k_pic_resolve': 12 * K,          # the ownership claim 4 + food RMW of the occupied cell 8
         'k_diffuse_rows_dep': 8 * C + 8 * K,      # chem R + W per cell; per agent chem RMW 8
+        # two-launch form: K2 and the sweep in one kernel per tile (the sum of the two lines above)
+        'k_pic_resolve_diffuse': 8 * C + 20 * K,
         'step': 12 * C + (92 + act) * K,
     }
 
@@ -101,12 +104,13 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.js
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false, true>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
-             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
+             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false, true>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
+             'k_pic_resolve_diffuse': 'void k_pic_resolve_diffuse<float, 6, 6, 2>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
-WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve')
+WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve', 'k_pic_resolve_diffuse')
 # bytes per agent that the tile-binned kernels read as 4-byte-per-lane streams (counted in full by FETCH_SIZE; only the
 # 16-byte-per-lane tile loads are under-counted): K1 x, y, slot, heading hi/lo, agent_food; K2 x, y, slot, deposit
-NARROW_STREAM_BYTES_PER_AGENT = {'k_pic_forward_move': 24, 'k_pic_resolve': 16}
+NARROW_STREAM_BYTES_PER_AGENT = {'k_pic_forward_move': 24, 'k_pic_resolve': 16, 'k_pic_resolve_diffuse': 16}
 
 
 def pmc_traffic(kernel, K=0):
@@ -158,21 +162,23 @@ def time_kernels(env, agent, reps):
     if env._pic is not None and env._pic.held is not None and env._pic.held[0] is env.agents.x:
         # tile-binned step: REAL steps whose three launches are issued one call each (die_pic.stages) with a HIP event
         # between them — every kernel meets the cache state it meets in the timed loop
-        names = ('k_pic_forward_move', 'k_pic_resolve', 'k_diffuse_rows_dep')
+        two = env._pic.two_launch(env, agent)
+        names = ('k_pic_forward_move', 'k_pic_resolve_diffuse') if two else ('k_pic_forward_move', 'k_pic_resolve', 'k_diffuse_rows_dep')
+        nk = len(names)
         n = max(reps, 20)
-        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(n)]
+        evs = [[torch.cuda.Event(enable_timing=True) for _ in range(nk + 2)] for _ in range(n)]
         o = env._get_current_obs
         for e in evs:
             env._pic_events = e
             o, *_ = env.step(agent.forward(o))
-            e[4].record()                 # nothing was enqueued since e[3]: what an empty event interval costs
+            e[nk + 1].record()            # nothing was enqueued since e[nk]: what an empty event interval costs
         env._pic_events = None
         torch.cuda.synchronize()
         for k, name in enumerate(names):
             out[name] = sum(e[k].elapsed_time(e[k + 1]) for e in evs) / n * 1e3
-        # an interval between two events contains the kernel AND the completion / dispatch gap around it (the three
+        # an interval between two events contains the kernel AND the completion / dispatch gap around it (the
         # intervals add up to the step): rocprofv3's kernel durations are shorter by about this much per launch
-        out['_empty_event_interval'] = sum(e[3].elapsed_time(e[4]) for e in evs) / n * 1e3
+        out['_empty_event_interval'] = sum(e[nk].elapsed_time(e[nk + 1]) for e in evs) / n * 1e3
         return out
 
     env.sort_agents()                     # the timed loop re-sorts every few steps: measure in that regime
@@ -371,6 +377,7 @@ def main():
         if args.pic_tile:
             env._pic_tile = tuple(int(v) for v in args.pic_tile.split(','))
         env._pic_k1_threads = args.pic_threads
+        env._pic_fused = not args.pic_three_launches
 
     def barrier():
         if dist_on:
@@ -445,7 +452,7 @@ def main():
         binned = getattr(env, '_pic', None) is not None and env._pic.held is not None
         lazy_action = binned and env._pic.lazy_actions
         B = algorithmic_bytes(C, K, action_stored=not lazy_action)
-        line['config']['step_kind'] = ('tile-binned' if binned else 'classic') + \
+        line['config']['step_kind'] = (('tile-binned, ' + ('two' if env._pic.two_launch(env, agent) else 'three') + ' launches') if binned else 'classic') + \
             (', action kept in registers (re-derived bit-identically when read; --eager-actions stores it every step)' if lazy_action else '')
         if lazy_action:
             # the same loop with the action of every step stored, as round 1 did: reported beside the headline, not instead of it

@@ -99,7 +99,6 @@ class NeuralAutomataAgent(TorchAgent):
         self.action_coefs = (float(scale), float(scale), float(deposit))
         self._sense_output: Optional[th.Tensor] = None         # (3, W, H) on the device after the first forward
         self._planes = {}                                      # device scratch by (W, H, device): ping-pong plane sets
-        self._weights = None                                   # (versions, [device tensors]) cache of the uploaded kernels
 
     @property
     def model(self) -> ConvolutionModel:
@@ -115,11 +114,9 @@ class NeuralAutomataAgent(TorchAgent):
         for k in layers:
             if k.padding_mode != 'circular':
                 raise NotImplementedError(f"boundary={k.padding_mode!r}: the device path implements 'circular' padding")
-        versions = tuple((k.weight._version, k.weight.data_ptr()) for k in layers)
-        if self._weights is None or self._weights[0] != versions or self._weights[1][0].device != device:
-            ws = [k.weight.detach().to(device=device, dtype=th.float32).contiguous() for k in layers]
-            self._weights = (versions, ws)
-        return self._weights[1]
+        # uploaded on every call (≈ 100 floats): in-place writes through `param.data` — how evotorch's fill_parameters
+        # loads each candidate — change neither `_version` nor `data_ptr()`, so no cheap key tells a stale copy apart
+        return [k.weight.detach().to(device=device, dtype=th.float32).contiguous() for k in layers]
 
     def _scratch(self, W, H, device, n_sets):
         key = (W, H, str(device))

@@ -581,6 +581,8 @@ static int gaussian_taps(float sigma, double* w) {
     return R;
 }
 
+int die_gaussian_taps(float sigma, double* w) { return gaussian_taps(sigma, w); }      // (die_pic.hip)
+
 template <typename T>
 static int launch_diffuse(const DiffuseArgs& a, int R, hipStream_t s) {
     dim3 grid((a.H + DIF_TY - 1) / DIF_TY, (a.W + DIF_TX - 1) / DIF_TX);
@@ -877,6 +879,8 @@ static bool fused_step_applies(const die_medium* m, const die_dynamics* d) {
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
     return m->gW <= 0 && d->diffuse_mode == DIE_DIFFUSE_WRAP && rows_kernel_applies(m->W, m->H, R) && R >= 1 && !d->staged;
 }
+
+bool fused_step_shape_ok(const die_medium* m, const die_dynamics* d) { return fused_step_applies(m, d); }      // (die_pic.hip)
 
 // everything of die_env_step after the claims are in place (fused path)
 static int env_step_tail(const die_medium* m, const die_agents* a, const die_action* act, const die_dynamics* d,

@@ -88,7 +88,11 @@ struct PicArgs {
     int boundary, cost;
     long long* part_gain;           // one fixed-point partial per tile
     uint32_t* error;                // device word, sticky: bit 0 segment bookkeeping broken, bit 1 an agent jumped further than a
-                                    // tile
+                                    // tile, bit 2 a rim record left the 3×3 neighbourhood
+    // two-launch form (die_pic.code != NULL): per agent of layout `out` one byte for k_pic_resolve_diffuse — where its new
+    // tile lies relative to the tile whose segment holds it, and which borders of the new tile it stands within R cells of
+    uint8_t* code;                  // ((ddx + 1)·3 + ddy + 1)·9 + (ex + 1)·3 + ey + 1
+    int rim_r;                      // gaussian radius R = width of the rim
 };
 
 __device__ __forceinline__ int pic_tile_of(const PicArgs& p, uint32_t X, uint32_t Y) {
@@ -177,7 +181,7 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_K1_MINW
 #define PIC_K1_MINW 6
 #endif
-template <typename T, int KIND, bool STAGE, bool ACT>
+template <typename T, int KIND, bool STAGE, bool ACT, bool RIM>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
@@ -293,6 +297,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0;
             float af = 0.f, dep = 0.f;
             double hd = 0.0;
+            uint32_t code = 0;
             if (act) {
                 const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
                 if (first && idx < n_own) {
@@ -331,13 +336,22 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 gsum += die_fix(gained);
                 hd = o.heading;
                 dep = o.dep;
+                int ddx = 0, ddy = 0;
                 if (!stay) {
-                    int ddx = ntx_ - tx, ddy = nty_ - ty;
+                    ddx = ntx_ - tx; ddy = nty_ - ty;
                     ddx = ddx > 1 ? ddx - p.ntx : (ddx < -1 ? ddx + p.ntx : ddx);
                     ddy = ddy > 1 ? ddy - p.nty : (ddy < -1 ? ddy + p.nty : ddy);
-                    if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) atomicOr(p.error, 2u);
+                    if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) { atomicOr(p.error, 2u); ddx = ddy = 0; }
                     else atomicAdd(&s_inc[(ddx + 1) * 3 + ddy + 1], 1u);   // one global atomic per neighbour at the end (2.5 M
                 }                                                          // agents: 11 µs of contended global atomics otherwise)
+                if (RIM) {
+                    // the field kernel of a tile diffuses that tile's cells and so needs the deposits on the R cells around it
+                    // too: it finds them among the agents of the 9 segments around it by this byte — where the agent's new tile
+                    // lies (dd), and which of that tile's borders it stands within R cells of (e) — without their coordinates
+                    const int lx = cx & (TX - 1), ly = cy & (TY - 1), Rr = p.rim_r;
+                    const int ex = lx < Rr ? 0 : (lx >= TX - Rr ? 2 : 1), ey = ly < Rr ? 0 : (ly >= TY - Rr ? 2 : 1);
+                    code = (uint32_t)(((ddx + 1) * 3 + ddy + 1) * 9 + ex * 3 + ey);
+                }
             }
             // positions: stayers fill the segment from the front, leavers from the back; one LDS atomic per wave and class
             const unsigned long long m_stay = __ballot(act && stay), m_leave = __ballot(act && !stay);
@@ -359,6 +373,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     p.out.hhi[q] = (uint32_t)__double2hiint(hd);
                     p.out.hlo[q] = (uint32_t)__double2loint(hd);
                     p.dep[q] = dep;
+                    if (RIM) p.code[q] = (uint8_t)code;
                 } else {
                     atomicOr(p.error, 1u);
                 }
@@ -489,6 +504,322 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
     }
 }
 
+// ---- two-launch form: K2 and the field sweep in one kernel per tile ------------------------------------------------------
+// k_pic_resolve_diffuse, one workgroup per tile d over a window of the tile ± R cells (R = gaussian radius):
+//   claims    32-bit LDS atomicMax of slot + 1 per window cell — "the highest alive slot on a cell writes" (core/env.py:211) —
+//             for the agents standing on d (its stayers + the neighbours' leavers that landed on it, as in k_pic_resolve) AND
+//             for the agents standing within R cells outside d (their deposits reach d's cells through the gaussian).  Both
+//             kinds are found among the agents of the 9 segments around d by the byte the agent kernel left per agent (where
+//             its new tile lies relative to its segment's tile, which borders of the new tile it stands within R cells of):
+//             four bytes per load, no coordinates touched unless the agent matters here — no list, no capacity;
+//   deposit   every such agent looks its cell up again; the winner adds its deposit to the chem window staged in LDS
+//             (chem[c] = chem[c] + deposit, core/env.py:211: one writer per cell, no atomic);
+//   feeding   food −= rate·food on d's occupied cells (core/env.py:222-228), 16-byte read-modify-write of the groups that hold one;
+//   diffusion the separable gaussian over the window: axis 0 first like scipy (symmetric pairs summed first, outermost pair
+//             first: the arithmetic of k_diffuse_rows, die_env.hip, bit for bit), × (1 − decay) (core/env.py:136-145), 16-byte
+//             stores of d's cells of chem_next.
+// No deposit plane: the 67 MB written by K2 and read back (with halo rows) by the sweep at 4096² are gone, and so is a
+// launch.  Two extra workgroups: the scan of the next step's segment sizes (as in k_pic_resolve) and the reduction of the
+// agent kernel's reward partials (as in the sweep).
+struct KbArgs {
+    const void* chem;
+    void* chem_next;
+    int food_infinite;
+    float keep;
+    float w[2 * 4 + 1];
+    die_step_result* result;
+    long long alive_const;
+};
+
+template <int XS, int YS> struct KbShape { static constexpr int BLOCK = ((1 << XS) * (1 << YS) >= 4096) ? 512 : 256; };
+
+template <typename T, int XS, int YS, int R>
+__global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffuse(PicArgs p, KbArgs a) {
+    constexpr int TX = 1 << XS, TY = 1 << YS, BLOCK = KbShape<XS, YS>::BLOCK;
+    constexpr int A = 16 / (int)sizeof(T);                 // cells per 16-byte vector
+    constexpr int WR = TX + 2 * R, WC = TY + 2 * R;        // the window
+    constexpr int CP = TY + 2 * A, NV = CP / A;            // staged columns [y0 − A, y0 + TY + A): whole vectors; vectors per row
+    static_assert(R >= 1 && R <= 4 && R <= A, "the rim lies inside one vector beside the tile");
+    extern __shared__ __align__(16) unsigned char kb_smem[];
+    float* s_chem = (float*)kb_smem;                        // WR × CP, window cell (r, c) at r·CP + c − R + A
+    uint32_t* s_claim = (uint32_t*)(s_chem + WR * CP);      // WR × WC; after the deposits: s_tmp, TX × CP (the x pass)
+    float* s_tmp = (float*)s_claim;
+    // the 9 segments around d in layout `out`: [0] d's own (its stayers are taken directly, only its leavers are scanned),
+    // [1..8] the ring (scanned whole); scanned in 4-byte words of codes
+    __shared__ uint32_t s_lo[9], s_hi[9], s_w0[9], s_wpre[10];   // agent index range to scan; its first code word; prefix of the word counts
+    __shared__ uint32_t s_own[2];                           // d's stayers: first index, count
+    __shared__ uint32_t s_nhit;                             // hits of the scan
+    const int NT = p.ntx * p.nty;
+    if ((int)blockIdx.y == p.ntx) {                         // the extra grid row
+        if (blockIdx.x == 0) {                              // sizes and offsets of the layout the NEXT step writes
+            uint32_t* s_sum = (uint32_t*)kb_smem;           // BLOCK words (the window arrays are not used by this workgroup)
+            const int per = (NT + BLOCK - 1) / BLOCK;
+            const int lo = threadIdx.x * per, hi = min(lo + per, NT);
+            uint32_t sum = 0;
+            for (int t = lo; t < hi; ++t) sum += p.out.s[t] + p.out.inc[t];
+            s_sum[threadIdx.x] = sum;
+            __syncthreads();
+            for (int o = 1; o < BLOCK; o <<= 1) {
+                const uint32_t v = (int)threadIdx.x >= o ? s_sum[threadIdx.x - o] : 0u;
+                __syncthreads();
+                s_sum[threadIdx.x] += v;
+                __syncthreads();
+            }
+            uint32_t run = s_sum[threadIdx.x] - sum;
+            for (int t = lo; t < hi; ++t) {
+                const uint32_t c = p.out.s[t] + p.out.inc[t];
+                p.in.off[t] = run;
+                p.in.n[t] = c;
+                p.in.inc[t] = 0;
+                run += c;
+            }
+        } else if (blockIdx.x == 1 && a.result) {           // reward: the agent kernel's per-tile partials (integers: any order)
+            long long* s_g = (long long*)kb_smem;           // BLOCK 64-bit words
+            long long t = 0;
+            for (int base = threadIdx.x; base < NT; base += BLOCK * 8) {
+                long long v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int i = base + q * BLOCK; v[q] = i < NT ? p.part_gain[i] : 0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t += v[q];
+            }
+            s_g[threadIdx.x] = t;
+            __syncthreads();
+            for (int o = BLOCK / 2; o > 0; o >>= 1) {
+                if ((int)threadIdx.x < o) s_g[threadIdx.x] += s_g[threadIdx.x + o];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) { a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = a.alive_const; }
+        }
+        return;
+    }
+    const int tx = blockIdx.y, ty = blockIdx.x, x0 = tx << XS, y0 = ty << YS;
+    const int W = p.g.W, H = p.g.H;
+    const T* chem = (const T*)a.chem;
+    T* food = (T*)p.food;
+    // 1. everything that depends on the tile index only goes out first: the per-tile words, the chem window, the food tile
+    uint32_t m_o = 0, m_s = 0, m_n = 0;
+    if (threadIdx.x < 9) {
+        const int q = threadIdx.x, k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
+        const int t = pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty);
+        m_o = p.out.off[t]; m_s = p.out.s[t]; m_n = p.out.n[t];
+        if (m_s > m_n) m_s = m_n = 0;                       // (broken bookkeeping — never loop over garbage)
+    }
+    constexpr int NCV = (WR * NV + BLOCK - 1) / BLOCK;
+    static_assert(NCV <= 3, "three window vectors per thread at most");       // (named registers: as an array they went to scratch)
+    auto window_load = [&](int q) {
+        const int i = min((int)threadIdx.x + q * BLOCK, WR * NV - 1);       // (surplus threads load the last vector again: no branch)
+        const int r = i / NV, v = i - r * NV;
+        return *(const uint4*)(chem + ((int64_t)pic_wrap(x0 - R + r, W) * H + pic_wrap(y0 - A + v * A, H)));
+    };
+    uint4 cv0 = window_load(0), cv1 = cv0, cv2 = cv0;
+    if constexpr (NCV > 1) cv1 = window_load(1);
+    if constexpr (NCV > 2) cv2 = window_load(2);
+    constexpr int FG = (TX * TY / 4 + BLOCK - 1) / BLOCK;
+    float fd[FG][4];
+    if (!a.food_infinite) {
+#pragma unroll
+        for (int q = 0; q < FG; ++q) {
+            const int i = ((int)threadIdx.x + q * BLOCK) * 4;
+            if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
+        }
+    }
+    for (int i = threadIdx.x; i < WR * WC / 4; i += BLOCK) ((uint4*)s_claim)[i] = make_uint4(0u, 0u, 0u, 0u);
+    static_assert((WR * WC) % 4 == 0, "16-byte zeroing");
+    if (threadIdx.x < 9) {
+        const uint32_t lo = threadIdx.x == 0 ? m_o + m_s : m_o, hi = m_o + m_n;
+        s_lo[threadIdx.x] = lo; s_hi[threadIdx.x] = hi; s_w0[threadIdx.x] = lo >> 2;
+        if (threadIdx.x == 0) { s_own[0] = m_o; s_own[1] = m_s; s_nhit = 0; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int q = 0; q < 9; ++q) { s_wpre[q] = run; run += s_hi[q] > s_lo[q] ? ((s_hi[q] - 1) >> 2) - (s_lo[q] >> 2) + 1 : 0u; }
+        s_wpre[9] = run;
+    }
+    __syncthreads();
+    const uint32_t own0 = s_own[0], nown = s_own[1], nwords = s_wpre[9];
+    // window cell of an agent standing on the tile at (ux, uy) tiles from d; 0xFFFFFFFF: outside the window
+    auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
+        const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
+        const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
+        return (r >= 0 && r < WR && c >= 0 && c < WC) ? (uint32_t)(r * WC + c) : 0xFFFFFFFFu;
+    };
+    // the scanned segments: every agent whose byte says "stands on d, or within R cells of d" → hit(index, (ux + 1)·3 + uy + 1)
+    auto scan = [&](auto&& hit) {
+        for (uint32_t v = threadIdx.x; v < nwords; v += BLOCK) {
+            int q = 0;
+            while (v >= s_wpre[q + 1]) ++q;
+            const uint32_t wi = s_w0[q] + (v - s_wpre[q]), lo = s_lo[q], hi = s_hi[q];
+            const uint32_t c4 = ((const uint32_t*)p.code)[wi];
+            const int k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q), kx = k3 / 3 - 1, ky = k3 % 3 - 1;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t j = wi * 4 + b, c = (c4 >> (8 * b)) & 255u;
+                if (j < lo || j >= hi || c >= 81u) continue;
+                const int dd = (int)c / 9, e = (int)c - dd * 9;
+                int ux = kx + dd / 3 - 1, uy = ky + dd % 3 - 1;              // the agent's tile relative to d, in [−2, 2] …
+                ux += ux < 0 ? p.ntx : 0; ux -= 2 * ux > p.ntx ? p.ntx : 0;   // … as the nearest periodic image (3 tiles: 2 ≡ −1)
+                uy += uy < 0 ? p.nty : 0; uy -= 2 * uy > p.nty ? p.nty : 0;
+                const int sx = e / 3 - 1, sy = e % 3 - 1;                    // which neighbours of its tile it stands close to
+                if ((ux == 0 || ux == -sx) && (uy == 0 || uy == -sy)) hit(j, (uint32_t)((ux + 1) * 3 + uy + 1));
+            }
+        }
+    };
+    // 2. claims.  The tile's own stayers two per thread and trip, their loads in flight together; the scan only LISTS its
+    //    hits (in LDS, where the chem window will be: it is committed after the claims) so that their coordinates are then
+    //    fetched two per thread with all loads in flight too — fetched at the hit, every hit of a wave was a round trip of
+    //    its own (147 µs against 63).  The first trip of each kind stays in registers for the deposit pass.
+    constexpr uint32_t LIST_CAP = 2 * BLOCK;                 // more hits than that (a crowd): the slow way, hit by hit
+    uint32_t* s_list = (uint32_t*)s_chem;                    // agent index | tile code << 28
+    static_assert(LIST_CAP <= WR * CP, "the list lives where the chem window will be");
+    const bool packable = a.alive_const < (1ll << 28);      // (more agents than that: always the slow way)
+    uint32_t cw[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cs[4] = {0u, 0u, 0u, 0u}, cd[4] = {0u, 0u, 0u, 0u};
+    uint32_t X[2] = {0u, 0u}, Y[2] = {0u, 0u};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const uint32_t i = threadIdx.x + u * BLOCK;
+        if (i < nown) { const uint32_t j = own0 + i; X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[u] = p.out.slot[j] + 1u; cd[u] = __float_as_uint(p.dep[j]); }
+    }
+    scan([&](uint32_t j, uint32_t ucode) {
+        const uint32_t at = atomicAdd(&s_nhit, 1u);
+        if (at < LIST_CAP && packable) s_list[at] = j | (ucode << 28);
+    });
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        if (threadIdx.x + u * BLOCK < nown) { cw[u] = window_cell(X[u], Y[u], 0, 0); if (cw[u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[u]], cs[u]); }
+    }
+    for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
+        const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
+        if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_], p.out.slot[j] + 1u);
+    }
+    __syncthreads();
+    const uint32_t nhit = s_nhit;
+    const bool crowd = nhit > LIST_CAP || !packable;
+    if (!crowd) {
+        uint32_t uc[2] = {4u, 4u};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t i = threadIdx.x + u * BLOCK;
+            if (i < nhit) {
+                const uint32_t h = s_list[i], j = h & 0x0FFFFFFFu;
+                X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[2 + u] = p.out.slot[j] + 1u; cd[2 + u] = __float_as_uint(p.dep[j]); uc[u] = h >> 28;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (threadIdx.x + u * BLOCK < nhit) {
+                cw[2 + u] = window_cell(X[u], Y[u], (int)uc[u] / 3 - 1, (int)uc[u] % 3 - 1);
+                if (cw[2 + u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[2 + u]], cs[2 + u]);
+            }
+        }
+        __syncthreads();                                    // every list entry has been read: the window may overwrite it
+    } else {
+        scan([&](uint32_t j, uint32_t ucode) {
+            const uint32_t w_ = window_cell(p.out.x[j], p.out.y[j], (int)ucode / 3 - 1, (int)ucode % 3 - 1);
+            if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_], p.out.slot[j] + 1u);
+        });
+    }
+    // 3. the chem window into LDS (as float)
+    auto window_commit = [&](int q, const uint4 u) {
+        const int i = (int)threadIdx.x + q * BLOCK;
+        if (i >= WR * NV) return;
+        const int r = i / NV, v = i - r * NV;
+        float* dst = s_chem + r * CP + v * A;
+        if constexpr (sizeof(T) == 4) {
+            *(uint4*)dst = u;
+        } else {
+            auto lo = [](uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu))); };
+            auto hi = [](uint32_t w) { return __half2float(__ushort_as_half((unsigned short)(w >> 16))); };
+            *(float4*)dst = make_float4(lo(u.x), hi(u.x), lo(u.y), hi(u.y));
+            *(float4*)(dst + 4) = make_float4(lo(u.z), hi(u.z), lo(u.w), hi(u.w));
+        }
+    };
+    window_commit(0, cv0);
+    if constexpr (NCV > 1) window_commit(1, cv1);
+    if constexpr (NCV > 2) window_commit(2, cv2);
+    __syncthreads();
+    // 4. deposits of the winners; feeding of the tile's occupied cells
+    auto deposit = [&](uint32_t widx, uint32_t s1, uint32_t db) {
+        if (widx == 0xFFFFFFFFu || s_claim[widx] != s1) return;
+        const uint32_t r = widx / WC, c = widx - r * WC;
+        float* q = &s_chem[r * CP + c - R + A];
+        *q = die_as_stored<T>(*q + __uint_as_float(db));
+    };
+    deposit(cw[0], cs[0], cd[0]);
+    deposit(cw[1], cs[1], cd[1]);
+    for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
+        const uint32_t j = own0 + i;
+        deposit(window_cell(p.out.x[j], p.out.y[j], 0, 0), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
+    }
+    if (!crowd) {
+        deposit(cw[2], cs[2], cd[2]);
+        deposit(cw[3], cs[3], cd[3]);
+    } else {                                                // a crowd: everybody scans again
+        scan([&](uint32_t j, uint32_t ucode) {
+            deposit(window_cell(p.out.x[j], p.out.y[j], (int)ucode / 3 - 1, (int)ucode % 3 - 1), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
+        });
+    }
+    if (!a.food_infinite) {
+#pragma unroll
+        for (int g = 0; g < FG; ++g) {
+            const int i = ((int)threadIdx.x + g * BLOCK) * 4;
+            if (i >= TX * TY) break;
+            const int row = i / TY, col = i - row * TY;
+            const uint32_t* c = &s_claim[(row + R) * WC + col + R];
+            const bool occ[4] = {c[0] != 0u, c[1] != 0u, c[2] != 0u, c[3] != 0u};
+            if (occ[0] || occ[1] || occ[2] || occ[3]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
+                Vec4<T>::st(food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
+            }
+        }
+    }
+    __syncthreads();
+    // 5. x pass (axis 0): column c of the window, RB output rows per item, the 2R + 1 rows of the stencil in registers
+    constexpr int RB = TX >= 64 ? 16 : 8;
+    for (int item = threadIdx.x; item < WC * (TX / RB); item += BLOCK) {
+        const int rb = item / WC, c = item - rb * WC;
+        const float* src = s_chem + (rb * RB) * CP + c - R + A;
+        float win[2 * R + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * R; ++k) win[k + 1] = src[k * CP];
+#pragma unroll
+        for (int o = 0; o < RB; ++o) {
+#pragma unroll
+            for (int k = 0; k < 2 * R; ++k) win[k] = win[k + 1];
+            win[2 * R] = src[(o + 2 * R) * CP];
+            float t = a.w[R] * win[R];                                       // centre, then symmetric pairs from the outermost
+#pragma unroll                                                               // inwards (k_diffuse_rows: identical sums)
+            for (int k = 0; k < R; ++k) t += (win[k] + win[2 * R - k]) * a.w[k];
+            s_tmp[(rb * RB + o) * CP + c - R + A] = t;
+        }
+    }
+    __syncthreads();
+    // 6. y pass (axis 1), decay, 16-byte (fp16: 8-byte) stores of the tile's cells
+    T* dst = (T*)a.chem_next;
+    constexpr int LO = A - R, LA = LO & ~3, NX = (LO - LA + 4 + 2 * R + 3) / 4;    // aligned float4 reads around the 4 cells
+    for (int item = threadIdx.x; item < TX * (TY / 4); item += BLOCK) {
+        const int row = item / (TY / 4), cg = item - row * (TY / 4);
+        float xf[NX * 4];
+#pragma unroll
+        for (int q = 0; q < NX; ++q) {
+            const float4 v = *(const float4*)&s_tmp[row * CP + LA + 4 * cg + 4 * q];
+            xf[4 * q] = v.x; xf[4 * q + 1] = v.y; xf[4 * q + 2] = v.z; xf[4 * q + 3] = v.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = LO - LA + R + j;                                  // this cell in xf
+            float t = a.w[R] * xf[cc];
+#pragma unroll
+            for (int k = 0; k < R; ++k) t += (xf[cc - R + k] + xf[cc + R - k]) * a.w[k];
+            o[j] = t * a.keep;
+        }
+        Vec4<T>::st(dst + (int64_t)(x0 + row) * H + y0 + 4 * cg, o);
+    }
+}
+
 // ---- (re)binning: any order of the agent arrays → a layout with every agent a stayer ---------------------------
 struct PicBinArgs {
     die_geo g;
@@ -572,6 +903,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_mark_owner(die_geo g, int64_t N, 
 // ---- host side ----------------------------------------------------------------------------------------------------
 int die_sweep_dep_plane(const die_medium* m, const die_dynamics* d, const float* dep_plane, const long long* part_gain, int n_part,
                         die_step_result* result, long long alive_const, void* stream);   // die_env.hip
+bool fused_step_shape_ok(const die_medium* m, const die_dynamics* d);                     // die_env.hip: periodic planes, H % 4 == 0, radius 1..4
 
 static bool pic_shape_ok(int xs, int ys) { return (xs == 6 && ys == 6) || (xs == 5 && ys == 7) || (xs == 5 && ys == 6) || (xs == 4 && ys == 5); }
 
@@ -591,7 +923,7 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
         DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
     }
     DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
-    DIE_REQUIRE(p->dep && p->dep_plane && p->part_gain && p->error, "%s: null workspace pointer", who);
+    DIE_REQUIRE(p->dep && p->part_gain && p->error && (p->code || p->dep_plane), "%s: null workspace pointer", who);
     return DIE_OK;
 }
 
@@ -644,12 +976,37 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
     }
 }
 
-template <typename T, bool STAGE>
+template <typename T, bool STAGE, bool RIM>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
     const dim3 grid(k.nty, k.ntx);
-    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true><<<grid, block, lds, s>>>(f, k);
-    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true><<<grid, block, lds, s>>>(f, k);
-    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false><<<grid, block, lds, s>>>(f, k);
+    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM><<<grid, block, lds, s>>>(f, k);
+    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true, RIM><<<grid, block, lds, s>>>(f, k);
+    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false, RIM><<<grid, block, lds, s>>>(f, k);
+}
+
+int die_gaussian_taps(float sigma, double* w);             // die_env.hip (scipy.ndimage._gaussian_kernel1d); w holds 2·8 + 1 taps
+
+template <typename T, int XS, int YS>
+static void launch_resolve_diffuse(const PicArgs& k, const KbArgs& a, int R, hipStream_t s) {
+    constexpr int TX = 1 << XS, TY = 1 << YS, A = 16 / (int)sizeof(T), CP = TY + 2 * A;
+    const int WR = TX + 2 * R, WC = TY + 2 * R;
+    const size_t lds = ((size_t)WR * CP + (size_t)(WR * WC > TX * CP ? WR * WC : TX * CP)) * 4;
+    const dim3 grid(k.nty, k.ntx + 1);
+    constexpr int B = KbShape<XS, YS>::BLOCK;
+    switch (R) {
+        case 1: k_pic_resolve_diffuse<T, XS, YS, 1><<<grid, B, lds, s>>>(k, a); break;
+        case 2: k_pic_resolve_diffuse<T, XS, YS, 2><<<grid, B, lds, s>>>(k, a); break;
+        case 3: k_pic_resolve_diffuse<T, XS, YS, 3><<<grid, B, lds, s>>>(k, a); break;
+        default: k_pic_resolve_diffuse<T, XS, YS, 4><<<grid, B, lds, s>>>(k, a); break;
+    }
+}
+
+template <typename T>
+static void launch_resolve_diffuse_shape(int xs, int ys, const PicArgs& k, const KbArgs& a, int R, hipStream_t s) {
+    if (xs == 6 && ys == 6) launch_resolve_diffuse<T, 6, 6>(k, a, R, s);
+    else if (xs == 5 && ys == 7) launch_resolve_diffuse<T, 5, 7>(k, a, R, s);
+    else if (xs == 5 && ys == 6) launch_resolve_diffuse<T, 5, 6>(k, a, R, s);
+    else launch_resolve_diffuse<T, 4, 5>(k, a, R, s);
 }
 
 extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
@@ -705,18 +1062,48 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
                 "die_pic_forward_env_step: plane too large for the 24-bit index arithmetic of the staging loop");
     const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
+    // two launches (one field kernel per tile, fed by the agent kernel's byte per agent) when the caller gave the byte array and
+    // every agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
+    // FAR border of the tile it walks onto
+    const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
+    const bool two = p->code != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
+                     (int)floorf(reach) + 1 + R <= (TX < TY ? TX : TY);
+    if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
+    k.code = two ? p->code : nullptr; k.rim_r = R;
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
     DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK && (1 << k.cs_c) <= DIE_WAVE && (1 << k.cs_f) <= DIE_WAVE,
                 "die_pic_forward_env_step: k1_threads %d", block);
     if (stages & 1) {
+#define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s); \
+                                       else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s); } while (0)
         if (m->dtype == DIE_F32) {
-            if (stage) launch_forward_move<float, true>(g->kind, f, k, NT, block, lds, s);
-            else launch_forward_move<float, false>(g->kind, f, k, NT, block, 0, s);
+            if (stage) DIE_PIC_K1(float, true, lds);
+            else DIE_PIC_K1(float, false, 0);
         } else {
-            if (stage) launch_forward_move<__half, true>(g->kind, f, k, NT, block, lds, s);
-            else launch_forward_move<__half, false>(g->kind, f, k, NT, block, 0, s);
+            if (stage) DIE_PIC_K1(__half, true, lds);
+            else DIE_PIC_K1(__half, false, 0);
         }
+#undef DIE_PIC_K1
+    }
+    if (two) {
+        if (stages & 2) {                                   // (bit 2 alone: nothing — the sweep is part of this kernel)
+            if (!fused_step_shape_ok(m, d)) {
+                die_set_error("die_pic_forward_env_step: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
+                return DIE_ERR_UNSUPPORTED;
+            }
+            KbArgs a;
+            double wd[2 * 8 + 1];
+            die_gaussian_taps(d->diffuse_sigma, wd);
+            a.chem = m->chem; a.chem_next = m->chem_next;
+            a.food_infinite = d->food_infinite; a.keep = (float)(1.0 - (double)d->rate_decay_chem);
+            for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
+            a.result = result; a.alive_const = p->N;
+            if (m->dtype == DIE_F32) launch_resolve_diffuse_shape<float>(p->tile_xs, p->tile_ys, k, a, R, s);
+            else launch_resolve_diffuse_shape<__half>(p->tile_xs, p->tile_ys, k, a, R, s);
+        }
+        DIE_CHECK_LAUNCH("die_pic_forward_env_step");
+        return DIE_OK;
     }
     if (stages & 2) {
         const bool f32 = m->dtype == DIE_F32;

@@ -133,7 +133,7 @@ class WaveSequence(FieldSequence):
     """core/data_init.py:71-89: running waves + moving islands (`die_food_flow_wave`)."""
 
     def _flow(self, medium: DeviceMedium, t: float, scale: float, decay: float):
-        _lib.check(_lib.lib.die_food_flow_wave(C.byref(medium.c_struct()), t, scale, decay, stream_ptr(medium.device)), 'die_food_flow_wave')
+        _lib.check(_lib.lib.die_food_flow_wave(C.byref(medium.c_struct(need_owner=False)), t, scale, decay, stream_ptr(medium.device)), 'die_food_flow_wave')
 
 
 class PerlinNoiseSequence(FieldSequence):
@@ -146,7 +146,7 @@ class PerlinNoiseSequence(FieldSequence):
         self._octaves, self._seed = int(octaves), int(seed)
 
     def _flow(self, medium: DeviceMedium, t: float, scale: float, decay: float):
-        _lib.check(_lib.lib.die_food_flow_perlin(C.byref(medium.c_struct()), t, self._octaves, scale, decay,
+        _lib.check(_lib.lib.die_food_flow_perlin(C.byref(medium.c_struct(need_owner=False)), t, self._octaves, scale, decay,
                                                  self._seed & 0xFFFFFFFFFFFFFFFF, stream_ptr(medium.device)), 'die_food_flow_perlin')
 
 

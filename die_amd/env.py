@@ -489,7 +489,7 @@ class Env(_EnvBase):
         outs = [torch.empty_like(t) for t in tensors]
         ein = (C.c_void_p * max(len(tensors), 1))(*[t.data_ptr() for t in tensors])
         eout = (C.c_void_p * max(len(outs), 1))(*[t.data_ptr() for t in outs])
-        m, a_in = self.medium.c_struct(), A.c_struct()
+        m, a_in = self.medium.c_struct(need_owner=False), A.c_struct()       # (the sort reads positions only)
         a_out = _lib.Agents(A.N, _ptr(ox), _ptr(oy), _ptr(oalive), _ptr(ofood), _ptr(oslot))
         _lib.check(_lib.lib.die_agents_sort(C.byref(m), C.byref(a_in), C.byref(a_out), len(tensors), ein, eout,
                                             _ptr(self._sort_ws), self._sort_ws.numel(), stream_ptr(self.device)),

@@ -6,6 +6,7 @@ import ctypes as C
 import weakref
 from typing import Optional, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -34,7 +35,12 @@ class PicState:
         self.N = N
         self.meta = [torch.zeros((4, self.NT), dtype=torch.int32, device=dev) for _ in range(2)]     # off, n, s, inc
         self.dep = torch.empty(N, dtype=torch.float32, device=dev)
-        self.dep_plane = torch.empty((W, H), dtype=torch.float32, device=dev)
+        # two-launch form (include/die_hip.h `die_pic.code`): one byte per agent from the agent kernel to the field kernel
+        self.fused = bool(getattr(env, '_pic_fused', True))
+        self.code = torch.zeros((N + 7) // 4 * 4, dtype=torch.uint8, device=dev) if self.fused else None
+        self._plane_shape = (W, H)
+        # three-launch form only (else allocated when a step turns out to need it: a long step on small tiles)
+        self._dep_plane = None if self.fused else torch.empty((W, H), dtype=torch.float32, device=dev)
         self.part = torch.zeros(self.NT, dtype=torch.int64, device=dev)
         self.error = torch.zeros(2 + 16 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
@@ -55,8 +61,18 @@ class PicState:
         lay = [None, None]
         lay[self.cur] = self._layout(cur_tensors, self.meta[self.cur])
         lay[1 - self.cur] = self._layout(other_tensors, self.meta[1 - self.cur])
-        return _lib.Pic(self.xs, self.ys, self.N, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self.dep_plane), _ptr(self.part),
-                        _ptr(self.error), self.k1_threads, stages)
+        return _lib.Pic(self.xs, self.ys, self.N, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
+                        _ptr(self.error), self.k1_threads, stages, _ptr(self.code))
+
+    def two_launch(self, env, agent) -> bool:
+        """Does die_pic_forward_env_step take the two-launch form for this agent?  (The library decides by the same rule;
+        here it only settles whether the deposit plane of the three-launch form has to exist.)"""
+        if not self.fused:
+            return False
+        W, H = self._plane_shape
+        reach = float(np.float32(abs(agent._scale)) * np.float32(max(W, H) - 1))      # (float32, as the library computes it)
+        R = int(4.0 * float(np.float32(env.dynamics.diffuse_sigma)) + 0.5)
+        return 1 <= R <= 4 and int(reach) + 1 + R <= min(1 << self.xs, 1 << self.ys)
 
     def is_current(self, env, agent) -> bool:
         A, h = env.agents, self.held
@@ -106,7 +122,7 @@ class PicState:
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),
@@ -114,18 +130,22 @@ class PicState:
         return rebuild
 
     def step(self, env, agent, action, dyn, result, events=None):
-        """One step.  `events`: four torch.cuda.Event objects — the three launches are then issued by three calls
-        (die_pic.stages) with an event between them, so that bench.py times each kernel inside real steps.
+        """One step.  `events`: torch.cuda.Event objects (one more than launches: 3 in the two-launch form, 4 in the
+        three-launch form) — the launches are then issued one call each (die_pic.stages) with an event between them, so
+        that bench.py times each kernel inside real steps.
 
         A normalised PhysarumAgent's action is a function of what the step leaves behind (heading', deposit array), so the
         step does not store it (30 MB and 7 % of the agent kernel at 4096²): the PendingAction gets a `_rebuild` hook and
         is filled in when somebody reads it — or, if it is still referenced then, before the next step."""
         self.flush_lazy()
+        if self._dep_plane is None and not self.two_launch(env, agent):
+            self._dep_plane = torch.empty(self._plane_shape, dtype=torch.float32, device=env.device)
         out = self._out_tensors(env)
         lazy = self.lazy_actions and agent._kind == _lib.DIE_AGENT_PHYSARUM and hasattr(action, '_rebuild')
         m = env.medium.c_struct(need_owner=False)
         u = None if lazy else C.byref(action.raw_struct())
-        for i, stages in enumerate((0,) if events is None else (1, 2, 4)):
+        two = self.two_launch(env, agent)
+        for i, stages in enumerate((0,) if events is None else ((1, 2) if two else (1, 2, 4))):
             p = self._struct(self.held, out, stages)
             if events is not None:
                 events[i].record()
@@ -134,7 +154,7 @@ class PicState:
             if rc != 0:
                 return rc
         if events is not None:
-            events[3].record()
+            events[2 if two else 3].record()
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)
         if lazy:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 16
+#define DIE_ABI_VERSION 17
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -391,13 +391,22 @@ typedef struct die_pic {
     int64_t N;                   /* agents = slots, all alive */
     die_pic_layout layout[2];
     float* dep;                  /* N floats of scratch */
-    float* dep_plane;            /* W*H: per cell the deposit of the highest slot standing on it, or 0xFFFFFFFF */
+    float* dep_plane;            /* three-launch form only (may be NULL when code is given and the step qualifies), W*H: per cell the deposit of the highest slot standing
+                                    on it, or 0xFFFFFFFF */
     void* part_gain;             /* die_pic_tiles() 64-bit words: reward partials (also the binning scratch) */
-    uint32_t* error;             /* device word, 0 = fine; non-zero after a step: an agent moved further than a tile */
+    uint32_t* error;             /* device word, 0 = fine; sticky bits after a step: 1 segment bookkeeping broken, 2 an agent moved
+                                    further than a tile.  Never cleared by the library */
     int32_t k1_threads;          /* tuning: workgroup size of the agent kernel (multiple of 64, <= 512); 0 = default */
     int32_t stages;              /* 0 = the whole step; else a bit mask of the launches to run (per-kernel timing: bench.py):
-                                    1 agent kernel (repeatable: reads layout[from] only), 2 claim resolution + next offsets,
-                                    4 field sweep */
+                                    1 agent kernel (ONE issue per step: it adds to layout[1 - from].inc), 2 claim resolution +
+                                    next offsets, 4 field sweep (two-launch form: the sweep is part of the kernel of bit 2) */
+    /* two-launch form (code != NULL): the agent kernel also leaves ONE BYTE per agent of the layout it writes — where the
+     * agent's new tile lies relative to the tile whose segment holds it, and which borders of that new tile it stands
+     * within the gaussian radius of — and ONE kernel per tile finds, by that byte, the agents of the 9 segments around
+     * it that stand on it or within the radius of it, resolves their claims in LDS, adds the winners' deposits,
+     * diffuses, decays and feeds: no deposit plane, one launch less. */
+    uint8_t* code;               /* N bytes, rounded up to a multiple of 4 (read as 32-bit words); NULL: three launches (claim
+                                    resolution writes dep_plane, die_env.hip's sweep reads it) */
 } die_pic;
 
 /* number of tiles (words per per-tile array), or -1 if the shape is not compiled in */
@@ -407,7 +416,9 @@ int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo, const die_pic* p,
                 int32_t into, void* stream);
 /* GradientAgent/PhysarumAgent.forward (core/agent/gradient.py:96-124) + Env.step (core/env.py:101-131) on binned agents:
- * three launches (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  The
+ * two launches when p->code is given and floor(|scale| * (max(W, H) - 1)) + 1 + gaussian radius <= tile (forward + move + feeding +
+ * re-binning + the byte per agent; per-tile claim resolution + deposit + diffusion + feeding + next offsets + reward), else three
+ * (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  Same bits.  The
  * agent state (g->heading_* are ignored: layout[from].heading_*) moves with the agents; `act` receives the action in the order
  * of layout[from].  Requires: every slot alive, no agents_die / sense mask, normalised gradient without inertia or noise
  * and |scale| * (max(W, H) - 1) <= tile - 1 (else DIE_ERR_UNSUPPORTED / DIE_ERR_ARG: use die_forward_env_step). */

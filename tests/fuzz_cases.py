@@ -155,16 +155,18 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
         se = int(rs.choice([0, 2, 3]))
         gradient = bool(rs.rand() < 0.25)            # GradientAgent without momentum: the binned step stores its action
         two_agents = bool(rs.rand() < 0.2)           # two agent objects take turns on one env (each with its own headings)
+        fused = bool(rs.rand() < 0.8)                # two-launch form (one field kernel per tile) / three launches
         only = os.environ.get('FUZZ_ONLY')
         if only is not None and int(only) != case:
             continue
         if only is not None:
-            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se} gradient={gradient} two={two_agents}', flush=True)
+            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se} gradient={gradient} two={two_agents} fused={fused}', flush=True)
         outs = []
         for pic in (True, False):
             env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=se if pic else 3, pic=pic,
                                          field_dtype=torch.float16 if f16 else torch.float32)
             env._pic_tile = (xs, ys) if pic else None
+            env._pic_fused = fused
             def make(sd):
                 if gradient:
                     g = die_amd.GradientAgent(max_agents=N, seed=sd, scale=kw['scale'], sense_offset=kw['sense_offset'], deposit=kw['deposit'],

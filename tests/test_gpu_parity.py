@@ -447,9 +447,10 @@ def test_staged_path_gives_identical_results(die):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('form', ['two launches', 'three launches'])
 @pytest.mark.parametrize('W,H,boundary,f16,tile', [(128, 96, 'wrap', False, (4, 5)), (192, 256, 'limit', False, (6, 6)),
                                                    (256, 192, 'wrap', True, (5, 6)), (96, 384, 'wrap', False, (5, 7))])
-def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile):
+def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile, form):
     """The tile-binned fast path (die_pic_forward_env_step: agents in exact tile order, claims resolved in LDS, deposit
     plane instead of the claim plane) against the classic fused step: every output bit for bit — fields, ownership,
     agents, headings, the actions handed back, rewards — with collisions, every compiled tile shape, a mid-run switch
@@ -464,6 +465,8 @@ def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile):
         env = die.Env.from_numpy(medium, agents, die.Dynamics(boundary=die.BoundaryCondition(boundary)), sort_every=3, pic=pic,
                                  field_dtype=torch.float16 if f16 else torch.float32)
         env._pic_tile = tile if pic else None
+        # the two forms of the binned step (die_pic.code): one field kernel per tile, or K2 + deposit plane + sweep
+        env._pic_fused = form != 'three launches'
         ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
         ag.set_state(dir0)
         obs = env._get_current_obs
@@ -480,10 +483,157 @@ def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile):
             if pic and i in (0, 3, 7, 10):
                 assert env._pic is not None and env._pic.held[0] is env.agents.x, 'the tile-binned path did not run'
                 assert (env._pic.xs, env._pic.ys) == tile
+                assert env._pic.two_launch(env, ag) == (form != 'three launches')
         outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), env.medium.owner_slots().cpu().numpy(),
                      np.stack(acts), np.array(rewards)))
     for name, a, b in zip(('medium', 'agents', 'heading', 'owners', 'actions', 'rewards'), outs[0], outs[1]):
         assert np.array_equal(a, b), name
+
+
+def applied(action):
+    """The action as the device applies it: displacements rounded to the Q0.32 grid of the coordinates (at most 2^-33 away
+    from the float the agent computed — enough to put ≈ 1e-6 of the agents of a 4096-cell axis on the other side of a cell
+    border if the oracle moved by the unrounded value)."""
+    a = np.array(action, dtype=np.float64)
+    a[:2] = np.rint(a[:2] * 2.0 ** 32) / 2.0 ** 32
+    return a
+
+
+def _binned_steps_against_the_oracle(die, medium, agents, dyn, tile, agent_kind, kw, n_steps, f16=False, form='two launches', seed=3):
+    """`n_steps` × `env.step(agent.forward(obs))` on the tile-binned path, every step teacher-forced against the oracle:
+    the oracle starts each step from the device's state (downloaded), computes ITS forward — compared with the action the
+    device read back —, then steps with the device's action (so that a decision that sits on a float threshold cannot
+    cascade) and its new state is compared with the device's: coordinates / cells / ownership / alive bit-exact, fields,
+    agent_food, reward within 1e-5 relative (fp16 fields: within their 11-bit significand)."""
+    N = agents.shape[1]
+    W, H = medium.shape[1:]
+    env = die.Env.from_numpy(medium, agents, dyn, sort_every=0, field_dtype=torch.float16 if f16 else torch.float32)
+    env._pic_tile = tile
+    env._pic_fused = form != 'three launches'
+    rd = ref_dyn(dyn)
+    for f in ('rate_feed', 'rate_decay_chem', 'diffuse_sigma'):       # the C struct carries them as f32
+        setattr(rd, f, float(np.float32(getattr(rd, f))))
+    if agent_kind == 'physarum':
+        dev, ref = die.PhysarumAgent(max_agents=N, seed=seed, **kw), R.RefPhysarumAgent(N, seed=seed, **kw)
+    else:
+        dev, ref = die.GradientAgent(max_agents=N, seed=seed, **kw), R.RefGradientAgent(N, seed=seed, **kw)
+    dir0 = f32(ref._direction_rads)
+    dev.set_state(dir0)
+    frtol, fatol = (1e-3, 1e-4) if f16 else (RTOL, 1e-7)
+    obs = env._get_current_obs
+    for step in range(n_steps):
+        m0, a0, d0 = env.medium.to_numpy(), env.agents.to_numpy(), dev.direction_rads_numpy()
+        ref._direction_rads = d0.copy()
+        renv = R.RefEnv(m0, a0, rd)
+        want_action = ref.forward(renv.obs)
+        action = dev.forward(obs)
+        obs, reward, term, _, info = env.step(action)
+        assert env._pic is not None and env._pic.held is not None and env._pic.held[0] is env.agents.x, 'the tile-binned step did not run'
+        assert env._pic.two_launch(env, dev) == (form != 'three launches')
+        got_action = action.to_numpy()
+        # atol: sin/cos of a heading at a zero crossing carry the f32 angle rounding (~2e-7 rad) x scale
+        bad = ~np.isclose(got_action, want_action, rtol=max(RTOL, frtol), atol=1e-6 * abs(kw['scale']) + (1e-3 if f16 else 0)).all(axis=0)
+        assert bad.mean() < 2e-3, f'step {step}: forward differs for {bad.sum()} of {N} slots'
+        _, want_reward, want_term, _, want_info = renv.step(applied(got_action))
+        ga, gm = env.agents.to_numpy(), env.medium.to_numpy()
+        if dyn.boundary == die.BoundaryCondition.limit:     # 1.0 is stored as 1 − 2^-32
+            assert np.abs(ga[:2] - renv.agents[:2]).max() <= 2.0 ** -32
+        else:
+            assert np.array_equal(ga[:2], renv.agents[:2]), f'step {step}: coordinates'
+        assert np.array_equal(ga[2], renv.agents[2])
+        assert np.array_equal(gm[0], renv.medium[0]), f'step {step}: agents channel'
+        ix, iy = R.cell(renv.agents[0], W), R.cell(renv.agents[1], H)
+        want_owner = np.full((W, H), -1, dtype=np.int64)
+        want_owner[ix, iy] = np.arange(N)                   # ascending order: the last (highest) write stays
+        assert np.array_equal(env.medium.owner_slots().cpu().numpy(), want_owner), f'step {step}: ownership'
+        assert np.allclose(ga[3], renv.agents[3], rtol=frtol, atol=fatol), f'step {step}: agent_food'
+        assert np.allclose(gm[1], renv.medium[1], rtol=frtol, atol=fatol), f'step {step}: food'
+        assert np.allclose(gm[2], renv.medium[2], rtol=frtol, atol=fatol), f'step {step}: chem'
+        assert info['num_agents'] == want_info['num_agents'] == N and term == want_term
+        assert abs(reward - want_reward) <= max(RTOL, frtol) * np.abs(renv.last_gained).sum() + 1e-9, f'step {step}: reward'
+    return env
+
+
+BINNED_ORACLE_CASES = [
+    dict(W=64, H=96, tile=(4, 5)),
+    dict(W=192, H=192, tile=(6, 6), collide=0.6),                            # forced collisions: last writer wins
+    dict(W=96, H=192, tile=(5, 6), boundary='limit'),
+    dict(W=96, H=384, tile=(5, 7), food_infinite=True),
+    dict(W=192, H=256, tile=(6, 6), zero_cost=True, sigma=0.8, rate_feed=0.3, decay=0.05),    # gaussian radius 3
+    dict(W=128, H=192, tile=(5, 6), f16=True),
+    dict(W=128, H=192, tile=(5, 6), agent='gradient'),
+    dict(W=192, H=192, tile=(6, 6), dense=True),                             # several agents per cell
+    dict(W=64, H=96, tile=(4, 5), form='three launches'),
+    dict(W=192, H=192, tile=(6, 6), collide=0.6, form='three launches'),
+]
+
+
+@pytest.mark.parametrize('case', BINNED_ORACLE_CASES, ids=lambda c: '-'.join(f'{k}{v}' for k, v in c.items()))
+def test_tile_binned_step_vs_oracle(die, case):
+    """The benchmarked path, die_pic_forward_env_step, directly against oracle.cpu_ref (core/env.py:101-131,
+    core/agent/gradient.py:96-124) — not through its equality with the classic step: all four tile shapes, wrap / limit,
+    fp16 fields, a GradientAgent, forced collisions, worlds with several agents per cell, food_infinite, zero_cost, a
+    wider gaussian, both forms of the step; three steps each, so that segments with leavers and arrivals (and rim records
+    written by a previous step's neighbours) are on the path."""
+    W, H = case['W'], case['H']
+    rs = np.random.RandomState(W * 3 + H)
+    N = 3 * W * H if case.get('dense') else int(0.15 * W * H)
+    medium, agents = random_state(W, H, N, N, rs, collide=case.get('collide', 0.3))
+    dyn = die.Dynamics(boundary=die.BoundaryCondition(case.get('boundary', 'wrap')), food_infinite=case.get('food_infinite', False),
+                       op_action_cost=die.zero_cost if case.get('zero_cost') else die.linear_action_cost,
+                       diffuse_sigma=case.get('sigma', 0.5), rate_feed=case.get('rate_feed', 0.1), rate_decay_chem=case.get('decay', 0.1))
+    if case.get('agent') == 'gradient':
+        kw = dict(scale=0.01, sense_offset=0.03, inertia=0.0, noise_scale=0.0, normalized_grad=True)
+    else:
+        kw = dict(scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+    if case.get('f16'):                                     # fields the device holds exactly
+        medium[1:] = medium[1:].astype(np.float16).astype(np.float64)
+    _binned_steps_against_the_oracle(die, medium, agents, dyn, case['tile'], case.get('agent', 'physarum'), kw, 3, f16=case.get('f16', False),
+                                     form=case.get('form', 'two launches'))
+
+
+def test_configs2_full_size_teacher_forced_step_vs_oracle(die):
+    """BASELINE configs[2] at FULL size — PhysarumAgent, 4096x4096 fp32, ratio 0.15, the benchmark's parameters — on the
+    benchmarked (tile-binned, two-launch) path: after four free steps (chem exists, segments hold leavers and arrivals)
+    ONE teacher-forced step against the oracle: cells / ownership / alive bit-exact, fields and agent_food at 1e-5."""
+    W = H = 4096
+    env = die.Env((W, H), die.Dynamics(init_agent_ratio=0.15), seed=1234, max_agents='alive', sync=False)
+    N = env.agents.N
+    kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), turn_angle=30, sense_angle=90, turn_tolerance=0.1, deposit=4.0)
+    dev, ref = die.PhysarumAgent(max_agents=N, seed=1234, **kw), R.RefPhysarumAgent(N, seed=1234, **kw)
+    obs = env._get_current_obs
+    for _ in range(4):
+        obs, *_ = env.step(dev.forward(obs))
+        ref._calls += 1                                     # (the Philox step counter of the oracle's agent keeps pace)
+    assert env._pic is not None and env._pic.held[0] is env.agents.x and env._pic.two_launch(env, dev)
+    m0, a0 = env.medium.to_numpy(), env.agents.to_numpy()
+    ref._direction_rads = dev.direction_rads_numpy()
+    rd = R.RefDynamics(rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)), diffuse_sigma=0.5)
+    renv = R.RefEnv(m0, a0, rd)
+    want_action = ref.forward(renv.obs)
+    action = dev.forward(obs)
+    obs, res, *_ = env.step(action)
+    reward, num_agents = env.read_result(res)
+    got_action = action.to_numpy()
+    bad = ~np.isclose(got_action, want_action, rtol=RTOL, atol=1e-6 * kw['scale']).all(axis=0)
+    assert bad.mean() < 1e-3, f'forward differs for {bad.sum()} of {N} slots'
+    _, want_reward, _, _, want_info = renv.step(applied(got_action))
+    ga = env.agents.to_numpy()
+    assert np.array_equal(ga[:3], renv.agents[:3])
+    assert np.allclose(ga[3], renv.agents[3], rtol=RTOL, atol=1e-7)
+    del ga
+    owner = env.medium.owner_slots().cpu().numpy()
+    ix, iy = R.cell(renv.agents[0], W), R.cell(renv.agents[1], H)
+    want_owner = np.full((W, H), -1, dtype=np.int64)
+    want_owner[ix, iy] = np.arange(N)
+    assert np.array_equal(owner, want_owner)
+    del owner, want_owner
+    gm = env.medium.to_numpy()
+    assert np.array_equal(gm[0], renv.medium[0])
+    assert np.allclose(gm[1], renv.medium[1], rtol=RTOL, atol=1e-8)
+    assert np.allclose(gm[2], renv.medium[2], rtol=RTOL, atol=1e-7)
+    assert num_agents == want_info['num_agents'] == N
+    assert abs(reward - want_reward) <= RTOL * np.abs(renv.last_gained).sum() + 1e-9
 
 
 def test_tile_binned_step_with_a_gradient_agent(die):
