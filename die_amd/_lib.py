@@ -72,7 +72,7 @@ class Pic(C.Structure):
     _fields_ = [('tile_xs', C.c_int32), ('tile_ys', C.c_int32), ('N', C.c_int64), ('layout', PicLayout * 2),
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
-                ('code', C.c_void_p)]
+                ('rim', C.c_void_p), ('rim_cnt', C.c_void_p)]
 
 
 class Batch(C.Structure):
@@ -166,6 +166,7 @@ _SIGNATURES = {
     'die_ghost_apply': (C.c_int, [_P(C.c_void_p), _P(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, _P(C.c_int64), _P(C.c_int64),
                                   _P(C.c_int64), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]),
     'die_pic_tiles': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    'die_pic_rim_cap': (C.c_int64, [C.c_int32, C.c_int32]),
     'die_pic_bin': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),

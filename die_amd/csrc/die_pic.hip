@@ -89,10 +89,13 @@ struct PicArgs {
     long long* part_gain;           // one fixed-point partial per tile
     uint32_t* error;                // device word, sticky: bit 0 segment bookkeeping broken, bit 1 an agent jumped further than a
                                     // tile, bit 2 a rim record left the 3×3 neighbourhood
-    // two-launch form (die_pic.code != NULL): per agent of layout `out` one byte for k_pic_resolve_diffuse — where its new
-    // tile lies relative to the tile whose segment holds it, and which borders of the new tile it stands within R cells of
-    uint8_t* code;                  // ((ddx + 1)·3 + ddy + 1)·9 + (ex + 1)·3 + ey + 1
-    int rim_r;                      // gaussian radius R = width of the rim
+    // two-launch form (die_pic.rim != NULL): per tile the list of its agents that matter to another tile's field kernel —
+    // those that walked off the tile, and those within R cells of one of the borders of the tile they stand on: entry =
+    // position in the tile's segment of layout `out` | code << 24, code = ((ddx + 1)·3 + ddy + 1)·9 + ex·3 + ey (where the
+    // agent's tile lies from here; which of ITS borders are near: 0 low, 1 none, 2 high)
+    uint32_t* rim;                  // [tile·rim_cap + i]
+    uint32_t* rim_cnt;              // [tile]: entries the tile had (may exceed rim_cap: the reader then scans the segment)
+    int rim_cap, rim_r;             // gaussian radius R = width of the rim
 };
 
 __device__ __forceinline__ int pic_tile_of(const PicArgs& p, uint32_t X, uint32_t Y) {
@@ -166,14 +169,16 @@ struct PicStage {
     }
 };
 
+#define PIC_RIM_CAP_MAX 224      // entries of a tile's rim list (k_pic_resolve_diffuse reads 9 lists with 4 loads per thread)
 #define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
 static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
 
 // Diagnostic build only (-DPIC_STAMPS; scratch/pic_stamps.py): s_memtime at the phase boundaries of K1, written by lane 0
-// of wave 0 behind the error word (the caller allocates 1 + 8·tiles words).  No stamp executes in the shipped kernel.
+// of wave 0 behind the error word (the caller allocates 2 + 32·tiles words: 16 64-bit stamps per tile, [0, 8) the agent
+// kernel's, [8, 16) the field kernel's).  No stamp executes in the shipped kernel.
 #ifdef PIC_STAMPS
 #define PIC_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-                          ((unsigned long long*)(p.error + 2))[(size_t)tile * 8 + (k)] = t_; } } while (0)
+                          ((unsigned long long*)(p.error + 2))[(size_t)tile * 16 + (k)] = t_; } } while (0)
 #else
 #define PIC_STAMP(k) do { } while (0)
 #endif
@@ -193,6 +198,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     __shared__ uint32_t s_base[9], s_pre[10];
     __shared__ uint32_t s_front, s_back, s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
+    __shared__ uint32_t s_rim[RIM ? PIC_RIM_CAP_MAX : 1], s_nrim; // RIM: this tile's list for the field kernels around it
     __shared__ uint32_t s_list[PIC_LIST_CAP];
     __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
     const int tx = blockIdx.y, ty = blockIdx.x, tile = tx * p.nty + ty;      // (a 2-D grid: no division by a run-time value)
@@ -200,6 +206,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE, nwaves = blockDim.x / DIE_WAVE;
     if (threadIdx.x == 0) { s_front = 0; s_back = 0; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
     if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
+    if (RIM && threadIdx.x == 0) s_nrim = 0;
     PIC_STAMP(0);
     // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
     // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
@@ -298,6 +305,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             float af = 0.f, dep = 0.f;
             double hd = 0.0;
             uint32_t code = 0;
+            bool listed = false;
             if (act) {
                 const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
                 if (first && idx < n_own) {
@@ -346,11 +354,12 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 }                                                          // agents: 11 µs of contended global atomics otherwise)
                 if (RIM) {
                     // the field kernel of a tile diffuses that tile's cells and so needs the deposits on the R cells around it
-                    // too: it finds them among the agents of the 9 segments around it by this byte — where the agent's new tile
-                    // lies (dd), and which of that tile's borders it stands within R cells of (e) — without their coordinates
+                    // too: listed for it are the agents that walked off this tile and those that stand within R cells of a
+                    // border of their (new) tile
                     const int lx = cx & (TX - 1), ly = cy & (TY - 1), Rr = p.rim_r;
                     const int ex = lx < Rr ? 0 : (lx >= TX - Rr ? 2 : 1), ey = ly < Rr ? 0 : (ly >= TY - Rr ? 2 : 1);
                     code = (uint32_t)(((ddx + 1) * 3 + ddy + 1) * 9 + ex * 3 + ey);
+                    listed = !stay || ex != 1 || ey != 1;
                 }
             }
             // positions: stayers fill the segment from the front, leavers from the back; one LDS atomic per wave and class
@@ -362,8 +371,18 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             }
             bf = __shfl(bf, 0, DIE_WAVE);
             bb = __shfl(bb, 0, DIE_WAVE);
+            const uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
+            if (RIM) {                                             // (one LDS atomic per wave, like the two above)
+                const unsigned long long m_rim = __ballot(act && listed);
+                uint32_t br = 0;
+                if (lane == 0 && m_rim) br = atomicAdd(&s_nrim, (uint32_t)__popcll(m_rim));
+                br = __shfl(br, 0, DIE_WAVE);
+                if (act && listed) {
+                    const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
+                    if (at < (uint32_t)p.rim_cap) s_rim[at] = (k & 0xFFFFFFu) | (code << 24);
+                }
+            }
             if (act) {
-                const uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
                 if (k < on) {
                     const uint32_t q = obase + k;
                     p.out.x[q] = X;
@@ -373,7 +392,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     p.out.hhi[q] = (uint32_t)__double2hiint(hd);
                     p.out.hlo[q] = (uint32_t)__double2loint(hd);
                     p.dep[q] = dep;
-                    if (RIM) p.code[q] = (uint8_t)code;
                 } else {
                     atomicOr(p.error, 1u);
                 }
@@ -394,6 +412,12 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
         const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
         atomicAdd(&p.out.inc[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
+    }
+    if (RIM) {
+        // (a segment too long for the 24-bit positions counts as an overflowing list: the reader scans it)
+        const uint32_t nr = on >= (1u << 24) ? (uint32_t)p.rim_cap + 1u : s_nrim;
+        for (uint32_t i = threadIdx.x; i < min(nr, (uint32_t)p.rim_cap); i += blockDim.x) p.rim[(size_t)tile * p.rim_cap + i] = s_rim[i];
+        if (threadIdx.x == 0) p.rim_cnt[tile] = nr;
     }
     if (threadIdx.x == 0) {
         long long t = 0;
@@ -509,9 +533,10 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
 //   claims    32-bit LDS atomicMax of slot + 1 per window cell — "the highest alive slot on a cell writes" (core/env.py:211) —
 //             for the agents standing on d (its stayers + the neighbours' leavers that landed on it, as in k_pic_resolve) AND
 //             for the agents standing within R cells outside d (their deposits reach d's cells through the gaussian).  Both
-//             kinds are found among the agents of the 9 segments around d by the byte the agent kernel left per agent (where
-//             its new tile lies relative to its segment's tile, which borders of the new tile it stands within R cells of):
-//             four bytes per load, no coordinates touched unless the agent matters here — no list, no capacity;
+//             kinds are found in the rim lists the agent kernel left for the 9 tiles around d (per tile: its agents that
+//             walked off it or stand near a border, with a code that says where) — lists at fixed places, requested at the
+//             very top with everything else that depends on the tile index only; a list that overflowed: that tile's
+//             segment is scanned by coordinates instead (slow, correct);
 //   deposit   every such agent looks its cell up again; the winner adds its deposit to the chem window staged in LDS
 //             (chem[c] = chem[c] + deposit, core/env.py:211: one writer per cell, no atomic);
 //   feeding   food −= rate·food on d's occupied cells (core/env.py:222-228), 16-byte read-modify-write of the groups that hold one;
@@ -524,6 +549,8 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
 struct KbArgs {
     const void* chem;
     void* chem_next;
+    const uint32_t* rim;
+    const uint32_t* rim_cnt;
     int food_infinite;
     float keep;
     float w[2 * 4 + 1];
@@ -531,10 +558,18 @@ struct KbArgs {
     long long alive_const;
 };
 
-template <int XS, int YS> struct KbShape { static constexpr int BLOCK = ((1 << XS) * (1 << YS) >= 4096) ? 512 : 256; };
+template <int XS, int YS> struct KbShape {
+    static constexpr int BLOCK = ((1 << XS) * (1 << YS) >= 4096) ? 512 : 256;
+    static constexpr int NE = 4;                                    // rim-list entries per thread: 9 lists in NE loads
+    static constexpr int RIM_CAP = NE * BLOCK / 9 / 4 * 4;          // 224 / 112
+    static_assert(RIM_CAP <= PIC_RIM_CAP_MAX, "the agent kernel's list holds it");
+};
 
+#ifndef PIC_KB_MINW
+#define PIC_KB_MINW 8           // 4 workgroups of 512 threads per CU (A/B: scratch/build_variant.sh)
+#endif
 template <typename T, int XS, int YS, int R>
-__global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffuse(PicArgs p, KbArgs a) {
+__global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_resolve_diffuse(PicArgs p, KbArgs a) {
     constexpr int TX = 1 << XS, TY = 1 << YS, BLOCK = KbShape<XS, YS>::BLOCK;
     constexpr int A = 16 / (int)sizeof(T);                 // cells per 16-byte vector
     constexpr int WR = TX + 2 * R, WC = TY + 2 * R;        // the window
@@ -544,11 +579,11 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
     float* s_chem = (float*)kb_smem;                        // WR × CP, window cell (r, c) at r·CP + c − R + A
     uint32_t* s_claim = (uint32_t*)(s_chem + WR * CP);      // WR × WC; after the deposits: s_tmp, TX × CP (the x pass)
     float* s_tmp = (float*)s_claim;
-    // the 9 segments around d in layout `out`: [0] d's own (its stayers are taken directly, only its leavers are scanned),
-    // [1..8] the ring (scanned whole); scanned in 4-byte words of codes
-    __shared__ uint32_t s_lo[9], s_hi[9], s_w0[9], s_wpre[10];   // agent index range to scan; its first code word; prefix of the word counts
+    // the 9 tiles around d, [0] d itself, [1..8] the ring: segment in layout `out`, rim list
+    __shared__ uint32_t s_off[9], s_n[9], s_rn[9];          // segment offset, size; entries of the rim list
     __shared__ uint32_t s_own[2];                           // d's stayers: first index, count
-    __shared__ uint32_t s_nhit;                             // hits of the scan
+    __shared__ unsigned char s_lut[9 * 81 + 3];             // (list, code) → (ux + 1)·3 + uy + 1 of an agent that matters here, else 0xFF
+    constexpr int CAPR = KbShape<XS, YS>::RIM_CAP, NE = KbShape<XS, YS>::NE;
     const int NT = p.ntx * p.nty;
     if ((int)blockIdx.y == p.ntx) {                         // the extra grid row
         if (blockIdx.x == 0) {                              // sizes and offsets of the layout the NEXT step writes
@@ -595,16 +630,29 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
     }
     const int tx = blockIdx.y, ty = blockIdx.x, x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
+    [[maybe_unused]] const int tile = tx * p.nty + ty;
+    PIC_STAMP(8);
     const T* chem = (const T*)a.chem;
     T* food = (T*)p.food;
-    // 1. everything that depends on the tile index only goes out first: the per-tile words, the chem window, the food tile
-    uint32_t m_o = 0, m_s = 0, m_n = 0;
+    // 1. everything that depends on the tile index only goes out first: the per-tile words, the rim lists, the chem window,
+    //    the food tile
+    auto ring_tile = [&](int q) {
+        const int k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
+        return pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty);
+    };
+    uint32_t m_o = 0, m_s = 0, m_n = 0, m_r = 0;
     if (threadIdx.x < 9) {
-        const int q = threadIdx.x, k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
-        const int t = pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty);
-        m_o = p.out.off[t]; m_s = p.out.s[t]; m_n = p.out.n[t];
+        const int t = ring_tile(threadIdx.x);
+        m_o = p.out.off[t]; m_s = p.out.s[t]; m_n = p.out.n[t]; m_r = a.rim_cnt[t];
         if (m_s > m_n) m_s = m_n = 0;                       // (broken bookkeeping — never loop over garbage)
     }
+    // rim entry e of the flattened 9 × CAPR: list e / CAPR, entry e % CAPR (whether it exists is known once the counts are here)
+    auto rim_load = [&](int m) {
+        const int e = (int)threadIdx.x + m * BLOCK, l = e / CAPR, i = e - l * CAPR;
+        return l < 9 ? a.rim[(size_t)ring_tile(l) * CAPR + i] : 0u;
+    };
+    static_assert(NE == 4, "four named registers");
+    const uint32_t re0 = rim_load(0), re1 = rim_load(1), re2 = rim_load(2), re3 = rim_load(3);
     constexpr int NCV = (WR * NV + BLOCK - 1) / BLOCK;
     static_assert(NCV <= 3, "three window vectors per thread at most");       // (named registers: as an array they went to scratch)
     auto window_load = [&](int q) {
@@ -615,112 +663,26 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
     uint4 cv0 = window_load(0), cv1 = cv0, cv2 = cv0;
     if constexpr (NCV > 1) cv1 = window_load(1);
     if constexpr (NCV > 2) cv2 = window_load(2);
-    constexpr int FG = (TX * TY / 4 + BLOCK - 1) / BLOCK;
-    float fd[FG][4];
-    if (!a.food_infinite) {
-#pragma unroll
-        for (int q = 0; q < FG; ++q) {
-            const int i = ((int)threadIdx.x + q * BLOCK) * 4;
-            if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
-        }
-    }
     for (int i = threadIdx.x; i < WR * WC / 4; i += BLOCK) ((uint4*)s_claim)[i] = make_uint4(0u, 0u, 0u, 0u);
     static_assert((WR * WC) % 4 == 0, "16-byte zeroing");
     if (threadIdx.x < 9) {
-        const uint32_t lo = threadIdx.x == 0 ? m_o + m_s : m_o, hi = m_o + m_n;
-        s_lo[threadIdx.x] = lo; s_hi[threadIdx.x] = hi; s_w0[threadIdx.x] = lo >> 2;
-        if (threadIdx.x == 0) { s_own[0] = m_o; s_own[1] = m_s; s_nhit = 0; }
+        s_off[threadIdx.x] = m_o; s_n[threadIdx.x] = m_n; s_rn[threadIdx.x] = m_r;
+        if (threadIdx.x == 0) { s_own[0] = m_o; s_own[1] = m_s; }
+    }
+    // (while the loads fly) which (list, code) pairs matter to d, and from which tile relative to d
+    for (int t = threadIdx.x; t < 9 * 81; t += BLOCK) {
+        const int q = t / 81, c = t - q * 81, k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q), dd = c / 9, e = c - dd * 9;
+        int ux = k3 / 3 - 1 + dd / 3 - 1, uy = k3 % 3 - 1 + dd % 3 - 1;   // the agent's tile relative to d, in [−2, 2] …
+        ux += ux < 0 ? p.ntx : 0; ux -= 2 * ux > p.ntx ? p.ntx : 0;        // … as the nearest periodic image (3 tiles: 2 ≡ −1)
+        uy += uy < 0 ? p.nty : 0; uy -= 2 * uy > p.nty ? p.nty : 0;
+        const int sx = e / 3 - 1, sy = e % 3 - 1;                          // which neighbours of its tile it stands close to
+        const bool here = (ux == 0 || ux == -sx) && (uy == 0 || uy == -sy) && !(q == 0 && dd == 4);   // (d's stayers: taken directly)
+        s_lut[t] = here ? (unsigned char)((ux + 1) * 3 + uy + 1) : (unsigned char)0xFF;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int q = 0; q < 9; ++q) { s_wpre[q] = run; run += s_hi[q] > s_lo[q] ? ((s_hi[q] - 1) >> 2) - (s_lo[q] >> 2) + 1 : 0u; }
-        s_wpre[9] = run;
-    }
-    __syncthreads();
-    const uint32_t own0 = s_own[0], nown = s_own[1], nwords = s_wpre[9];
-    // window cell of an agent standing on the tile at (ux, uy) tiles from d; 0xFFFFFFFF: outside the window
-    auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
-        const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
-        const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
-        return (r >= 0 && r < WR && c >= 0 && c < WC) ? (uint32_t)(r * WC + c) : 0xFFFFFFFFu;
-    };
-    // the scanned segments: every agent whose byte says "stands on d, or within R cells of d" → hit(index, (ux + 1)·3 + uy + 1)
-    auto scan = [&](auto&& hit) {
-        for (uint32_t v = threadIdx.x; v < nwords; v += BLOCK) {
-            int q = 0;
-            while (v >= s_wpre[q + 1]) ++q;
-            const uint32_t wi = s_w0[q] + (v - s_wpre[q]), lo = s_lo[q], hi = s_hi[q];
-            const uint32_t c4 = ((const uint32_t*)p.code)[wi];
-            const int k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q), kx = k3 / 3 - 1, ky = k3 % 3 - 1;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const uint32_t j = wi * 4 + b, c = (c4 >> (8 * b)) & 255u;
-                if (j < lo || j >= hi || c >= 81u) continue;
-                const int dd = (int)c / 9, e = (int)c - dd * 9;
-                int ux = kx + dd / 3 - 1, uy = ky + dd % 3 - 1;              // the agent's tile relative to d, in [−2, 2] …
-                ux += ux < 0 ? p.ntx : 0; ux -= 2 * ux > p.ntx ? p.ntx : 0;   // … as the nearest periodic image (3 tiles: 2 ≡ −1)
-                uy += uy < 0 ? p.nty : 0; uy -= 2 * uy > p.nty ? p.nty : 0;
-                const int sx = e / 3 - 1, sy = e % 3 - 1;                    // which neighbours of its tile it stands close to
-                if ((ux == 0 || ux == -sx) && (uy == 0 || uy == -sy)) hit(j, (uint32_t)((ux + 1) * 3 + uy + 1));
-            }
-        }
-    };
-    // 2. claims.  The tile's own stayers two per thread and trip, their loads in flight together; the scan only LISTS its
-    //    hits (in LDS, where the chem window will be: it is committed after the claims) so that their coordinates are then
-    //    fetched two per thread with all loads in flight too — fetched at the hit, every hit of a wave was a round trip of
-    //    its own (147 µs against 63).  The first trip of each kind stays in registers for the deposit pass.
-    constexpr uint32_t LIST_CAP = 2 * BLOCK;                 // more hits than that (a crowd): the slow way, hit by hit
-    uint32_t* s_list = (uint32_t*)s_chem;                    // agent index | tile code << 28
-    static_assert(LIST_CAP <= WR * CP, "the list lives where the chem window will be");
-    const bool packable = a.alive_const < (1ll << 28);      // (more agents than that: always the slow way)
-    uint32_t cw[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, cs[4] = {0u, 0u, 0u, 0u}, cd[4] = {0u, 0u, 0u, 0u};
-    uint32_t X[2] = {0u, 0u}, Y[2] = {0u, 0u};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const uint32_t i = threadIdx.x + u * BLOCK;
-        if (i < nown) { const uint32_t j = own0 + i; X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[u] = p.out.slot[j] + 1u; cd[u] = __float_as_uint(p.dep[j]); }
-    }
-    scan([&](uint32_t j, uint32_t ucode) {
-        const uint32_t at = atomicAdd(&s_nhit, 1u);
-        if (at < LIST_CAP && packable) s_list[at] = j | (ucode << 28);
-    });
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        if (threadIdx.x + u * BLOCK < nown) { cw[u] = window_cell(X[u], Y[u], 0, 0); if (cw[u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[u]], cs[u]); }
-    }
-    for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
-        const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
-        if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_], p.out.slot[j] + 1u);
-    }
-    __syncthreads();
-    const uint32_t nhit = s_nhit;
-    const bool crowd = nhit > LIST_CAP || !packable;
-    if (!crowd) {
-        uint32_t uc[2] = {4u, 4u};
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t i = threadIdx.x + u * BLOCK;
-            if (i < nhit) {
-                const uint32_t h = s_list[i], j = h & 0x0FFFFFFFu;
-                X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[2 + u] = p.out.slot[j] + 1u; cd[2 + u] = __float_as_uint(p.dep[j]); uc[u] = h >> 28;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (threadIdx.x + u * BLOCK < nhit) {
-                cw[2 + u] = window_cell(X[u], Y[u], (int)uc[u] / 3 - 1, (int)uc[u] % 3 - 1);
-                if (cw[2 + u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[2 + u]], cs[2 + u]);
-            }
-        }
-        __syncthreads();                                    // every list entry has been read: the window may overwrite it
-    } else {
-        scan([&](uint32_t j, uint32_t ucode) {
-            const uint32_t w_ = window_cell(p.out.x[j], p.out.y[j], (int)ucode / 3 - 1, (int)ucode % 3 - 1);
-            if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_], p.out.slot[j] + 1u);
-        });
-    }
-    // 3. the chem window into LDS (as float)
+    PIC_STAMP(9);
+    // the chem window into LDS (as float): requested first, so it is here when the per-tile words are — its registers are
+    // free for the agents' data
     auto window_commit = [&](int q, const uint4 u) {
         const int i = (int)threadIdx.x + q * BLOCK;
         if (i >= WR * NV) return;
@@ -738,7 +700,80 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
     window_commit(0, cv0);
     if constexpr (NCV > 1) window_commit(1, cv1);
     if constexpr (NCV > 2) window_commit(2, cv2);
+    const uint32_t own0 = s_own[0], nown = s_own[1];
+    // window cell of an agent standing on the tile at (ux, uy) tiles from d; 0xFFFFFFFF: outside the window
+    auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
+        const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
+        const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
+        return (r >= 0 && r < WR && c >= 0 && c < WC) ? (uint32_t)(r * WC + c) : 0xFFFFFFFFu;
+    };
+    // a rim entry → (agent index, tile code), or 0xFFFFFFFF when it does not exist / does not matter here
+    auto rim_decode = [&](int m, uint32_t ent, uint32_t& uc) {
+        const int e = (int)threadIdx.x + m * BLOCK, l = e / CAPR, i = e - l * CAPR;
+        uc = 0xFFu;
+        if (l >= 9 || (uint32_t)i >= s_rn[l] || s_rn[l] > (uint32_t)CAPR) return 0xFFFFFFFFu;
+        const uint32_t code = ent >> 24, k = ent & 0xFFFFFFu;
+        if (code >= 81u || k >= s_n[l]) return 0xFFFFFFFFu;
+        uc = s_lut[l * 81 + code];
+        return uc == 0xFFu ? 0xFFFFFFFFu : s_off[l] + k;
+    };
+    // a tile whose list overflowed: every agent of its segment that stands in the window (for d itself: its leavers only)
+    auto scan_segment = [&](int l, bool apply) {
+        const uint32_t lo = l == 0 ? own0 + nown : s_off[l], hi = s_off[l] + s_n[l];
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += BLOCK) {
+            const int cx = die_cell((int64_t)p.out.x[j], p.g.gW), cy = die_cell((int64_t)p.out.y[j], p.g.gH);
+            int rr = cx - x0, rc = cy - y0;                 // periodic distance to the tile's origin
+            rr = rr > W / 2 ? rr - W : (rr < -(W / 2) ? rr + W : rr);
+            rc = rc > H / 2 ? rc - H : (rc < -(H / 2) ? rc + H : rc);
+            if (rr < -R || rr >= TX + R || rc < -R || rc >= TY + R) continue;
+            const uint32_t widx = (uint32_t)((rr + R) * WC + rc + R), s1 = p.out.slot[j] + 1u;
+            if (!apply) atomicMax(&s_claim[widx], s1);
+            else if (s_claim[widx] == s1) {
+                float* c = &s_chem[(rr + R) * CP + rc + A];
+                *c = die_as_stored<T>(*c + p.dep[j]);
+            }
+        }
+    };
+    uint32_t over = 0;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) over |= s_rn[l] > (uint32_t)CAPR ? 1u << l : 0u;
+    // 2. claims: the tile's own stayers two per thread and trip and this thread's rim entries, all their loads in flight
+    //    together; the first trip and the entries stay in registers for the deposit pass
+    constexpr int FG = (TX * TY / 4 + BLOCK - 1) / BLOCK;
+    float fd[FG][4];
+    uint32_t cw[2 + NE], cs[2 + NE], cd[2 + NE];
+    {
+        uint32_t X[2 + NE], Y[2 + NE], uc[NE];
+        const uint32_t rj[NE] = {rim_decode(0, re0, uc[0]), rim_decode(1, re1, uc[1]), rim_decode(2, re2, uc[2]), rim_decode(3, re3, uc[3])};
+#pragma unroll
+        for (int u = 0; u < 2 + NE; ++u) {
+            const uint32_t j = u < 2 ? (threadIdx.x + u * BLOCK < nown ? own0 + threadIdx.x + u * BLOCK : 0xFFFFFFFFu) : rj[u - 2];
+            cw[u] = 0xFFFFFFFFu; cs[u] = 0u; cd[u] = 0u; X[u] = Y[u] = 0u;
+            if (j != 0xFFFFFFFFu) { X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[u] = p.out.slot[j] + 1u; cd[u] = __float_as_uint(p.dep[j]); cw[u] = 0u; }
+        }
+        // (the food tile is needed last: requested behind the agents' data — loads return in order)
+        if (!a.food_infinite) {
+#pragma unroll
+            for (int q = 0; q < FG; ++q) {
+                const int i = ((int)threadIdx.x + q * BLOCK) * 4;
+                if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2 + NE; ++u) {
+            if (cw[u] == 0xFFFFFFFFu) continue;
+            cw[u] = u < 2 ? window_cell(X[u], Y[u], 0, 0) : window_cell(X[u], Y[u], (int)uc[u - 2] / 3 - 1, (int)uc[u - 2] % 3 - 1);
+            if (cw[u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[u]], cs[u]);
+        }
+    }
+    for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
+        const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
+        if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_], p.out.slot[j] + 1u);
+    }
+    if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, false);
+    PIC_STAMP(10);
     __syncthreads();
+    PIC_STAMP(11);
     // 4. deposits of the winners; feeding of the tile's occupied cells
     auto deposit = [&](uint32_t widx, uint32_t s1, uint32_t db) {
         if (widx == 0xFFFFFFFFu || s_claim[widx] != s1) return;
@@ -746,20 +781,13 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
         float* q = &s_chem[r * CP + c - R + A];
         *q = die_as_stored<T>(*q + __uint_as_float(db));
     };
-    deposit(cw[0], cs[0], cd[0]);
-    deposit(cw[1], cs[1], cd[1]);
+#pragma unroll
+    for (int u = 0; u < 2 + NE; ++u) deposit(cw[u], cs[u], cd[u]);
     for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
         const uint32_t j = own0 + i;
         deposit(window_cell(p.out.x[j], p.out.y[j], 0, 0), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
     }
-    if (!crowd) {
-        deposit(cw[2], cs[2], cd[2]);
-        deposit(cw[3], cs[3], cd[3]);
-    } else {                                                // a crowd: everybody scans again
-        scan([&](uint32_t j, uint32_t ucode) {
-            deposit(window_cell(p.out.x[j], p.out.y[j], (int)ucode / 3 - 1, (int)ucode % 3 - 1), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
-        });
-    }
+    if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, true);
     if (!a.food_infinite) {
 #pragma unroll
         for (int g = 0; g < FG; ++g) {
@@ -776,6 +804,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
         }
     }
     __syncthreads();
+    PIC_STAMP(12);
     // 5. x pass (axis 0): column c of the window, RB output rows per item, the 2R + 1 rows of the stencil in registers
     constexpr int RB = TX >= 64 ? 16 : 8;
     for (int item = threadIdx.x; item < WC * (TX / RB); item += BLOCK) {
@@ -796,6 +825,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
         }
     }
     __syncthreads();
+    PIC_STAMP(13);
     // 6. y pass (axis 1), decay, 16-byte (fp16: 8-byte) stores of the tile's cells
     T* dst = (T*)a.chem_next;
     constexpr int LO = A - R, LA = LO & ~3, NX = (LO - LA + 4 + 2 * R + 3) / 4;    // aligned float4 reads around the 4 cells
@@ -818,6 +848,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK)) void k_pic_resolve_diffus
         }
         Vec4<T>::st(dst + (int64_t)(x0 + row) * H + y0 + 4 * cg, o);
     }
+    PIC_STAMP(14);
 }
 
 // ---- (re)binning: any order of the agent arrays → a layout with every agent a stayer ---------------------------
@@ -923,7 +954,7 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
         DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
     }
     DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
-    DIE_REQUIRE(p->dep && p->part_gain && p->error && (p->code || p->dep_plane), "%s: null workspace pointer", who);
+    DIE_REQUIRE(p->dep && p->part_gain && p->error && ((p->rim && p->rim_cnt) || p->dep_plane), "%s: null workspace pointer", who);
     return DIE_OK;
 }
 
@@ -932,6 +963,11 @@ static PicLayout pic_layout(const die_pic_layout& L) {
     o.x = L.x; o.y = L.y; o.agent_food = L.agent_food; o.slot = L.slot; o.hhi = L.heading_hi; o.hlo = L.heading_lo;
     o.off = L.off; o.n = L.n; o.s = L.s; o.inc = L.inc;
     return o;
+}
+
+extern "C" int64_t die_pic_rim_cap(int32_t tile_xs, int32_t tile_ys) {
+    if (!pic_shape_ok(tile_xs, tile_ys)) return -1;
+    return (1 << tile_xs) * (1 << tile_ys) >= 4096 ? KbShape<6, 6>::RIM_CAP : KbShape<4, 5>::RIM_CAP;
 }
 
 extern "C" int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys) {
@@ -1062,14 +1098,14 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
                 "die_pic_forward_env_step: plane too large for the 24-bit index arithmetic of the staging loop");
     const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
-    // two launches (one field kernel per tile, fed by the agent kernel's byte per agent) when the caller gave the byte array and
-    // every agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
+    // two launches (one field kernel per tile, fed by the agent kernel's rim lists) when the caller gave the lists and every
+    // agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
     // FAR border of the tile it walks onto
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    const bool two = p->code != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
+    const bool two = p->rim != nullptr && p->rim_cnt != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
                      (int)floorf(reach) + 1 + R <= (TX < TY ? TX : TY);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
-    k.code = two ? p->code : nullptr; k.rim_r = R;
+    k.rim = p->rim; k.rim_cnt = p->rim_cnt; k.rim_cap = (int)die_pic_rim_cap(p->tile_xs, p->tile_ys); k.rim_r = R;
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
     DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK && (1 << k.cs_c) <= DIE_WAVE && (1 << k.cs_f) <= DIE_WAVE,
@@ -1095,7 +1131,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             KbArgs a;
             double wd[2 * 8 + 1];
             die_gaussian_taps(d->diffuse_sigma, wd);
-            a.chem = m->chem; a.chem_next = m->chem_next;
+            a.chem = m->chem; a.chem_next = m->chem_next; a.rim = p->rim; a.rim_cnt = p->rim_cnt;
             a.food_infinite = d->food_infinite; a.keep = (float)(1.0 - (double)d->rate_decay_chem);
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
             a.result = result; a.alive_const = p->N;

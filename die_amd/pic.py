@@ -35,14 +35,16 @@ class PicState:
         self.N = N
         self.meta = [torch.zeros((4, self.NT), dtype=torch.int32, device=dev) for _ in range(2)]     # off, n, s, inc
         self.dep = torch.empty(N, dtype=torch.float32, device=dev)
-        # two-launch form (include/die_hip.h `die_pic.code`): one byte per agent from the agent kernel to the field kernel
+        # two-launch form (include/die_hip.h `die_pic.rim`): per tile a short list from the agent kernel to the field kernels
         self.fused = bool(getattr(env, '_pic_fused', True))
-        self.code = torch.zeros((N + 7) // 4 * 4, dtype=torch.uint8, device=dev) if self.fused else None
+        cap = int(_lib.lib.die_pic_rim_cap(self.xs, self.ys))
+        self.rim = torch.zeros(self.NT * cap, dtype=torch.int32, device=dev) if self.fused else None
+        self.rim_cnt = torch.zeros(self.NT, dtype=torch.int32, device=dev) if self.fused else None
         self._plane_shape = (W, H)
         # three-launch form only (else allocated when a step turns out to need it: a long step on small tiles)
         self._dep_plane = None if self.fused else torch.empty((W, H), dtype=torch.float32, device=dev)
         self.part = torch.zeros(self.NT, dtype=torch.int64, device=dev)
-        self.error = torch.zeros(2 + 16 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
+        self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
         self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
         self.k1_threads = 0          # tuning knob of die_pic (0 = library default)
@@ -62,7 +64,7 @@ class PicState:
         lay[self.cur] = self._layout(cur_tensors, self.meta[self.cur])
         lay[1 - self.cur] = self._layout(other_tensors, self.meta[1 - self.cur])
         return _lib.Pic(self.xs, self.ys, self.N, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
-                        _ptr(self.error), self.k1_threads, stages, _ptr(self.code))
+                        _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_cnt))
 
     def two_launch(self, env, agent) -> bool:
         """Does die_pic_forward_env_step take the two-launch form for this agent?  (The library decides by the same rule;
@@ -122,7 +124,7 @@ class PicState:
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),

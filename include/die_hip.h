@@ -391,7 +391,7 @@ typedef struct die_pic {
     int64_t N;                   /* agents = slots, all alive */
     die_pic_layout layout[2];
     float* dep;                  /* N floats of scratch */
-    float* dep_plane;            /* three-launch form only (may be NULL when code is given and the step qualifies), W*H: per cell the deposit of the highest slot standing
+    float* dep_plane;            /* three-launch form only (may be NULL when rim is given and the step qualifies), W*H: per cell the deposit of the highest slot standing
                                     on it, or 0xFFFFFFFF */
     void* part_gain;             /* die_pic_tiles() 64-bit words: reward partials (also the binning scratch) */
     uint32_t* error;             /* device word, 0 = fine; sticky bits after a step: 1 segment bookkeeping broken, 2 an agent moved
@@ -400,15 +400,18 @@ typedef struct die_pic {
     int32_t stages;              /* 0 = the whole step; else a bit mask of the launches to run (per-kernel timing: bench.py):
                                     1 agent kernel (ONE issue per step: it adds to layout[1 - from].inc), 2 claim resolution +
                                     next offsets, 4 field sweep (two-launch form: the sweep is part of the kernel of bit 2) */
-    /* two-launch form (code != NULL): the agent kernel also leaves ONE BYTE per agent of the layout it writes — where the
-     * agent's new tile lies relative to the tile whose segment holds it, and which borders of that new tile it stands
-     * within the gaussian radius of — and ONE kernel per tile finds, by that byte, the agents of the 9 segments around
-     * it that stand on it or within the radius of it, resolves their claims in LDS, adds the winners' deposits,
-     * diffuses, decays and feeds: no deposit plane, one launch less. */
-    uint8_t* code;               /* N bytes, rounded up to a multiple of 4 (read as 32-bit words); NULL: three launches (claim
-                                    resolution writes dep_plane, die_env.hip's sweep reads it) */
+    /* two-launch form (rim != NULL): the agent kernel also lists, per tile, the agents of the tile's new segment that matter
+     * to ANOTHER tile's field — those that walked off the tile and those that stand within the gaussian radius of a border —
+     * and ONE kernel per tile reads the lists of the 9 tiles around it (fixed places: requested with the first loads),
+     * resolves the claims of its tile + rim in LDS, adds the winners' deposits, diffuses, decays and feeds: no deposit
+     * plane, one launch less.  A list that overflows costs time (that tile's segment is then scanned), never correctness. */
+    uint32_t* rim;               /* die_pic_tiles() * die_pic_rim_cap() words, or NULL: three launches (claim resolution writes
+                                    dep_plane, die_env.hip's sweep reads it) */
+    uint32_t* rim_cnt;           /* die_pic_tiles() words */
 } die_pic;
 
+/* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */
+int64_t die_pic_rim_cap(int32_t tile_xs, int32_t tile_ys);
 /* number of tiles (words per per-tile array), or -1 if the shape is not compiled in */
 int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 /* Bin agents held in any order (die_agents; `heading` in the same order) into layout[into]; both layouts' per-tile words
@@ -416,8 +419,8 @@ int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo, const die_pic* p,
                 int32_t into, void* stream);
 /* GradientAgent/PhysarumAgent.forward (core/agent/gradient.py:96-124) + Env.step (core/env.py:101-131) on binned agents:
- * two launches when p->code is given and floor(|scale| * (max(W, H) - 1)) + 1 + gaussian radius <= tile (forward + move + feeding +
- * re-binning + the byte per agent; per-tile claim resolution + deposit + diffusion + feeding + next offsets + reward), else three
+ * two launches when p->rim is given and floor(|scale| * (max(W, H) - 1)) + 1 + gaussian radius <= tile (forward + move + feeding +
+ * re-binning + rim lists; per-tile claim resolution + deposit + diffusion + feeding + next offsets + reward), else three
  * (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  Same bits.  The
  * agent state (g->heading_* are ignored: layout[from].heading_*) moves with the agents; `act` receives the action in the order
  * of layout[from].  Requires: every slot alive, no agents_die / sense mask, normalised gradient without inertia or noise

@@ -11,7 +11,8 @@ obs = env._get_current_obs
 for _ in range(40):
     obs, *_ = env.step(ag.forward(obs))
 torch.cuda.synchronize()
-st = env._pic.error[2:].cpu().numpy().view(np.uint64).reshape(-1, 8)[:, :6].astype(np.float64)
+raw = env._pic.error[2:].cpu().numpy().view(np.uint64).reshape(-1, 16)
+st = raw[:, :6].astype(np.float64)
 d = np.diff(st, axis=1)
 names = ['tile loads issued, per-tile words, ranges', 'agent streams issued, tiles committed to LDS', 'filter arrivals + barrier', 'chunk loop (wave 0)', 'wave sum + final barrier']
 tot = st[:, 5] - st[:, 0]
@@ -19,3 +20,14 @@ print('s_memtime ticks (shader clock) per tile workgroup, mean / median / p95')
 for i, n in enumerate(names):
     print(f'  {n:46s} {d[:, i].mean():8.1f} {np.median(d[:, i]):8.1f} {np.percentile(d[:, i], 95):8.1f}   {100 * d[:, i].sum() / tot.sum():5.1f} %')
 print(f'  {"total":46s} {tot.mean():8.1f} {np.median(tot):8.1f} {np.percentile(tot, 95):8.1f}')
+
+if raw[:, 8:15].any():
+    st = raw[:, 8:15].astype(np.float64)
+    d = np.diff(st, axis=1)
+    names = ['loads issued, LUT, per-tile words + barrier', 'claims: rim decode, agent loads, LDS atomics', 'window commit + barrier', 'deposits, feeding + barrier',
+             'x pass + barrier', 'y pass, stores issued']
+    tot = st[:, 6] - st[:, 0]
+    print('field kernel (k_pic_resolve_diffuse), wave 0 of every tile workgroup')
+    for i, n in enumerate(names):
+        print(f'  {n:46s} {d[:, i].mean():8.1f} {np.median(d[:, i]):8.1f} {np.percentile(d[:, i], 95):8.1f}   {100 * d[:, i].sum() / tot.sum():5.1f} %')
+    print(f'  {"total":46s} {tot.mean():8.1f} {np.median(tot):8.1f} {np.percentile(tot, 95):8.1f}')

@@ -465,7 +465,7 @@ def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile, fo
         env = die.Env.from_numpy(medium, agents, die.Dynamics(boundary=die.BoundaryCondition(boundary)), sort_every=3, pic=pic,
                                  field_dtype=torch.float16 if f16 else torch.float32)
         env._pic_tile = tile if pic else None
-        # the two forms of the binned step (die_pic.code): one field kernel per tile, or K2 + deposit plane + sweep
+        # the two forms of the binned step (die_pic.rim): one field kernel per tile, or K2 + deposit plane + sweep
         env._pic_fused = form != 'three launches'
         ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
         ag.set_state(dir0)
