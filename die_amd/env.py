@@ -117,8 +117,9 @@ class Env(_EnvBase):
             raise ValueError(f"diffuse_mode={d.diffuse_mode!r}: one of {sorted(_lib.DIFFUSE_MODES)}")
         if d.compat not in ('intended', 'reference'):
             raise ValueError(f"compat={d.compat!r}: 'intended' or 'reference'")
-        if d.op_action_cost not in (linear_action_cost, zero_cost):
-            raise NotImplementedError('op_action_cost must be linear_action_cost or zero_cost on device')
+        if d.op_action_cost not in (linear_action_cost, zero_cost) and d.agents_die:
+            raise NotImplementedError('a custom op_action_cost runs through a host round trip AFTER the step; with agents_die the '
+                                      'lifecycle inside the step would see agent_food before the cost: use linear_action_cost or zero_cost')
         if self._field_size[0] < 2 or self._field_size[1] < 2:
             raise ValueError('field must be at least 2x2')
 
@@ -139,6 +140,8 @@ class Env(_EnvBase):
             self._alloc_sort_buffers()      # no step of a timed loop pays for allocations
         self._fuse_forward = True           # False once die_forward_env_step reports the shape unsupported
         self._pic = None                    # PicState, built at the first eligible step
+        self._pic_status_written = False    # the last step copied the binned step's error word behind its result
+        self._status_word = None
         self._frozen = None                 # compat='reference' with agents_die: (x, y, alive, K) the stale indexer sees
         self._pic_tile = None
         self.medium.sense_mask = None
@@ -201,6 +204,7 @@ class Env(_EnvBase):
         else:
             logging.warning(f'Unfamiliar boundary condition: {d.boundary}!')      # core/env.py:158-161
             boundary = _lib.DIE_BOUNDARY_NONE
+        # (a custom cost operator: the step runs with zero cost, `_apply_custom_cost` subtracts the operator's values afterwards)
         cost = _lib.DIE_COST_LINEAR if d.op_action_cost is linear_action_cost else _lib.DIE_COST_ZERO
         return _lib.Dynamics(d.rate_feed, d.rate_decay_chem, d.diffuse_sigma, boundary, cost, 0.02, 0.01,
                              int(d.food_infinite), int(d.agents_die), int(not self._all_alive), _lib.DIFFUSE_MODES[d.diffuse_mode],
@@ -239,10 +243,33 @@ class Env(_EnvBase):
         _lib.check(_lib.lib.die_medium_deposit_feed_diffuse(C.byref(m), C.byref(d), sp), 'die_medium_deposit_feed_diffuse')
         _lib.check(_lib.lib.die_agents_lifecycle(C.byref(a), sp), 'die_agents_lifecycle')
 
+    def _custom_cost(self, action):
+        """`Dynamics.op_action_cost` as an arbitrary callable (core/env.py:43,209: any CostOperator): evaluated on the host on
+        the (3, N) action in slot order, like `op_food_flow` — a round trip per step.  Returns the (N,) device tensor of costs."""
+        a = action.to_numpy() if hasattr(action, 'to_numpy') else np.asarray(action, dtype=np.float64)
+        burned = np.asarray(self.dynamics.op_action_cost(a), dtype=np.float64).reshape(-1)
+        if burned.shape[0] != self.agents.N:
+            raise ValueError(f'op_action_cost returned {burned.shape[0]} values for {self.agents.N} slots')
+        return torch.from_numpy(burned.astype(np.float32)).to(self.device)
+
+    def _apply_custom_cost(self, burned, result):
+        """agent_food −= burned, reward −= Σ burned (core/env.py:229-243: agent_food += consumed − burned over ALL slots); the
+        step itself ran with zero cost."""
+        A = self.agents
+        A.agent_food -= burned if A.slot is None else burned[A.slot.long()]
+        result[0] -= burned.double().sum()
+
     def step(self, action):
         """core/env.py:101-131 → (obs, reward, terminated, truncated, info)."""
-        result = torch.empty(2, dtype=torch.float64, device=self.device)
+        # sync=True: reward, num_agents and the binned step's error word travel in ONE host copy (die_pic.status_out)
+        res3 = torch.empty(3, dtype=torch.float64, device=self.device) if self._sync else None
+        result = res3[:2] if res3 is not None else torch.empty(2, dtype=torch.float64, device=self.device)
+        self._status_word = res3
+        self._pic_status_written = False
         fused = binned = False
+        burned = None
+        if self.dynamics.op_action_cost not in (linear_action_cost, zero_cost):
+            burned = self._custom_cost(action)
         if self._pic is not None:
             self._pic.flush_lazy()          # an un-read action of the previous binned step: its inputs are about to change
         if self.dynamics.agents_die and self.dynamics.compat == 'reference':
@@ -277,6 +304,8 @@ class Env(_EnvBase):
                        'die_env_step')
         if not binned:
             self._agents_changed()          # a classic step moved the agents in place: the tile order is gone, bin again
+        if burned is not None:
+            self._apply_custom_cost(burned, result)
         self.medium.swap_chem()
         if self.dynamics.op_food_flow is not _identity_food_flow:
             self._food_flow()
@@ -288,7 +317,7 @@ class Env(_EnvBase):
         self.last_result = result
         if not self._sync:
             return self._get_current_obs, result, False, False, {}
-        reward, num_agents = self.read_result(result)
+        reward, num_agents = self.read_result(res3)
         if self.dynamics.agents_die:
             self._all_alive = False
         mean_gain = reward / num_agents if num_agents > 0 else 0.
@@ -296,11 +325,23 @@ class Env(_EnvBase):
         return self._get_current_obs, reward, num_agents == 0, False, info
 
     def read_result(self, result: torch.Tensor) -> Tuple[float, int]:
-        """(reward, num_agents) of a die_step_result buffer (synchronises)."""
+        """(reward, num_agents) of a die_step_result buffer (synchronises).  A 3-word buffer (`Env(sync=True)` builds one per
+        step) carries the tile-binned step's error word behind the result: one host copy instead of two."""
         host = result.cpu()
         if self._pic is not None:
-            self._pic.check()
+            if host.numel() >= 3 and self._pic_status_written:
+                self._pic.raise_for(int(host.view(torch.int64)[2]))
+            elif self._pic.steps_since_check:
+                self._pic.check()
         return float(host[0]), int(host.view(torch.int64)[1])
+
+    def check(self):
+        """Synchronise and raise if the tile-binned step has reported a bookkeeping error since the last check (an agent
+        that moved further than a tile).  `sync=True` steps and `read_result` do this by themselves; loops that never read
+        anything back (`sync=False`, `run`) call it when they want to know."""
+        torch.cuda.synchronize(self.device)
+        if self._pic is not None and self._pic.steps_since_check:
+            self._pic.check()
 
     # ------------------------------------------------------------------ tile-binned step (die_amd/pic.py)
     def _pic_applies(self, action) -> bool:
@@ -335,8 +376,12 @@ class Env(_EnvBase):
         if not self._pic.is_current(self, ag):
             self._pic.bin(self, ag)
             action.rebind(self.agents)
-        _lib.check(self._pic.step(self, ag, action, self._c_dynamics(), result, getattr(self, '_pic_events', None)),
+        status = getattr(self, '_status_word', None)
+        two = self._pic.two_launch(self, ag)
+        _lib.check(self._pic.step(self, ag, action, self._c_dynamics(), result, getattr(self, '_pic_events', None),
+                                  status_out=status.data_ptr() + 16 if status is not None and two else None),
                    'die_pic_forward_env_step')
+        self._pic_status_written = status is not None and two
         ag._forward_consumed(action)
         self.medium.owner_stale = self._mark_owner
         return True
@@ -394,6 +439,8 @@ class Env(_EnvBase):
                 out[i].copy_(res)
         finally:
             self._sync = sync
+        if sync:                        # (an env built with sync=True reads results back anyway: report a broken layout now)
+            self.check()
         return out
 
     @staticmethod

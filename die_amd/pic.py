@@ -51,6 +51,7 @@ class PicState:
         self.cur = 0                 # layout index that holds the agents
         self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
         self.agent = None
+        self.steps_since_check = 0   # binned steps whose error word nobody has read yet
         self.lazy_actions = True     # PhysarumAgent: the step keeps the action in registers, PendingAction re-derives it on demand
         self._lazy_ref = None        # weak reference to the last such action (it must be filled in before its inputs change)
 
@@ -59,12 +60,12 @@ class PicState:
         x, y, af, slot, hh, hl = tensors
         return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hh), _ptr(hl), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
 
-    def _struct(self, cur_tensors, other_tensors, stages: int = 0) -> _lib.Pic:
+    def _struct(self, cur_tensors, other_tensors, stages: int = 0, status_out=None) -> _lib.Pic:
         lay = [None, None]
         lay[self.cur] = self._layout(cur_tensors, self.meta[self.cur])
         lay[1 - self.cur] = self._layout(other_tensors, self.meta[1 - self.cur])
         return _lib.Pic(self.xs, self.ys, self.N, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
-                        _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_cnt))
+                        _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_cnt), status_out)
 
     def two_launch(self, env, agent) -> bool:
         """Does die_pic_forward_env_step take the two-launch form for this agent?  (The library decides by the same rule;
@@ -96,8 +97,11 @@ class PicState:
         return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4])
 
     def bin(self, env, agent):
-        """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset."""
+        """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset.  (The sticky error word is read first
+        — a re-bin would otherwise paper over a broken layout; the library never clears it.)"""
         self.flush_lazy()
+        if self.steps_since_check:
+            self.check()
         A = env.agents
         out = self._out_tensors(env)
         cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo)
@@ -124,14 +128,14 @@ class PicState:
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),
                        'die_pic_action_physarum')
         return rebuild
 
-    def step(self, env, agent, action, dyn, result, events=None):
+    def step(self, env, agent, action, dyn, result, events=None, status_out=None):
         """One step.  `events`: torch.cuda.Event objects (one more than launches: 3 in the two-launch form, 4 in the
         three-launch form) — the launches are then issued one call each (die_pic.stages) with an event between them, so
         that bench.py times each kernel inside real steps.
@@ -148,7 +152,7 @@ class PicState:
         u = None if lazy else C.byref(action.raw_struct())
         two = self.two_launch(env, agent)
         for i, stages in enumerate((0,) if events is None else ((1, 2) if two else (1, 2, 4))):
-            p = self._struct(self.held, out, stages)
+            p = self._struct(self.held, out, stages, status_out if two else None)
             if events is not None:
                 events[i].record()
             rc = _lib.lib.die_pic_forward_env_step(C.byref(m), C.byref(p), self.cur, C.byref(action.g_struct), u, C.byref(dyn),
@@ -158,6 +162,7 @@ class PicState:
         if events is not None:
             events[2 if two else 3].record()
         self.cur = 1 - self.cur
+        self.steps_since_check += 1
         self._adopt(env, agent, out)
         if lazy:
             action._rebuild = self._rebuilder(env, agent, out)
@@ -167,5 +172,11 @@ class PicState:
     def check(self):
         """After a synchronisation: did every agent stay within its tile's neighbourhood?"""
         e = int(self.error[0].item())
+        self.raise_for(e)
+
+    def raise_for(self, e: int):
+        """`e`: the error word as read from the device (here, or with the step result: die_pic.status_out)."""
+        self.steps_since_check = 0
         if e:
+            self.error[:1].zero_()           # the library never clears it: the host does, once it has reported it
             raise RuntimeError(f'tile-binned step: bookkeeping error {e} (an agent moved further than one tile in a step)')

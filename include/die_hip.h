@@ -408,6 +408,8 @@ typedef struct die_pic {
     uint32_t* rim;               /* die_pic_tiles() * die_pic_rim_cap() words, or NULL: three launches (claim resolution writes
                                     dep_plane, die_env.hip's sweep reads it) */
     uint32_t* rim_cnt;           /* die_pic_tiles() words */
+    int64_t* status_out;         /* two-launch form, may be NULL: the step copies *error here next to writing `result` — a caller that
+                                    places it behind its die_step_result reads reward, num_alive and the error word in ONE copy */
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */

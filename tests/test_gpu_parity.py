@@ -636,6 +636,127 @@ def test_configs2_full_size_teacher_forced_step_vs_oracle(die):
     assert abs(reward - want_reward) <= RTOL * np.abs(renv.last_gained).sum() + 1e-9
 
 
+@pytest.mark.parametrize('form', ['two launches', 'three launches'])
+def test_tile_binned_step_with_a_crowd_crossing_one_border(die, form):
+    """Several thousand agents stand in a strip two cells wide along one tile border, all heading across it: more arrivals
+    into one tile than the agent kernel's arrival list holds per round (PIC_LIST_CAP = 1024: it must take a second round,
+    never overflow — the fault of a round-2 experiment build with a shorter list), and more border agents than a rim list
+    of the two-launch form holds (the field kernel must fall back to scanning the segments).  Bit for bit the classic step."""
+    W, H, tile = 192, 192, (6, 6)
+    N = 9000
+    rs = np.random.RandomState(77)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.0)
+    medium[2] = 0.                                          # no gradient: everybody turns ±30° and moves ≈ 1.3 cells ahead
+    crowd = np.arange(N) < 7000
+    agents[0, crowd] = q32((62.0 + 1.8 * rs.rand(crowd.sum())) / (W - 1))       # rows 62..63.8: just below the border at row 64
+    agents[1, crowd] = q32((70.0 + 50.0 * rs.rand(crowd.sum())) / (H - 1))      # all within the tile columns 64..127
+    dir0 = f32(np.where(crowd, 0.0, np.floor(rs.uniform(-np.pi, np.pi, N) / np.radians(30)) * np.radians(30)))
+    outs = []
+    for pic in (True, False):
+        env = die.Env.from_numpy(medium, agents, sort_every=0, pic=pic)
+        env._pic_tile = tile if pic else None
+        env._pic_fused = form != 'three launches'
+        ag = die.PhysarumAgent(max_agents=N, seed=9, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        acts = []
+        for i in range(4):
+            a = ag.forward(obs)
+            obs, rew, _, _, info = env.step(a)
+            acts.append(a.to_numpy())
+            if pic and i == 0:
+                moved = env.agents.to_numpy()
+                assert int((R.cell(moved[0, crowd], W) >= 64).sum()) > 1500, 'the crowd did not cross'
+        if pic:
+            assert env._pic is not None and env._pic.held[0] is env.agents.x and env._pic.two_launch(env, ag) == (form != 'three launches')
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.stack(acts), np.array([rew, info['num_agents']])))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'actions', 'reward'), outs[0], outs[1]):
+        assert np.array_equal(a, b), name
+
+
+def test_device_food_flow_leaves_the_claim_plane_alone(die):
+    """A device food-flow operator (WaveSequence: die_food_flow_wave) after a tile-binned step must not make the env rebuild
+    the claim plane — it never reads it (`c_struct()` defaulted to need_owner=True there, which put N scattered
+    64-bit atomics back into every step).  `medium.owner_stale` is still pending after the step; the state is the classic
+    step's, bit for bit, when somebody does ask."""
+    W, H, N = 192, 192, 6000
+    rs = np.random.RandomState(4)
+    medium, agents = random_state(W, H, N, N, rs)
+    outs = []
+    for pic in (True, False):
+        flow = die.WaveSequence((W, H), dt=0.01).get_flow_operator(scale=0.2, decay=0.1)
+        env = die.Env.from_numpy(medium, agents, die.Dynamics(op_food_flow=flow), sort_every=0, pic=pic)
+        env._pic_tile = (6, 6) if pic else None
+        ag = die.PhysarumAgent(max_agents=N, seed=2, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        obs = env._get_current_obs
+        for _ in range(3):
+            obs, *_ = env.step(ag.forward(obs))
+            if pic:
+                assert env._pic is not None and env._pic.held[0] is env.agents.x
+                assert env.medium.owner_stale is not None, 'the food-flow operator forced a rebuild of the claim plane'
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_custom_action_cost_operator(die):
+    """`Dynamics.op_action_cost` as an arbitrary callable (core/env.py:43,209: any CostOperator) — evaluated on the host on
+    the (3, N) action, subtracted after the step: agent_food, reward and info against the oracle running the same callable;
+    with and without dead slots (they pay too: core/env.py:229-243 works on all N slots)."""
+    def quadratic_cost(action):
+        a = np.asarray(action)
+        return 0.5 * a[2] ** 2 + 3.0 * (np.abs(a[0]) + np.abs(a[1]))
+    for W, H, N, K, tile in ((64, 48, 900, 600, None), (192, 192, 5000, 5000, (6, 6))):
+        rs = np.random.RandomState(W + N)
+        medium, agents = random_state(W, H, N, K, rs)
+        dyn = die.Dynamics(op_action_cost=quadratic_cost)
+        rd = R.RefDynamics(op_action_cost=quadratic_cost, rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)))
+        env, ref = die.Env.from_numpy(medium, agents, dyn, sort_every=0), R.RefEnv(medium, agents, rd)
+        env._pic_tile = tile
+        ag = die.PhysarumAgent(max_agents=N, seed=2, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+        obs = env._get_current_obs
+        for step in range(2):
+            a0, m0 = env.agents.to_numpy(), env.medium.to_numpy()
+            action = ag.forward(obs)
+            obs, reward, _, _, info = env.step(action)
+            ref = R.RefEnv(m0, a0, rd)                       # (the operator needs the action on the host: the forward runs stand-alone)
+            _, want_reward, _, _, want_info = ref.step(applied(action.to_numpy()))
+            ga = env.agents.to_numpy()
+            assert np.allclose(ga[3], ref.agents[3], rtol=RTOL, atol=1e-6)
+            assert abs(reward - want_reward) <= RTOL * (np.abs(ref.last_gained).sum() + quadratic_cost(action.to_numpy()).sum()) + 1e-9
+            assert info['num_agents'] == want_info['num_agents']
+
+
+def test_sync_steps_read_the_error_word_with_the_result(die):
+    """`Env(sync=True)` reads reward, num_agents AND the tile-binned step's error word in one host copy (die_pic.status_out):
+    the word travels behind the die_step_result.  A set bit (here: planted) raises at the step that reports it and is then
+    cleared by the host — the library itself never clears it (the re-bin used to)."""
+    W, H, N = 192, 192, 4000
+    rs = np.random.RandomState(8)
+    medium, agents = random_state(W, H, N, N, rs)
+    env = die.Env.from_numpy(medium, agents, sort_every=0, sync=True)
+    env._pic_tile = (6, 6)
+    ag = die.PhysarumAgent(max_agents=N, seed=2, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    obs = env._get_current_obs
+    obs, reward, _, _, info = env.step(ag.forward(obs))
+    assert env._pic_status_written and info['num_agents'] == N and env._pic.steps_since_check == 0
+    env._pic.error[0] = 2                                   # "an agent moved further than a tile"
+    with pytest.raises(RuntimeError, match='bookkeeping error 2'):
+        env.step(ag.forward(obs))
+    assert int(env._pic.error[0].item()) == 0
+    obs, reward, _, _, info = env.step(ag.forward(env._get_current_obs))      # and the env goes on
+    assert info['num_agents'] == N
+    # loops that read nothing back: Env.check() reports; a re-bin does not swallow the word
+    env2 = die.Env.from_numpy(medium, agents, sort_every=0, sync=False)
+    env2._pic_tile = (6, 6)
+    ag = die.PhysarumAgent(max_agents=N, seed=2, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    obs = env2._get_current_obs
+    obs, *_ = env2.step(ag.forward(obs))
+    env2._pic.error[0] = 1
+    env2.sort_agents()                                      # the tile order is gone: the next binned step re-bins …
+    with pytest.raises(RuntimeError, match='bookkeeping error 1'):
+        env2.step(ag.forward(env2._get_current_obs))        # … and reads the pending word first
+
+
 def test_tile_binned_step_with_a_gradient_agent(die):
     """GradientAgent without inertia / noise (normalised gradient: bounded step) takes the binned path too
     (k_pic_forward_move<T, GRADIENT>): same bits as the classic step."""
@@ -1500,6 +1621,30 @@ def test_neural_automata_forward_parity(die, W, H, kernel_sizes):
         env.step(action)
 
 
+def test_neural_automata_weights_written_in_place_are_seen(die):
+    """The evolution loop loads every candidate through `param.data.view(-1)[:] = …` (core/agent/evo.py is driven that way
+    by evotorch's NEProblem, examples/learning_agents.py): neither `_version` nor `data_ptr()` of the weight changes, so a
+    cache of the uploaded kernels keyed on them would serve the first candidate for ever.  The device forward
+    must follow the weights: two forwards around an in-place write differ, and each matches the oracle for ITS weights."""
+    import torch as th
+    W, H, N = 48, 40, 500
+    rs = np.random.RandomState(3)
+    medium, agents = random_state(W, H, N, N, rs)
+    th.manual_seed(5)
+    ag = die.NeuralAutomataAgent(scale=0.07, deposit=1.5, kernel_sizes=(3, 3))
+    ag.model.init_weights()
+    env = die.Env.from_numpy(medium, agents)
+    first = ag.forward(env._get_current_obs).to_numpy()
+    keys = [(k.weight._version, k.weight.data_ptr()) for k in ag.model.conv_layers()]
+    for k in ag.model.conv_layers():
+        k.weight.data.view(-1)[:] = th.from_numpy(rs.normal(0, 0.3, k.weight.numel()).astype(np.float32))
+    assert keys == [(k.weight._version, k.weight.data_ptr()) for k in ag.model.conv_layers()]      # (the write is invisible to such a key)
+    second = ag.forward(env._get_current_obs).to_numpy()
+    ws = [k.weight.detach().numpy().astype(np.float64) for k in ag.model.conv_layers()]
+    assert np.allclose(second, R.nca_forward((agents, medium), ws, 0.07, 1.5, True), rtol=RTOL, atol=1e-5)
+    assert not np.allclose(first, second, atol=1e-3)
+
+
 def test_conv_stack_against_reference_made_vectors(die, golden_dir):
     """die_conv2d_circular on the inputs / weights of tests/golden/ref_helpers.npz against the outputs the REFERENCE'S
     ConvolutionModel produced for them (tests/golden/make_ref_helper_vectors.py): 1e-5."""
@@ -1611,8 +1756,36 @@ def test_gradient_agent_render_is_the_gradient_field(die):
 
 
 # ------------------------------------------------------------------------------------ batched replicas
-@pytest.mark.parametrize('W,H,R,f16', [(64, 48, 5, False), (256, 128, 3, True)])
-def test_batched_replicas_equal_stand_alone_runs(die, W, H, R, f16):
+def test_batched_replicas_at_the_configs4_grid(die):
+    """BASELINE configs[4]'s grid, 16384x16384 with fp16 field channels, as a BATCH of two replicas on one GPU: at this size
+    BatchedEnv steps every replica with the tile-binned step on its own stream.  Size-independent invariants per replica
+    (every agent alive, reward = change of the agents' food, one owner per occupied cell) and independence of the replicas
+    (different seeds: different rewards)."""
+    from die_amd.batch import BatchedEnv, BatchedPhysarumAgent
+    W = H = 16384
+    benv = BatchedEnv((W, H), die.Dynamics(init_agent_ratio=0.15), replicas=2, seed=11, field_dtype=torch.float16)
+    assert benv.per_replica
+    bag = BatchedPhysarumAgent(benv, seed=3, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+    af0 = [e.agents.agent_food.double().sum().item() for e in benv.envs]
+    res = benv.run(bag, 3)
+    rew, alive = BatchedEnv.read_results(res)
+    for r, e in enumerate(benv.envs):
+        K = e.agents.N
+        assert abs(K / (W * H) - 0.15) < 0.001 and (alive[:, r] == K).all()
+        assert e._pic is not None and e._pic.held[0] is e.agents.x, 'the tile-binned step did not run'
+        e.check()
+        af1 = e.agents.agent_food.double().sum().item()
+        assert abs((af1 - af0[r]) - rew[:, r].sum()) <= 1e-5 * abs(af0[r])
+        own = e.medium.owner_slots()
+        n_occ = int((own >= 0).sum().item())
+        assert 0.85 * K < n_occ <= K and int(own.max().item()) < K
+        del own
+        assert torch.isfinite(e.medium.chem.float()).all() and float(e.medium.chem.float().max()) > 0
+    assert rew[-1, 0] != rew[-1, 1]
+
+
+@pytest.mark.parametrize('W,H,R,f16,per_replica', [(64, 48, 5, False, False), (256, 128, 3, True, False), (192, 128, 3, False, True)])
+def test_batched_replicas_equal_stand_alone_runs(die, W, H, R, f16, per_replica):
     """die_forward_env_step_batch: R replicas in one launch pair.  Replica r must be, bit for bit, the stand-alone
     Env(seed + r) driven by PhysarumAgent(seed + r): fields, agents, headings, rewards — across an epoch wrap of the
     claim plane (33 steps)."""
@@ -1620,7 +1793,9 @@ def test_batched_replicas_equal_stand_alone_runs(die, W, H, R, f16):
     dt = torch.float16 if f16 else torch.float32
     kw = dict(scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
     steps = 33
-    benv = BatchedEnv((W, H), die.Dynamics(init_agent_ratio=0.15), replicas=R, seed=40, field_dtype=dt)
+    # per_replica: the large-world regime (one Env per replica, each on its own stream) forced onto a small world
+    benv = BatchedEnv((W, H), die.Dynamics(init_agent_ratio=0.15), replicas=R, seed=40, field_dtype=dt, per_replica=per_replica)
+    assert benv.per_replica == per_replica
     bag = BatchedPhysarumAgent(benv, seed=7, **kw)
     res = benv.run(bag, steps)
     rew, alive = BatchedEnv.read_results(res)
