@@ -72,7 +72,7 @@ class Pic(C.Structure):
     _fields_ = [('tile_xs', C.c_int32), ('tile_ys', C.c_int32), ('N', C.c_int64), ('layout', PicLayout * 2),
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
-                ('rim', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p)]
+                ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p)]
 
 
 class Batch(C.Structure):

@@ -137,6 +137,18 @@ __device__ __forceinline__ int64_t die_local(const die_geo& g, int gx, int gy) {
     return (int64_t)lx * g.H + ly;
 }
 
+// world cell → row (or column) of the local planes for the TILE-BINNED kernels: the periodic image inside the planes or, for a
+// cell the planes do not hold (an agent that walked out of a decomposed tile's halo), the NEAREST edge — an agent's local
+// cell never jumps, so "an agent moves less than a tile per step" survives the plane's edge (die_local above tries one
+// periodic image and clamps: fine for a lookup, but it sends the first row past the bottom edge to row 0).
+// c in [0, gn), o = global cell of local element 0, n = local extent, gn = world extent
+__device__ __forceinline__ int die_plane_coord(int c, int o, int n, int gn) {
+    int l = c - o;
+    l += l < 0 ? gn : 0;
+    l -= l >= gn ? gn : 0;
+    return l < n ? l : (l - n < gn - l ? n - 1 : 0);
+}
+
 // does this rank account for the agent standing on world cell (gx, gy)?  (ghost-agent decomposition)
 __device__ __forceinline__ bool die_owned(const die_geo& g, int gx, int gy) {
     if (g.own_x1 == 0) return true;

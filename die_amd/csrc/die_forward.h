@@ -133,14 +133,17 @@ struct FwdGlobalMem {
     __device__ __forceinline__ float food_at(int gx, int gy) const { return seen(food, die_local(g, gx, gy)); }
 };
 // … or a tile staged in LDS (die_pic.hip): chem with a margin of the probe reach around the tile, food of the tile itself
-template <typename T>
+template <typename T, bool TILED = false>
 struct FwdTileMem {
     static constexpr bool kSmallOffsets = true;       // the staged margin bounds |sense_offset| far below half the world
-    const T* chem;          // element (gx, gy) at (gx − cx0)·pitch + (gy − cy0)
-    const T* food;          // element (gx, gy) at (gx − fx0)·fpitch + (gy − fy0)
+    const T* chem;          // plane element (lx, ly) at (lx − cx0)·pitch + (ly − cy0)
+    const T* food;          // plane element (lx, ly) at (lx − fx0)·fpitch + (ly − fy0)
     int cx0, cy0, pitch, fx0, fy0, fpitch;
-    __device__ __forceinline__ float chem_at(int gx, int gy) const { return die_ld(chem, (int64_t)((gx - cx0) * pitch + (gy - cy0))); }
-    __device__ __forceinline__ float food_at(int gx, int gy) const { return die_ld(food, (int64_t)((gx - fx0) * fpitch + (gy - fy0))); }
+    die_geo g;              // TILED (the planes are a tile of a decomposed world): world cell → plane element first
+    __device__ __forceinline__ int lx(int gx) const { return TILED ? die_plane_coord(gx, g.ox, g.W, g.gW) : gx; }
+    __device__ __forceinline__ int ly(int gy) const { return TILED ? die_plane_coord(gy, g.oy, g.H, g.gH) : gy; }
+    __device__ __forceinline__ float chem_at(int gx, int gy) const { return die_ld(chem, (int64_t)((lx(gx) - cx0) * pitch + (ly(gy) - cy0))); }
+    __device__ __forceinline__ float food_at(int gx, int gy) const { return die_ld(food, (int64_t)((lx(gx) - fx0) * fpitch + (ly(gy) - fy0))); }
 };
 
 template <typename T, int KIND, bool EXT, class MEM>

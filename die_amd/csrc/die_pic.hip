@@ -90,16 +90,30 @@ struct PicArgs {
     uint32_t* error;                // device word, sticky: bit 0 segment bookkeeping broken, bit 1 an agent jumped further than a
                                     // tile, bit 2 a rim record left the 3×3 neighbourhood
     // two-launch form (die_pic.rim != NULL): per tile the list of its agents that matter to another tile's field kernel —
-    // those that walked off the tile, and those within R cells of one of the borders of the tile they stand on: entry =
-    // position in the tile's segment of layout `out` | code << 24, code = ((ddx + 1)·3 + ddy + 1)·9 + ex·3 + ey (where the
-    // agent's tile lies from here; which of ITS borders are near: 0 low, 1 none, 2 high)
-    uint32_t* rim;                  // [tile·rim_cap + i]
+    // those that walked off the tile, and those within R cells of one of the borders of the tile they stand on.  Entry i of
+    // tile t: a code byte at rim_code[t·rim_cap + i] = ((ddx + 1)·3 + ddy + 1)·9 + ex·3 + ey (where the agent's tile lies from
+    // t; which of ITS borders are near: 0 low, 1 none, 2 high) and a 16-byte record (x, y, slot, deposit bits) at
+    // rim[t·rim_cap + i] — so the reader fetches 2 KB of codes for its 9 lists and ONE 16-byte line per agent that matters
+    // (four 4-byte gathers from the segment arrays per such agent were a quarter of the field kernel's memory requests)
+    uint4* rim;
+    uint8_t* rim_code;
     uint32_t* rim_cnt;              // [tile]: entries the tile had (may exceed rim_cap: the reader then scans the segment)
     int rim_cap, rim_r;             // gaussian radius R = width of the rim
 };
 
-__device__ __forceinline__ int pic_tile_of(const PicArgs& p, uint32_t X, uint32_t Y) {
-    return (die_cell((int64_t)X, p.g.gW) >> p.xs) * p.nty + (die_cell((int64_t)Y, p.g.gH) >> p.ys);
+// plane row / column of the cell an agent stands on.  TILED: the planes are a tile of a decomposed world (die_medium.gW > 0) —
+// every kernel below treats that tile as periodic; what this brings in across its outer edge stays in the outermost cells
+// of the halo, which the ghost-agent decomposition discards anyway (die_amd/dist.py)
+template <bool TILED> __device__ __forceinline__ int pic_row(const die_geo& g, uint32_t X) {
+    const int c = die_cell((int64_t)X, g.gW);
+    return TILED ? die_plane_coord(c, g.ox, g.W, g.gW) : c;
+}
+template <bool TILED> __device__ __forceinline__ int pic_col(const die_geo& g, uint32_t Y) {
+    const int c = die_cell((int64_t)Y, g.gH);
+    return TILED ? die_plane_coord(c, g.oy, g.H, g.gH) : c;
+}
+template <bool TILED> __device__ __forceinline__ int pic_tile_of(const PicArgs& p, uint32_t X, uint32_t Y) {
+    return (pic_row<TILED>(p.g, X) >> p.xs) * p.nty + (pic_col<TILED>(p.g, Y) >> p.ys);
 }
 
 // The 9 index ranges that hold the agents standing on `tile` in layout L: [0] its own stayers, [1..8] the leavers of the
@@ -169,7 +183,7 @@ struct PicStage {
     }
 };
 
-#define PIC_RIM_CAP_MAX 224      // entries of a tile's rim list (k_pic_resolve_diffuse reads 9 lists with 4 loads per thread)
+#define PIC_RIM_CAP_MAX 224      // entries of a tile's rim list (k_pic_resolve_diffuse reads the codes of 9 lists with one word per thread)
 #define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
 static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
 
@@ -186,22 +200,23 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_K1_MINW
 #define PIC_K1_MINW 6
 #endif
-template <typename T, int KIND, bool STAGE, bool ACT, bool RIM>
+template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
     // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)
     f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
     f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
-    f.g = p.g;                            // one copy of the geometry (a single periodic tile: gW == W)
+    f.g = p.g;                            // one copy of the geometry
     extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
     __shared__ uint32_t s_base[9], s_pre[10];
     __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
     __shared__ uint32_t s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
-    __shared__ uint32_t s_rim[RIM ? PIC_RIM_CAP_MAX : 1];         // RIM: this tile's list for the field kernels around it
+    __shared__ __align__(4) uint8_t s_rimc[RIM ? PIC_RIM_CAP_MAX : 4];   // RIM: the codes of this tile's list (flushed as words)
     __shared__ uint32_t s_list[PIC_LIST_CAP];
     __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
+    __shared__ uint32_t s_alv[TILED ? PIC_K1_BLOCK / DIE_WAVE : 1];   // TILED: agents this rank accounts for (die_medium.own_*)
     const int tx = blockIdx.y, ty = blockIdx.x, tile = tx * p.nty + ty;      // (a 2-D grid: no division by a run-time value)
     const int TX = 1 << p.xs, TY = 1 << p.ys, x0 = tx << p.xs, y0 = ty << p.ys;
     const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE, nwaves = blockDim.x / DIE_WAVE;
@@ -246,7 +261,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         const uint32_t j = base0 + pidx;
         pX = p.in.x[j]; pY = p.in.y[j]; pS = p.in.slot[j]; pHh = p.in.hhi[j]; pHl = p.in.hlo[j]; pA = p.in.agent_food[j];
     }
-    FwdTileMem<T> tm;
+    FwdTileMem<T, TILED> tm;
+    tm.g = p.g;
     if (STAGE) {
         T* s_chem = (T*)pic_smem;
         T* s_food = s_chem + rows * pitch;
@@ -261,6 +277,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     }
     PIC_STAMP(2);
     long long gsum = 0;
+    uint32_t nowned = 0;
     // Rounds: the tile's own stayers plus (at most PIC_LIST_CAP per round) the neighbours' leavers that landed here,
     // compacted into s_list first so that the heavy part below runs on full waves.  One round unless a crowd arrives.
     for (uint32_t cb = 0; cb == 0 || cb < ncand; cb += PIC_LIST_CAP) {
@@ -271,13 +288,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             uint32_t j = 0;
             if (c0 == 0) {                                         // loaded above
                 j = cj;
-                hit = chas && pic_tile_of(p, cX, cY) == tile;
+                hit = chas && pic_tile_of<TILED>(p, cX, cY) == tile;
             } else if (c < cend) {
                 const uint32_t idx = own + c;
                 int r = 1;
                 while (idx >= s_pre[r + 1]) ++r;
                 j = s_base[r] + (idx - s_pre[r]);
-                hit = pic_tile_of(p, p.in.x[j], p.in.y[j]) == tile;
+                hit = pic_tile_of<TILED>(p, p.in.x[j], p.in.y[j]) == tile;
             }
             const unsigned long long m = __ballot(hit);
             uint32_t at = 0;
@@ -332,16 +349,18 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
                     Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
                 }
-                const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
+                const int gcx = die_cell((int64_t)X, p.g.gW), gcy = die_cell((int64_t)Y, p.g.gH);      // world cell …
+                const int cx = TILED ? die_plane_coord(gcx, p.g.ox, p.g.W, p.g.gW) : gcx;                // … and where the planes hold it
+                const int cy = TILED ? die_plane_coord(gcy, p.g.oy, p.g.H, p.g.gH) : gcy;
                 const int ntx_ = cx >> p.xs, nty_ = cy >> p.ys;
                 stay = ntx_ == tx && nty_ == ty;
                 // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption
-                const float fnew = (STAGE && stay) ? tm.food_at(cx, cy) : die_ld(food, (int64_t)cx * p.g.H + cy);
+                const float fnew = (STAGE && stay) ? tm.food_at(gcx, gcy) : die_ld(food, (int64_t)cx * p.g.H + cy);
                 const float consumed = p.rate_feed * fnew;
                 const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * sqrtf(o.dx * o.dx + o.dy * o.dy) : 0.f;
                 const float gained = consumed - cost;
                 af += gained;
-                gsum += die_fix(gained);
+                if (!TILED || die_owned(p.g, gcx, gcy)) { gsum += die_fix(gained); ++nowned; }       // (a ghost is its owner's to count)
                 hd = o.heading;
                 dep = o.dep;
                 int ddx = 0, ddy = 0;
@@ -374,7 +393,10 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             const uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
             if (RIM && act && listed) {
                 const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
-                if (at < (uint32_t)p.rim_cap) s_rim[at] = (k & 0xFFFFFFu) | (code << 24);
+                if (at < (uint32_t)p.rim_cap) {
+                    s_rimc[at] = (uint8_t)code;
+                    p.rim[(size_t)tile * p.rim_cap + at] = make_uint4(X, Y, sid, __float_as_uint(dep));
+                }
             }
             if (act) {
                 if (k < on) {
@@ -401,6 +423,10 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     PIC_STAMP(4);
     gsum = die_wave_sum(gsum);
     if (lane == 0) s_gain[threadIdx.x / DIE_WAVE] = gsum;
+    if (TILED) {
+        const long long c = die_wave_sum((long long)nowned);
+        if (lane == 0) s_alv[threadIdx.x / DIE_WAVE] = (uint32_t)c;
+    }
     __syncthreads();
     PIC_STAMP(5);
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
@@ -410,13 +436,19 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     if (RIM) {
         // (a segment too long for the 24-bit positions counts as an overflowing list: the reader scans it)
         const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(s_cnt >> 42) & 0x1FFFFFu;
-        for (uint32_t i = threadIdx.x; i < min(nr, (uint32_t)p.rim_cap); i += blockDim.x) p.rim[(size_t)tile * p.rim_cap + i] = s_rim[i];
+        for (uint32_t i = threadIdx.x; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += blockDim.x)
+            ((uint32_t*)p.rim_code)[((size_t)tile * p.rim_cap) / 4 + i] = ((const uint32_t*)s_rimc)[i];
         if (threadIdx.x == 0) p.rim_cnt[tile] = nr;
     }
     if (threadIdx.x == 0) {
         long long t = 0;
         for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) t += s_gain[i];
         p.part_gain[tile] = t;
+        if (TILED) {
+            long long c = 0;
+            for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) c += s_alv[i];
+            p.part_gain[(size_t)p.ntx * p.nty + tile] = c;  // second half of the array: owned agents per tile
+        }
         const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
         p.out.s[tile] = nfront;
         if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
@@ -544,7 +576,8 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
 struct KbArgs {
     const void* chem;
     void* chem_next;
-    const uint32_t* rim;
+    const uint4* rim;
+    const uint8_t* rim_code;
     const uint32_t* rim_cnt;
     int food_infinite;
     float keep;
@@ -557,15 +590,15 @@ struct KbArgs {
 
 template <int XS, int YS> struct KbShape {
     static constexpr int BLOCK = ((1 << XS) * (1 << YS) >= 4096) ? 512 : 256;
-    static constexpr int NE = 4;                                    // rim-list entries per thread: 9 lists in NE loads
-    static constexpr int RIM_CAP = NE * BLOCK / 9 / 4 * 4;          // 224 / 112
+    static constexpr int NE = 4;                                    // rim-list entries per thread: the 4 code bytes of one word
+    static constexpr int RIM_CAP = NE * BLOCK / 9 / 4 * 4;          // 224 / 112 (a multiple of 4: a word never straddles two lists)
     static_assert(RIM_CAP <= PIC_RIM_CAP_MAX, "the agent kernel's list holds it");
 };
 
 #ifndef PIC_KB_MINW
 #define PIC_KB_MINW 8           // 4 workgroups of 512 threads per CU (A/B: scratch/build_variant.sh)
 #endif
-template <typename T, int XS, int YS, int R>
+template <typename T, int XS, int YS, int R, bool TILED>
 __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_resolve_diffuse(PicArgs p, KbArgs a) {
     constexpr int TX = 1 << XS, TY = 1 << YS, BLOCK = KbShape<XS, YS>::BLOCK;
     constexpr int A = 16 / (int)sizeof(T);                 // cells per 16-byte vector
@@ -621,8 +654,25 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 if ((int)threadIdx.x < o) s_g[threadIdx.x] += s_g[threadIdx.x + o];
                 __syncthreads();
             }
+            long long alive = a.alive_const;
+            if (TILED) {                                    // agents standing on cells this rank accounts for (counted by the agent kernel)
+                const long long g0 = s_g[0];
+                __syncthreads();
+                long long c = 0;
+                for (int i = threadIdx.x; i < NT; i += BLOCK) c += p.part_gain[(size_t)NT + i];
+                s_g[threadIdx.x] = c;
+                __syncthreads();
+                for (int o = BLOCK / 2; o > 0; o >>= 1) {
+                    if ((int)threadIdx.x < o) s_g[threadIdx.x] += s_g[threadIdx.x + o];
+                    __syncthreads();
+                }
+                alive = s_g[0];
+                __syncthreads();
+                if (threadIdx.x == 0) s_g[0] = g0;
+                __syncthreads();
+            }
             if (threadIdx.x == 0) {
-                a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = a.alive_const;
+                a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
                 if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
             }
         }
@@ -646,13 +696,11 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         m_o = p.out.off[t]; m_s = p.out.s[t]; m_n = p.out.n[t]; m_r = a.rim_cnt[t];
         if (m_s > m_n) m_s = m_n = 0;                       // (broken bookkeeping — never loop over garbage)
     }
-    // rim entry e of the flattened 9 × CAPR: list e / CAPR, entry e % CAPR (whether it exists is known once the counts are here)
-    auto rim_load = [&](int m) {
-        const int e = (int)threadIdx.x + m * BLOCK, l = e / CAPR, i = e - l * CAPR;
-        return l < 9 ? a.rim[(size_t)ring_tile(l) * CAPR + i] : 0u;
-    };
-    static_assert(NE == 4, "four named registers");
-    const uint32_t re0 = rim_load(0), re1 = rim_load(1), re2 = rim_load(2), re3 = rim_load(3);
+    // the codes of rim entries 4·tid .. 4·tid + 3 of the flattened 9 × CAPR (list e / CAPR, entry e % CAPR; whether an entry
+    // exists is known once the counts are here)
+    static_assert(NE == 4 && CAPR % 4 == 0 && 9 * CAPR <= 4 * BLOCK, "one word of codes per thread");
+    const int rl = 4 * (int)threadIdx.x / CAPR, ri = 4 * (int)threadIdx.x - rl * CAPR;
+    const uint32_t rcodes = rl < 9 ? ((const uint32_t*)a.rim_code)[((size_t)ring_tile(rl) * CAPR + ri) / 4] : 0u;
     constexpr int NCV = (WR * NV + BLOCK - 1) / BLOCK;
     static_assert(NCV <= 3, "three window vectors per thread at most");       // (named registers: as an array they went to scratch)
     auto window_load = [&](int q) {
@@ -703,26 +751,26 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     const uint32_t own0 = s_own[0], nown = s_own[1];
     // window cell of an agent standing on the tile at (ux, uy) tiles from d; 0xFFFFFFFF: outside the window
     auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
-        const int cx = die_cell((int64_t)X, p.g.gW), cy = die_cell((int64_t)Y, p.g.gH);
+        const int cx = pic_row<TILED>(p.g, X), cy = pic_col<TILED>(p.g, Y);
         const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
         return (r >= 0 && r < WR && c >= 0 && c < WC) ? (uint32_t)(r * WC + c) | ((uint32_t)r << 16) : 0xFFFFFFFFu;   // (row kept: no division later)
     };
     static_assert(WR * WC < (1 << 16) && WR < (1 << 15), "window cell and row in one word");
-    // a rim entry → (agent index, tile code), or 0xFFFFFFFF when it does not exist / does not matter here
-    auto rim_decode = [&](int m, uint32_t ent, uint32_t& uc) {
-        const int e = (int)threadIdx.x + m * BLOCK, l = e / CAPR, i = e - l * CAPR;
+    // code byte m of this thread's word → where the record lies and the tile code, or 0xFFFFFFFF when the entry does not
+    // exist / does not matter here
+    auto rim_decode = [&](int m, uint32_t& uc) {
         uc = 0xFFu;
-        if (l >= 9 || (uint32_t)i >= s_rn[l] || s_rn[l] > (uint32_t)CAPR) return 0xFFFFFFFFu;
-        const uint32_t code = ent >> 24, k = ent & 0xFFFFFFu;
-        if (code >= 81u || k >= s_n[l]) return 0xFFFFFFFFu;
-        uc = s_lut[l * 81 + code];
-        return uc == 0xFFu ? 0xFFFFFFFFu : s_off[l] + k;
+        if (rl >= 9 || (uint32_t)(ri + m) >= s_rn[rl] || s_rn[rl] > (uint32_t)CAPR) return 0xFFFFFFFFu;
+        const uint32_t code = (rcodes >> (8 * m)) & 255u;
+        if (code >= 81u) return 0xFFFFFFFFu;
+        uc = s_lut[rl * 81 + code];
+        return uc == 0xFFu ? 0xFFFFFFFFu : (uint32_t)(ri + m);
     };
     // a tile whose list overflowed: every agent of its segment that stands in the window (for d itself: its leavers only)
     auto scan_segment = [&](int l, bool apply) {
         const uint32_t lo = l == 0 ? own0 + nown : s_off[l], hi = s_off[l] + s_n[l];
         for (uint32_t j = lo + threadIdx.x; j < hi; j += BLOCK) {
-            const int cx = die_cell((int64_t)p.out.x[j], p.g.gW), cy = die_cell((int64_t)p.out.y[j], p.g.gH);
+            const int cx = pic_row<TILED>(p.g, p.out.x[j]), cy = pic_col<TILED>(p.g, p.out.y[j]);
             int rr = cx - x0, rc = cy - y0;                 // periodic distance to the tile's origin
             rr = rr > W / 2 ? rr - W : (rr < -(W / 2) ? rr + W : rr);
             rc = rc > H / 2 ? rc - H : (rc < -(H / 2) ? rc + H : rc);
@@ -745,12 +793,20 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     uint32_t cw[2 + NE], cs[2 + NE], cd[2 + NE];
     {
         uint32_t X[2 + NE], Y[2 + NE], uc[NE];
-        const uint32_t rj[NE] = {rim_decode(0, re0, uc[0]), rim_decode(1, re1, uc[1]), rim_decode(2, re2, uc[2]), rim_decode(3, re3, uc[3])};
+        const uint32_t rj[NE] = {rim_decode(0, uc[0]), rim_decode(1, uc[1]), rim_decode(2, uc[2]), rim_decode(3, uc[3])};
+        const uint4* rrec = a.rim + (size_t)ring_tile(rl < 9 ? rl : 0) * CAPR;
 #pragma unroll
         for (int u = 0; u < 2 + NE; ++u) {
-            const uint32_t j = u < 2 ? (threadIdx.x + u * BLOCK < nown ? own0 + threadIdx.x + u * BLOCK : 0xFFFFFFFFu) : rj[u - 2];
             cw[u] = 0xFFFFFFFFu; cs[u] = 0u; cd[u] = 0u; X[u] = Y[u] = 0u;
-            if (j != 0xFFFFFFFFu) { X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[u] = p.out.slot[j] + 1u; cd[u] = __float_as_uint(p.dep[j]); cw[u] = 0u; }
+            if (u < 2) {
+                if (threadIdx.x + u * BLOCK < nown) {
+                    const uint32_t j = own0 + threadIdx.x + u * BLOCK;
+                    X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[u] = p.out.slot[j] + 1u; cd[u] = __float_as_uint(p.dep[j]); cw[u] = 0u;
+                }
+            } else if (rj[u - 2] != 0xFFFFFFFFu) {
+                const uint4 q = rrec[rj[u - 2]];
+                X[u] = q.x; Y[u] = q.y; cs[u] = q.z + 1u; cd[u] = q.w; cw[u] = 0u;
+            }
         }
         // (the food tile is needed last: requested behind the agents' data — loads return in order)
         if (!a.food_infinite) {
@@ -855,6 +911,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 // ---- (re)binning: any order of the agent arrays → a layout with every agent a stayer ---------------------------
 struct PicBinArgs {
     die_geo g;
+    int tiled;                      // the planes are a tile of a decomposed world: bin by the plane cell (pic_row / pic_col)
     int64_t N;
     int nty, xs, ys;
     const uint32_t *x, *y, *slot;
@@ -870,7 +927,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_hist(PicBinArgs a, uint32_t* 
         const int64_t n = b + threadIdx.x;
         const bool active = n < a.N;
         uint32_t key = 0;
-        if (active) key = (uint32_t)((die_cell((int64_t)a.x[n], a.g.gW) >> a.xs) * a.nty + (die_cell((int64_t)a.y[n], a.g.gH) >> a.ys));
+        if (active) key = a.tiled ? (uint32_t)((pic_row<true>(a.g, a.x[n]) >> a.xs) * a.nty + (pic_col<true>(a.g, a.y[n]) >> a.ys))
+                                  : (uint32_t)((pic_row<false>(a.g, a.x[n]) >> a.xs) * a.nty + (pic_col<false>(a.g, a.y[n]) >> a.ys));
         wave_grouped_add<false>(hist, key, active);
     }
 }
@@ -908,7 +966,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
         const bool active = n < a.N;
         const uint32_t X = active ? a.x[n] : 0u, Y = active ? a.y[n] : 0u;
         uint32_t key = 0;
-        if (active) key = (uint32_t)((die_cell((int64_t)X, a.g.gW) >> a.xs) * a.nty + (die_cell((int64_t)Y, a.g.gH) >> a.ys));
+        if (active) key = a.tiled ? (uint32_t)((pic_row<true>(a.g, X) >> a.xs) * a.nty + (pic_col<true>(a.g, Y) >> a.ys))
+                                  : (uint32_t)((pic_row<false>(a.g, X) >> a.xs) * a.nty + (pic_col<false>(a.g, Y) >> a.ys));
         const uint32_t j = wave_grouped_add<true>(a.cursor, key, active);
         if (!active) continue;
         a.out.x[j] = X;
@@ -940,7 +999,6 @@ static bool pic_shape_ok(int xs, int ys) { return (xs == 6 && ys == 6) || (xs ==
 
 static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
     DIE_REQUIRE(m && p, "%s: null argument", who);
-    DIE_REQUIRE(m->gW <= 0, "%s: periodic single-tile planes only", who);
     DIE_REQUIRE(pic_shape_ok(p->tile_xs, p->tile_ys), "%s: tile shape 2^%d x 2^%d is not compiled in (64x64, 32x128, 32x64, 16x32)", who,
                 p->tile_xs, p->tile_ys);
     const int TX = 1 << p->tile_xs, TY = 1 << p->tile_ys;
@@ -954,7 +1012,7 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
         DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
     }
     DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
-    DIE_REQUIRE(p->dep && p->part_gain && p->error && ((p->rim && p->rim_cnt) || p->dep_plane), "%s: null workspace pointer", who);
+    DIE_REQUIRE(p->dep && p->part_gain && p->error && ((p->rim && p->rim_code && p->rim_cnt) || p->dep_plane), "%s: null workspace pointer", who);
     return DIE_OK;
 }
 
@@ -989,7 +1047,7 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
     hipError_t e = hipMemsetAsync(hist, 0, (size_t)NT * 4, s);
     if (e != hipSuccess) { die_set_error("die_pic_bin: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
     PicBinArgs b;
-    b.g = die_geo_of(m); b.N = a->N; b.nty = m->H >> p->tile_ys; b.xs = p->tile_xs; b.ys = p->tile_ys;
+    b.g = die_geo_of(m); b.tiled = m->gW > 0; b.N = a->N; b.nty = m->H >> p->tile_ys; b.xs = p->tile_xs; b.ys = p->tile_ys;
     b.x = a->x; b.y = a->y; b.slot = a->slot; b.agent_food = a->agent_food; b.hhi = heading_hi; b.hlo = heading_lo;
     b.out = pic_layout(p->layout[into]); b.cursor = cursor;
     int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
@@ -1012,17 +1070,17 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
     }
 }
 
-template <typename T, bool STAGE, bool RIM>
+template <typename T, bool STAGE, bool RIM, bool TILED = false>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
     const dim3 grid(k.nty, k.ntx);
-    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM><<<grid, block, lds, s>>>(f, k);
-    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true, RIM><<<grid, block, lds, s>>>(f, k);
-    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false, RIM><<<grid, block, lds, s>>>(f, k);
+    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, TILED><<<grid, block, lds, s>>>(f, k);
+    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true, RIM, TILED><<<grid, block, lds, s>>>(f, k);
+    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false, RIM, TILED><<<grid, block, lds, s>>>(f, k);
 }
 
 int die_gaussian_taps(float sigma, double* w);             // die_env.hip (scipy.ndimage._gaussian_kernel1d); w holds 2·8 + 1 taps
 
-template <typename T, int XS, int YS>
+template <typename T, int XS, int YS, bool TILED>
 static void launch_resolve_diffuse(const PicArgs& k, const KbArgs& a, int R, hipStream_t s) {
     constexpr int TX = 1 << XS, TY = 1 << YS, A = 16 / (int)sizeof(T), CP = TY + 2 * A;
     const int WR = TX + 2 * R, WC = TY + 2 * R;
@@ -1030,19 +1088,19 @@ static void launch_resolve_diffuse(const PicArgs& k, const KbArgs& a, int R, hip
     const dim3 grid(k.nty, k.ntx + 1);
     constexpr int B = KbShape<XS, YS>::BLOCK;
     switch (R) {
-        case 1: k_pic_resolve_diffuse<T, XS, YS, 1><<<grid, B, lds, s>>>(k, a); break;
-        case 2: k_pic_resolve_diffuse<T, XS, YS, 2><<<grid, B, lds, s>>>(k, a); break;
-        case 3: k_pic_resolve_diffuse<T, XS, YS, 3><<<grid, B, lds, s>>>(k, a); break;
-        default: k_pic_resolve_diffuse<T, XS, YS, 4><<<grid, B, lds, s>>>(k, a); break;
+        case 1: k_pic_resolve_diffuse<T, XS, YS, 1, TILED><<<grid, B, lds, s>>>(k, a); break;
+        case 2: k_pic_resolve_diffuse<T, XS, YS, 2, TILED><<<grid, B, lds, s>>>(k, a); break;
+        case 3: k_pic_resolve_diffuse<T, XS, YS, 3, TILED><<<grid, B, lds, s>>>(k, a); break;
+        default: k_pic_resolve_diffuse<T, XS, YS, 4, TILED><<<grid, B, lds, s>>>(k, a); break;
     }
 }
 
-template <typename T>
+template <typename T, bool TILED>
 static void launch_resolve_diffuse_shape(int xs, int ys, const PicArgs& k, const KbArgs& a, int R, hipStream_t s) {
-    if (xs == 6 && ys == 6) launch_resolve_diffuse<T, 6, 6>(k, a, R, s);
-    else if (xs == 5 && ys == 7) launch_resolve_diffuse<T, 5, 7>(k, a, R, s);
-    else if (xs == 5 && ys == 6) launch_resolve_diffuse<T, 5, 6>(k, a, R, s);
-    else launch_resolve_diffuse<T, 4, 5>(k, a, R, s);
+    if (xs == 6 && ys == 6) launch_resolve_diffuse<T, 6, 6, TILED>(k, a, R, s);
+    else if (xs == 5 && ys == 7) launch_resolve_diffuse<T, 5, 7, TILED>(k, a, R, s);
+    else if (xs == 5 && ys == 6) launch_resolve_diffuse<T, 5, 6, TILED>(k, a, R, s);
+    else launch_resolve_diffuse<T, 4, 5, TILED>(k, a, R, s);
 }
 
 extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
@@ -1061,7 +1119,9 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     }
     DIE_REQUIRE(d->cost == DIE_COST_LINEAR || d->cost == DIE_COST_ZERO, "die_pic_forward_env_step: bad cost operator %d", d->cost);
     const int TX = 1 << p->tile_xs, TY = 1 << p->tile_ys;
-    const float reach = fabsf(g->scale) * (float)((m->W > m->H ? m->W : m->H) - 1);     // cells per step, at most
+    const bool tiled = m->gW > 0;                           // a decomposed world's tile: lengths are fractions of the WORLD
+    const int worldmax = tiled ? (m->gW > m->gH ? m->gW : m->gH) : (m->W > m->H ? m->W : m->H);
+    const float reach = fabsf(g->scale) * (float)(worldmax - 1);     // cells per step, at most
     if (!(reach <= (float)((TX < TY ? TX : TY) - 1))) {
         die_set_error("die_pic_forward_env_step: a step of %.1f cells does not stay within the neighbouring %dx%d tiles", (double)reach, TX, TY);
         return DIE_ERR_UNSUPPORTED;
@@ -1087,7 +1147,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // K1 stages chem of the tile ± the probe reach in LDS when that fits: an agent's probe cell lies at most
     // floor(|sense_offset|·(size − 1)) + 1 cells from its own cell, the gradient taps one further
     const int esz = m->dtype == DIE_F32 ? 4 : 2, V = 16 / esz;
-    int P = (int)floorf(fabsf(g->sense_offset) * (float)((m->W > m->H ? m->W : m->H) - 1)) + 2;
+    int P = (int)floorf(fabsf(g->sense_offset) * (float)(worldmax - 1)) + 2;
     P = (P + V - 1) / V * V;
     const bool stage = P <= PIC_MAX_MARGIN;
     k.margin = stage ? P : 0;
@@ -1102,10 +1162,14 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
     // FAR border of the tile it walks onto
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    const bool two = p->rim != nullptr && p->rim_cnt != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
+    const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
                      (int)floorf(reach) + 1 + R <= (TX < TY ? TX : TY);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
-    k.rim = p->rim; k.rim_cnt = p->rim_cnt; k.rim_cap = (int)die_pic_rim_cap(p->tile_xs, p->tile_ys); k.rim_r = R;
+    if (tiled && !(two && stage)) {
+        die_set_error("die_pic_forward_env_step: a decomposed world's tile runs the two-launch form with staged tiles only (probe reach %d, radius %d)", P, R);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    k.rim = (uint4*)p->rim; k.rim_code = p->rim_code; k.rim_cnt = p->rim_cnt; k.rim_cap = (int)die_pic_rim_cap(p->tile_xs, p->tile_ys); k.rim_r = R;
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
     DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK && (1 << k.cs_c) <= DIE_WAVE && (1 << k.cs_f) <= DIE_WAVE,
@@ -1113,7 +1177,10 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s); \
                                        else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s); } while (0)
-        if (m->dtype == DIE_F32) {
+        if (tiled) {
+            if (m->dtype == DIE_F32) launch_forward_move<float, true, true, true>(g->kind, f, k, NT, block, lds, s);
+            else launch_forward_move<__half, true, true, true>(g->kind, f, k, NT, block, lds, s);
+        } else if (m->dtype == DIE_F32) {
             if (stage) DIE_PIC_K1(float, true, lds);
             else DIE_PIC_K1(float, false, 0);
         } else {
@@ -1124,19 +1191,22 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     }
     if (two) {
         if (stages & 2) {                                   // (bit 2 alone: nothing — the sweep is part of this kernel)
-            if (!fused_step_shape_ok(m, d)) {
+            if (!tiled && !fused_step_shape_ok(m, d)) {
                 die_set_error("die_pic_forward_env_step: only for periodic planes with H %% 4 == 0 and gaussian radius 1..4");
                 return DIE_ERR_UNSUPPORTED;
             }
             KbArgs a;
             double wd[2 * 8 + 1];
             die_gaussian_taps(d->diffuse_sigma, wd);
-            a.chem = m->chem; a.chem_next = m->chem_next; a.rim = p->rim; a.rim_cnt = p->rim_cnt;
+            a.chem = m->chem; a.chem_next = m->chem_next; a.rim = (const uint4*)p->rim; a.rim_code = p->rim_code; a.rim_cnt = p->rim_cnt;
             a.food_infinite = d->food_infinite; a.keep = (float)(1.0 - (double)d->rate_decay_chem);
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
             a.result = result; a.alive_const = p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
-            if (m->dtype == DIE_F32) launch_resolve_diffuse_shape<float>(p->tile_xs, p->tile_ys, k, a, R, s);
-            else launch_resolve_diffuse_shape<__half>(p->tile_xs, p->tile_ys, k, a, R, s);
+            if (tiled) {
+                if (m->dtype == DIE_F32) launch_resolve_diffuse_shape<float, true>(p->tile_xs, p->tile_ys, k, a, R, s);
+                else launch_resolve_diffuse_shape<__half, true>(p->tile_xs, p->tile_ys, k, a, R, s);
+            } else if (m->dtype == DIE_F32) launch_resolve_diffuse_shape<float, false>(p->tile_xs, p->tile_ys, k, a, R, s);
+            else launch_resolve_diffuse_shape<__half, false>(p->tile_xs, p->tile_ys, k, a, R, s);
         }
         DIE_CHECK_LAUNCH("die_pic_forward_env_step");
         return DIE_OK;

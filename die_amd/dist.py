@@ -313,7 +313,8 @@ class DistEnv:
     def __init__(self, world: Tuple[int, int], grid: Tuple[int, int], dynamics=None, *, probe_reach: int,
                  capacity: Optional[int] = None, device=None, group=None, field_dtype=torch.float32,
                  seed: int = 0, init: bool = True, sort_every: int = 8, overlap: bool = True,
-                 migrate_every: int = 1, max_step_cells: float = 2.0, ghosts: bool = False, ghost_headroom: float = 2.0):
+                 migrate_every: int = 1, max_step_cells: float = 2.0, ghosts: bool = False, ghost_headroom: float = 2.0,
+                 pic: bool = True):
         from . import _lib
         from .data_init import DataInitializer
         from .device_array import DeviceAgents, DeviceMedium
@@ -346,8 +347,28 @@ class DistEnv:
             if (hx and 2 * hx > world[0] // grid[0]) or (hy and 2 * hy > world[1] // grid[1]):
                 raise ValueError(f'ghost halo {(hx, hy)} needs tiles of at least twice that size (tile '
                                  f'{(world[0] // grid[0], world[1] // grid[1])}): lower migrate_every')
+            # tile-binned step on the padded tile (die_amd/pic.py; the N = 1 step on a padded tile): the planes must split
+            # into whole tiles — a deeper halo is always valid, so it is rounded up to the next fit of the largest shape
+            self._pic_tile = None
+            if pic:
+                from .pic import TILE_SHAPES
+                for xs, ys in TILE_SHAPES:
+                    TX, TY = 1 << xs, 1 << ys
+                    fx, fy = hx, hy
+                    while fx and (world[0] // grid[0] + 2 * fx) % TX:
+                        fx += 1
+                    while fy and ((world[1] // grid[1] + 2 * fy) % TY or (world[1] // grid[1] + 2 * fy) % 4):
+                        fy += 1
+                    Wp, Hp = world[0] // grid[0] + 2 * fx, world[1] // grid[1] + 2 * fy
+                    if Wp % TX or Hp % TY or Wp // TX < 3 or Hp // TY < 3 or 2 * fx > world[0] // grid[0] or 2 * fy > world[1] // grid[1]:
+                        continue
+                    if fx - hx > max(hx // 4, TX // 2) or fy - hy > max(hy // 4, TY // 2):      # (not at the price of much more halo)
+                        continue
+                    hx, hy, self._pic_tile = fx, fy, (xs, ys)
+                    break
             halo = (hx, hy)
         else:
+            self._pic_tile = None
             halo = self.band + int(probe_reach) + 1 + R
             while (world[1] // grid[1] + 2 * halo) % 4:                    # die_diffuse_decay_tile needs H % 4 == 0
                 halo += 1
@@ -361,6 +382,9 @@ class DistEnv:
         if self.ghosts:
             self.medium.own = (g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi)
         self._ghosts_fresh = False
+        self._pic = None                 # PicState (die_amd/pic.py), built at the first step that qualifies
+        self._pic_off = False            # the library refused the binned step for this configuration once
+        self.pic_steps = 0               # steps taken by the tile-binned path (tests, bench)
         self._ghost_headroom = float(ghost_headroom)
         self._owned = None
         self._profile, self._prof = os.environ.get('DIE_DIST_PROFILE', '0') == '1', {}
@@ -572,8 +596,18 @@ class DistEnv:
             self._refresh_ghosts(action)
         sp = stream_ptr(self.device)
         d = self._c_dynamics()
-        M.next_epoch()
         result = torch.empty(2, dtype=torch.float64, device=self.device)
+        if self._pic_applies(action) and self._pic_step(action, d, result):
+            M.swap_chem()
+            self._food_flow()
+            self._steps += 1
+            if self._steps % self.migrate_every == 0:
+                self._refresh_ghosts(action, after_step=True)
+            self.last_result = result
+            return self._get_current_obs, result
+        if self._pic is not None:
+            self._pic_void()                # a classic step moves the agents in place: the tile order is gone
+        M.next_epoch()
         ws, wsn = _ptr(self._workspace), self._workspace.numel()
         second = not self._all_alive
         if A.N > 0:
@@ -613,6 +647,67 @@ class DistEnv:
             self.sort_agents()
         self.last_result = result
         return self._get_current_obs, result
+
+    # -- tile-binned step on the padded tile (die_amd/pic.py, csrc/die_pic.hip TILED): a rank's step is the N = 1 step ------
+    def _pic_applies(self, action) -> bool:
+        from .device_array import PendingAction
+        from .env import BoundaryCondition
+        if self._pic_tile is None or self._pic_off or not self.ghosts or not self._all_alive or self.agents.N <= 0:
+            return False
+        if not (isinstance(action, PendingAction) and action.pending and action.agents is self.agents and action.medium is self.medium):
+            return False
+        ag, dyn, g = action.agent, self.dynamics, self.geo
+        if dyn.agents_die or not isinstance(dyn.boundary, BoundaryCondition) or not 1 <= self.R <= 4:
+            return False
+        if not (ag._normalized and ag._inertia == 0 and ag._noise_scale == 0 and ag._step_base is None and ag._prev_grad is None
+                and ag._turn_sign is None):
+            return False
+        TX, TY = 1 << self._pic_tile[0], 1 << self._pic_tile[1]
+        wmax = max(g.gW, g.gH) - 1
+        reach = float(np.float32(abs(ag._scale)) * np.float32(wmax))
+        probe = int(np.floor(float(np.float32(abs(ag._sense_offset_scale)) * np.float32(wmax)))) + 2
+        vec = 4 if self.medium.dtype == torch.float32 else 8
+        return int(reach) + 1 + self.R <= min(TX, TY) and (probe + vec - 1) // vec * vec <= 24
+
+    def _pic_void(self):
+        if self._pic is not None:
+            self._pic.flush_lazy()
+            self._pic.held = None
+
+    def _pic_step(self, action, d, result) -> bool:
+        from .pic import PicState
+        lib, ag = self._lib, action.agent
+        self._check_reach(action)
+        self._check_seed(int(action.g_struct.seed))
+        if self._pic is None:
+            self._pic = PicState(self, self._pic_tile)
+        if not self._pic.is_current(self, ag):
+            self._pic.bin(self, ag)
+            action.rebind(self.agents)
+        rc = self._pic.step(self, ag, action, d, result)
+        if rc == -3:                         # DIE_ERR_UNSUPPORTED: nothing was launched; the classic step takes over for good
+            self._pic_off = True
+            self._pic_void()
+            return False
+        lib.check(rc, 'die_pic_forward_env_step')
+        ag._forward_consumed(action)
+        self.medium.owner_stale = self._mark_owner
+        self.pic_steps += 1
+        return True
+
+    def _mark_owner(self):
+        """Rebuild the claim plane ('agents' channel) of the padded tile from the local agents after tile-binned steps."""
+        from .device_array import stream_ptr
+        M = self.medium
+        M.next_epoch()
+        m, a = M.c_struct(need_owner=False), self._struct(self.agents)
+        self._lib.check(self._lib.lib.die_agents_mark_owner(C.byref(m), C.byref(a), stream_ptr(self.device)), 'die_agents_mark_owner')
+
+    def check(self):
+        """Synchronise; raise if the tile-binned step reported a bookkeeping error since the last check."""
+        torch.cuda.synchronize(self.device)
+        if self._pic is not None and self._pic.steps_since_check:
+            self._pic.check()
 
     def _check_seed(self, seed: int):
         """A ghost must draw what its original draws: every rank's Agent needs the same seed (once per seed value)."""
@@ -665,6 +760,7 @@ class DistEnv:
     def _refresh_ghosts(self, action, after_step: bool = False):
         """Re-seat owners, ghosts and the chem / food halos (see _step_ghost)."""
         from .device_array import PendingAction
+        self._pic_void()                    # arrays are edited in place below: an un-read lazy action first, then no tile order
         # a consumed action, or one whose forward() has not run yet, holds nothing worth sending
         self._send_action = not after_step and not (isinstance(action, PendingAction) and action.pending)
         if self._send_action and action.data.shape[1] < self.capacity:
@@ -1048,6 +1144,7 @@ class DistEnv:
     def sort_agents(self):
         """Bucket-sort the local agent arrays (die_agents_sort), attached Agent state included."""
         from .device_array import _ptr, stream_ptr
+        self._pic_void()
         lib, A = self._lib, self.agents
         cap = self.capacity
         if self._shadow is None:

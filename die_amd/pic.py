@@ -25,25 +25,32 @@ def pick_tile(W: int, H: int, reach_cells: float) -> Optional[Tuple[int, int]]:
 
 
 class PicState:
+    """`env`: a die_amd.Env, or a die_amd.dist.DistEnv in ghost-agent mode (its planes are a padded tile of the world, its agent
+    arrays hold `capacity` entries of which the first `env.agents.N` are agents: the buffers here are sized by the arrays,
+    the count is read at every call)."""
+
     def __init__(self, env, tile: Tuple[int, int]):
         self.xs, self.ys = tile
-        W, H = env._field_size
+        W, H = env.medium.W, env.medium.H
         self.NT = int(_lib.lib.die_pic_tiles(W, H, self.xs, self.ys))
         if self.NT <= 0:
             raise ValueError(f'tile shape 2^{tile} is not available')
-        dev, N = env.device, env.agents.N
-        self.N = N
+        dev, N = env.device, int(env.agents.x.numel())
+        self.cap = N
         self.meta = [torch.zeros((4, self.NT), dtype=torch.int32, device=dev) for _ in range(2)]     # off, n, s, inc
         self.dep = torch.empty(N, dtype=torch.float32, device=dev)
         # two-launch form (include/die_hip.h `die_pic.rim`): per tile a short list from the agent kernel to the field kernels
         self.fused = bool(getattr(env, '_pic_fused', True))
         cap = int(_lib.lib.die_pic_rim_cap(self.xs, self.ys))
-        self.rim = torch.zeros(self.NT * cap, dtype=torch.int32, device=dev) if self.fused else None
+        self.rim = torch.zeros((self.NT * cap, 4), dtype=torch.int32, device=dev) if self.fused else None
+        self.rim_code = torch.zeros(self.NT * cap, dtype=torch.uint8, device=dev) if self.fused else None
         self.rim_cnt = torch.zeros(self.NT, dtype=torch.int32, device=dev) if self.fused else None
         self._plane_shape = (W, H)
+        self._world_shape = (env.medium.world[0], env.medium.world[1]) if env.medium.world is not None else (W, H)
+        self._n_agents = int(env.agents.N)
         # three-launch form only (else allocated when a step turns out to need it: a long step on small tiles)
         self._dep_plane = None if self.fused else torch.empty((W, H), dtype=torch.float32, device=dev)
-        self.part = torch.zeros(self.NT, dtype=torch.int64, device=dev)
+        self.part = torch.zeros(2 * self.NT, dtype=torch.int64, device=dev)       # reward partials | owned agents (decomposed tiles)
         self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
         self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
@@ -64,15 +71,15 @@ class PicState:
         lay = [None, None]
         lay[self.cur] = self._layout(cur_tensors, self.meta[self.cur])
         lay[1 - self.cur] = self._layout(other_tensors, self.meta[1 - self.cur])
-        return _lib.Pic(self.xs, self.ys, self.N, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
-                        _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_cnt), status_out)
+        return _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
+                        _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code), _ptr(self.rim_cnt), status_out)
 
     def two_launch(self, env, agent) -> bool:
         """Does die_pic_forward_env_step take the two-launch form for this agent?  (The library decides by the same rule;
         here it only settles whether the deposit plane of the three-launch form has to exist.)"""
         if not self.fused:
             return False
-        W, H = self._plane_shape
+        W, H = self._world_shape
         reach = float(np.float32(abs(agent._scale)) * np.float32(max(W, H) - 1))      # (float32, as the library computes it)
         R = int(4.0 * float(np.float32(env.dynamics.diffuse_sigma)) + 0.5)
         return 1 <= R <= 4 and int(reach) + 1 + R <= min(1 << self.xs, 1 << self.ys)
@@ -93,7 +100,7 @@ class PicState:
         self.held, self.agent = tuple(new), agent
 
     def _out_tensors(self, env):
-        slot = torch.empty(self.N, dtype=torch.int32, device=env.device)
+        slot = torch.empty(self.cap, dtype=torch.int32, device=env.device)
         return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4])
 
     def bin(self, env, agent):
@@ -103,6 +110,7 @@ class PicState:
         if self.steps_since_check:
             self.check()
         A = env.agents
+        self._n_agents = int(A.N)
         out = self._out_tensors(env)
         cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo)
         p = self._struct(cur_t, out)
@@ -122,13 +130,13 @@ class PicState:
 
     def _rebuilder(self, env, agent, out):
         """die_pic_action_physarum on what the step left in `out` (the layout it wrote) — see include/die_hip.h."""
-        lay, N, dep, dev = self.cur, self.N, self.dep, env.device
+        lay, N, dep, dev = self.cur, self._n_agents, self.dep, env.device
         slot, hh, hl = out[3], out[4], out[5]
 
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),
@@ -144,6 +152,7 @@ class PicState:
         step does not store it (30 MB and 7 % of the agent kernel at 4096²): the PendingAction gets a `_rebuild` hook and
         is filled in when somebody reads it — or, if it is still referenced then, before the next step."""
         self.flush_lazy()
+        self._n_agents = int(env.agents.N)
         if self._dep_plane is None and not self.two_launch(env, agent):
             self._dep_plane = torch.empty(self._plane_shape, dtype=torch.float32, device=env.device)
         out = self._out_tensors(env)

@@ -393,7 +393,8 @@ typedef struct die_pic {
     float* dep;                  /* N floats of scratch */
     float* dep_plane;            /* three-launch form only (may be NULL when rim is given and the step qualifies), W*H: per cell the deposit of the highest slot standing
                                     on it, or 0xFFFFFFFF */
-    void* part_gain;             /* die_pic_tiles() 64-bit words: reward partials (also the binning scratch) */
+    void* part_gain;             /* 2 * die_pic_tiles() 64-bit words: reward partials per tile, then (tiles of a decomposed world:
+                                    die_medium.gW > 0) the owned agents per tile; also the binning scratch */
     uint32_t* error;             /* device word, 0 = fine; sticky bits after a step: 1 segment bookkeeping broken, 2 an agent moved
                                     further than a tile.  Never cleared by the library */
     int32_t k1_threads;          /* tuning: workgroup size of the agent kernel (multiple of 64, <= 512); 0 = default */
@@ -405,8 +406,9 @@ typedef struct die_pic {
      * and ONE kernel per tile reads the lists of the 9 tiles around it (fixed places: requested with the first loads),
      * resolves the claims of its tile + rim in LDS, adds the winners' deposits, diffuses, decays and feeds: no deposit
      * plane, one launch less.  A list that overflows costs time (that tile's segment is then scanned), never correctness. */
-    uint32_t* rim;               /* die_pic_tiles() * die_pic_rim_cap() words, or NULL: three launches (claim resolution writes
-                                    dep_plane, die_env.hip's sweep reads it) */
+    void* rim;                   /* die_pic_tiles() * die_pic_rim_cap() records of 16 bytes (x, y, slot, deposit bits), or NULL: three
+                                    launches (claim resolution writes dep_plane, die_env.hip's sweep reads it) */
+    uint8_t* rim_code;           /* die_pic_tiles() * die_pic_rim_cap() bytes: where each listed agent stands (see die_pic.hip) */
     uint32_t* rim_cnt;           /* die_pic_tiles() words */
     int64_t* status_out;         /* two-launch form, may be NULL: the step copies *error here next to writing `result` — a caller that
                                     places it behind its die_step_result reads reward, num_alive and the error word in ONE copy */
@@ -426,7 +428,11 @@ int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* headin
  * (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  Same bits.  The
  * agent state (g->heading_* are ignored: layout[from].heading_*) moves with the agents; `act` receives the action in the order
  * of layout[from].  Requires: every slot alive, no agents_die / sense mask, normalised gradient without inertia or noise
- * and |scale| * (max(W, H) - 1) <= tile - 1 (else DIE_ERR_UNSUPPORTED / DIE_ERR_ARG: use die_forward_env_step). */
+ * and |scale| * (max(W, H) - 1) <= tile - 1 (else DIE_ERR_UNSUPPORTED / DIE_ERR_ARG: use die_forward_env_step).
+ * The planes may be a tile of a decomposed world (die_medium.gW > 0; two-launch form only): agents are binned by the plane
+ * cell that holds their world cell (nearest edge for agents beyond the planes), the planes are treated as periodic — what
+ * that brings in across their outer edge stays in the outermost cells of the halo, which a ghost-agent decomposition
+ * discards —, probes clamp at the WORLD's edge, and reward / num_alive count the agents on cells the rank owns (own_*). */
 int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g, const die_action* act,
                              const die_dynamics* d, die_step_result* result, void* stream);
 /* `act` of die_pic_forward_env_step may be NULL: the action then stays in registers.  For a normalised PhysarumAgent it can

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do
   lib=$R/scratch/libs/libdie_$v.so; [ $v = hip ] && lib=$R/die_amd/libdie_hip.so
   d=$R/gpurun_out/ab_$v; rm -rf $d
-  DIE_AMD_LIB=$lib timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --kernel-reps 1 $AB_EXTRA > $d.json 2> $d.err || { tail -5 $d.err; exit 1; }
+  DIE_AMD_LIB=$lib timeout -k 10 150 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-extras --kernel-reps 1 $AB_EXTRA > $d.json 2> $d.err || { tail -5 $d.err; exit 1; }
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   echo "== $v [$(grep " $v:" $R/scratch/variants.log | tail -1)]: $(python3 -c "import json;d=json.load(open('$d.json'));print(d['value'], d['step_ms']['median'])")"
   python3 - $f <<'PY'

@@ -75,8 +75,11 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
             obs, res = env.step(agent.forward(obs))
             rewards.append(env.read_result(res))
         world = env.gather_world()
+        if hasattr(env, 'check'):
+            env.check()
         if rank == 0:
-            np.savez(out_path, medium=world[0], agents=world[1], rewards=np.array(rewards))
+            np.savez(out_path, medium=world[0], agents=world[1], rewards=np.array(rewards), pic_steps=getattr(env, 'pic_steps', 0),
+                     plane=np.array([env.geo.W, env.geo.H]))
     finally:
         dist.destroy_process_group()
 
@@ -158,6 +161,36 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
         assert np.array_equal(got['medium'][c], m[c])
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
     assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
+
+
+@pytest.mark.parametrize('grid,refresh_every,backend,wave,plane', [
+    ((2, 2), 2, 'gloo', False, (256, 192)), ((1, 2), 3, 'gloo', True, (384, 256)), ((2, 1), 2, 'gloo-f16', False, (256, 256)),
+    ((1, 1), 4, 'nccl', False, (384, 256))])
+def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_every, backend, wave, plane):
+    """A rank of the ghost-agent decomposition takes the step the single GPU takes: the tile-binned two-launch step on its
+    padded tile (die_pic.hip TILED: agents binned by the plane cell that holds their world cell, ownership-masked reward,
+    probes clamped at the WORLD's edge; the halo is rounded up until the planes split into whole tiles), re-binned after
+    every refresh.  Every slot alive (the binned step's precondition).  Gathered world and rewards equal the single-device
+    run bit for bit; the worker reports how many of its steps took the binned path: all of them."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    W, H, N, steps = 384, 256, 12000, 9
+    out = str(tmp_path / 'dist.npz')
+    size = grid[0] * grid[1]
+    f16 = backend.endswith('-f16')
+    backend = backend.replace('-f16', '')
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, False, refresh_every, out, backend, True, wave, f16),
+             nprocs=size, join=True)
+    got = np.load(out)
+    assert int(got['pic_steps']) == steps, 'the ranks did not take the tile-binned step'
+    assert tuple(got['plane']) == plane                     # (halo rounded up so that the planes are whole tiles)
+    m, a, r = _single_device_run(W, H, N, N, steps, wave, f16)
+    assert np.array_equal(got['agents'], a)
+    for c in range(3):
+        assert np.array_equal(got['medium'][c], m[c])
+    assert np.array_equal(got['rewards'][:, 1], r[:, 1])
+    assert np.array_equal(got['rewards'][:, 0], r[:, 0])
 
 
 @pytest.mark.parametrize('ghosts,migrate_every', [(True, 3), (False, 1), (False, 4)])
