@@ -115,8 +115,8 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.js
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false, true>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
-             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false, true>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
-             'k_pic_resolve_diffuse': 'void k_pic_resolve_diffuse<float, 6, 6, 2>',
+             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false, true, false>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
+             'k_pic_resolve_diffuse': 'void k_pic_resolve_diffuse<float, 6, 6, 2, false>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
 WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve', 'k_pic_resolve_diffuse')
 # bytes per agent that the tile-binned kernels read as 4-byte-per-lane streams (counted in full by FETCH_SIZE; only the

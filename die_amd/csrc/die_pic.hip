@@ -1163,7 +1163,9 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // FAR border of the tile it walks onto
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
     const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
-                     (int)floorf(reach) + 1 + R <= (TX < TY ? TX : TY);
+                     (int)floorf(reach) + 2 + R <= (TX < TY ? TX : TY);     // (+ 2: floor(reach) + 1 cells by the move itself, one more
+                     // across the world's seam, where cell W − 1 and cell 0 are the same point of the coordinate circle — labels
+                     // linspace(0, 1, W), core/data_init.py:95-112 — and an agent's cell index jumps by one extra)
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
     if (tiled && !(two && stage)) {
         die_set_error("die_pic_forward_env_step: a decomposed world's tile runs the two-launch form with staged tiles only (probe reach %d, radius %d)", P, R);

@@ -667,7 +667,7 @@ class DistEnv:
         reach = float(np.float32(abs(ag._scale)) * np.float32(wmax))
         probe = int(np.floor(float(np.float32(abs(ag._sense_offset_scale)) * np.float32(wmax)))) + 2
         vec = 4 if self.medium.dtype == torch.float32 else 8
-        return int(reach) + 1 + self.R <= min(TX, TY) and (probe + vec - 1) // vec * vec <= 24
+        return int(reach) + 2 + self.R <= min(TX, TY) and (probe + vec - 1) // vec * vec <= 24
 
     def _pic_void(self):
         if self._pic is not None:

@@ -82,7 +82,7 @@ class PicState:
         W, H = self._world_shape
         reach = float(np.float32(abs(agent._scale)) * np.float32(max(W, H) - 1))      # (float32, as the library computes it)
         R = int(4.0 * float(np.float32(env.dynamics.diffuse_sigma)) + 0.5)
-        return 1 <= R <= 4 and int(reach) + 1 + R <= min(1 << self.xs, 1 << self.ys)
+        return 1 <= R <= 4 and int(reach) + 2 + R <= min(1 << self.xs, 1 << self.ys)
 
     def is_current(self, env, agent) -> bool:
         A, h = env.agents, self.held

@@ -423,7 +423,7 @@ int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo, const die_pic* p,
                 int32_t into, void* stream);
 /* GradientAgent/PhysarumAgent.forward (core/agent/gradient.py:96-124) + Env.step (core/env.py:101-131) on binned agents:
- * two launches when p->rim is given and floor(|scale| * (max(W, H) - 1)) + 1 + gaussian radius <= tile (forward + move + feeding +
+ * two launches when p->rim is given and floor(|scale| * (max(W, H) - 1)) + 2 + gaussian radius <= tile (forward + move + feeding +
  * re-binning + rim lists; per-tile claim resolution + deposit + diffusion + feeding + next offsets + reward), else three
  * (forward + move + feeding + re-binning; LDS claim resolution + next offsets; field sweep + reward).  Same bits.  The
  * agent state (g->heading_* are ignored: layout[from].heading_*) moves with the agents; `act` receives the action in the order
