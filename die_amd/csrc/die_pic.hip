@@ -185,6 +185,10 @@ struct PicStage {
 
 #define PIC_RIM_CAP_MAX 224      // entries of a tile's rim list (k_pic_resolve_diffuse reads the codes of 9 lists with one word per thread)
 #define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
+// (The first round appends up to one candidate per thread: a list shorter than the workgroup is written past its end.  A
+// round-2 experiment build with a shorter list faulted that way — most probably the `n1` run of gpurun_out/sw3_n1.err,
+// DESIGN.md §10 — hence the assertion; tests/test_gpu_parity.py::test_tile_binned_step_with_a_crowd_crossing_one_border
+// drives the rounds below beyond the first on the shipped kernel.)
 static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
 
 // Diagnostic build only (-DPIC_STAMPS; scratch/pic_stamps.py): s_memtime at the phase boundaries of K1, written by lane 0
