@@ -120,28 +120,33 @@ template <bool TILED> __device__ __forceinline__ int pic_tile_of(const PicArgs& 
 // neighbours (periodic neighbourhood; under the 'limit' boundary nothing crosses the seam and those ranges simply fail
 // the tile test).  base[r] = first array index, pre[r] = exclusive prefix of the lengths, pre[9] = total candidates.
 // Two halves, so that the (dependent) loads of the per-tile words are in flight while the caller stages its tile.
-struct PicMeta { uint32_t base, len; };
+// (The loaded words are only TOUCHED in pic_ranges_finish: arithmetic on them right behind the loads made the compiler wait
+// for them — a full memory round trip under load — before it issued the caller's tile loads at all; found in the ISA in
+// round 3: `s_waitcnt vmcnt(0)` between the three per-tile loads and the eight tile loads.)
+struct PicMeta { uint32_t o, s, n; };
 
 __device__ __forceinline__ int pic_wrap(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }     // v in [−n, 2n)
 
 __device__ __forceinline__ PicMeta pic_meta_load(const PicLayout& L, int tx, int ty, int ntx, int nty) {
-    PicMeta mt = {0u, 0u};
+    PicMeta mt = {0u, 0u, 0u};
     if (threadIdx.x < 9) {
         const int q = threadIdx.x;            // 0: (0, 0); 1..8: the ring
         const int k = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
         const int dx = k / 3 - 1, dy = k % 3 - 1;
         const int nx = pic_wrap(tx + dx, ntx), ny = pic_wrap(ty + dy, nty);
         const int t = nx * nty + ny;
-        const uint32_t o = L.off[t], s = L.s[t], n = L.n[t];
-        mt.base = q == 0 ? o : o + s;
-        mt.len = s > n ? 0u : (q == 0 ? s : n - s);     // (s > n: broken bookkeeping — never loop over garbage)
+        mt.o = L.off[t]; mt.s = L.s[t]; mt.n = L.n[t];
     }
     return mt;
 }
 
 __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* base, uint32_t* pre) {
     __shared__ uint32_t s_len[9];
-    if (threadIdx.x < 9) { base[threadIdx.x] = mt.base; s_len[threadIdx.x] = mt.len; }
+    if (threadIdx.x < 9) {
+        const bool own = threadIdx.x == 0;
+        base[threadIdx.x] = own ? mt.o : mt.o + mt.s;
+        s_len[threadIdx.x] = mt.s > mt.n ? 0u : (own ? mt.s : mt.n - mt.s);     // (s > n: broken bookkeeping — never loop over garbage)
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
@@ -697,8 +702,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     uint32_t m_o = 0, m_s = 0, m_n = 0, m_r = 0;
     if (threadIdx.x < 9) {
         const int t = ring_tile(threadIdx.x);
-        m_o = p.out.off[t]; m_s = p.out.s[t]; m_n = p.out.n[t]; m_r = a.rim_cnt[t];
-        if (m_s > m_n) m_s = m_n = 0;                       // (broken bookkeeping — never loop over garbage)
+        m_o = p.out.off[t]; m_s = p.out.s[t]; m_n = p.out.n[t]; m_r = a.rim_cnt[t];      // (not touched before the other loads are out)
     }
     // the codes of rim entries 4·tid .. 4·tid + 3 of the flattened 9 × CAPR (list e / CAPR, entry e % CAPR; whether an entry
     // exists is known once the counts are here)
@@ -718,6 +722,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     for (int i = threadIdx.x; i < WR * WC / 4; i += BLOCK) ((uint4*)s_claim)[i] = make_uint4(0u, 0u, 0u, 0u);
     static_assert((WR * WC) % 4 == 0, "16-byte zeroing");
     if (threadIdx.x < 9) {
+        if (m_s > m_n) m_s = m_n = 0;                       // (broken bookkeeping — never loop over garbage)
         s_off[threadIdx.x] = m_o; s_n[threadIdx.x] = m_n; s_rn[threadIdx.x] = m_r;
         if (threadIdx.x == 0) { s_own[0] = m_o; s_own[1] = m_s; }
     }
