@@ -46,6 +46,28 @@ def test_struct_layouts_match_header(built_lib):
     assert C.sizeof(_lib.Dynamics) == 12 * 4
     assert C.sizeof(_lib.GradientAgent) == 8 * 4 + 3 * 8 + 5 * 8 + 8 + 4 + 4 + 8
     assert C.sizeof(_lib.FoodSpec) == 16 + 4 * 8 * 8
+    assert C.sizeof(_lib.PicLayout) == 10 * 8
+    # die_pic: tile shape 2 x i32, N i64, two layouts, dep / dep_plane / part_gain / error, k1_threads + stages, rim / rim_code /
+    # rim_cnt / status_out
+    assert C.sizeof(_lib.Pic) == 8 + 8 + 2 * 10 * 8 + 4 * 8 + 8 + 4 * 8
+    assert C.sizeof(_lib.Batch) == 8 + 8 + 8 + 8 + 64 * 8
+
+
+def test_tile_binned_geometry_helpers_without_gpu(built_lib):
+    """die_pic_tiles / die_pic_rim_cap are pure host arithmetic: compiled tile shapes, entries per rim list (nine lists of
+    that many code bytes are one 4-byte load per thread of the field kernel: 4 x 512 / 9 and 4 x 256 / 9, rounded down to
+    whole words)."""
+    from die_amd import _lib
+    from die_amd.pic import pick_tile
+    L = _lib.lib
+    assert L.die_pic_tiles(4096, 4096, 6, 6) == 4096 and L.die_pic_tiles(192, 256, 4, 5) == 12 * 8
+    assert L.die_pic_tiles(4096, 4096, 3, 3) == -1 and L.die_pic_tiles(0, 64, 6, 6) == -1
+    assert L.die_pic_rim_cap(6, 6) == 224 and L.die_pic_rim_cap(5, 7) == 224 and L.die_pic_rim_cap(5, 6) == 112 and L.die_pic_rim_cap(4, 5) == 112
+    assert L.die_pic_rim_cap(7, 7) == -1
+    for xs, ys in ((6, 6), (5, 7), (5, 6), (4, 5)):
+        assert L.die_pic_rim_cap(xs, ys) % 4 == 0 and 9 * L.die_pic_rim_cap(xs, ys) <= 4 * (512 if (1 << xs) * (1 << ys) >= 4096 else 256)
+    assert pick_tile(4096, 4096, 1.53) == (6, 6) and pick_tile(128, 96, 1.53) == (4, 5) and pick_tile(100, 100, 1.53) is None
+    assert pick_tile(192, 192, 40.0) == (6, 6) and pick_tile(192, 192, 63.5) is None
 
 
 def test_argument_validation_without_gpu(built_lib):
