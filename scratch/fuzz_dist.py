@@ -7,9 +7,22 @@ def free_port():
         s.bind(('127.0.0.1', 0)); return s.getsockname()[1]
 
 GHOST = os.environ.get('FUZZ_GHOST', '0') == '1'
+PIC = os.environ.get('FUZZ_PIC', '0') == '1'          # ghost mode on worlds whose ranks qualify for the tile-binned step
 
 def make_case(seed):
     rs = np.random.RandomState(seed)
+    if PIC:
+        grid = [(1, 2), (2, 1), (2, 2), (1, 3), (1, 1)][rs.randint(5)]
+        Wi = int(rs.choice([128, 192, 256])); Hi = int(rs.choice([128, 192, 256]))
+        W, H = Wi * grid[0], Hi * grid[1]
+        N = int(rs.choice([4000, 20000, 60000]))
+        me = int(rs.choice([1, 2, 3]))
+        reach = int(np.ceil(max(6.2 / (W - 1), 0.03) * (max(W, H) - 1)))
+        loss = reach + 1 + int(np.ceil(max(1.53 / (W - 1), 0.01 * 1.5) * (max(W, H) - 1) + 0.5)) + 2
+        while me > 1 and 2 * (me * loss + 3) > min(Wi if grid[0] > 1 else 10 ** 6, Hi if grid[1] > 1 else 10 ** 6):
+            me -= 1                      # (the ghost halo must fit twice into a rank's interior)
+        return dict(grid=grid, W=W, H=H, N=N, K=N, agent='physarum', boundary=str(rs.choice(['wrap', 'limit'])), agents_die=False,
+                    steps=int(rs.choice([7, 10])), migrate_every=me, sort_every=0, seed=seed, ghosts=True)
     if GHOST:        # ghost-agent mode: bounded steps only, tiles at least twice the halo
         grid = [(1, 2), (2, 1), (2, 2), (1, 3), (3, 1), (1, 4)][rs.randint(6)]
         if os.environ.get('FUZZ_GRID'):
@@ -79,7 +92,7 @@ def worker(rank, size, port, case, out):
             obs, res = env.step(ag.forward(obs))
         world = env.gather_world()
         if rank == 0:
-            np.savez(out, medium=world[0], agents=world[1])
+            np.savez(out, medium=world[0], agents=world[1], pic_steps=getattr(env, 'pic_steps', 0), plane=np.array([env.geo.W, env.geo.H]))
     finally:
         dist.destroy_process_group()
 
@@ -107,7 +120,7 @@ if __name__ == '__main__':
                 assert np.abs(got['agents'][:2] - a[:2]).max() == 0
             assert np.array_equal(got['agents'], a), 'agents'
             assert np.array_equal(got['medium'], m), 'medium'
-            print('ok  ', case, flush=True)
+            print('ok  ', case, 'binned steps', int(got['pic_steps']), 'plane', got['plane'].tolist(), flush=True)
         except Exception as e:
             fails += 1; print('FAIL', case, type(e).__name__, str(e)[-400:].replace(chr(10), ' | '), flush=True)
     print(f'fuzz dist: {fails} failures', flush=True)
