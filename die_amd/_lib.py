@@ -59,6 +59,7 @@ class ConvPlane(C.Structure):
 
 
 DIE_PLANE_F32, DIE_PLANE_F16, DIE_PLANE_AGENTS = 0, 1, 2
+PAD_MODES = {'circular': 0, 'zeros': 1, 'reflect': 2, 'replicate': 3}        # torch.nn.Conv2d padding_mode → die_pad_mode
 DIE_FIELD_CONST, DIE_FIELD_NOISE, DIE_FIELD_AGENTS, DIE_FIELD_PERLIN = 0, 1, 2, 3
 
 
@@ -174,6 +175,8 @@ _SIGNATURES = {
     'die_pic_action_physarum': (C.c_int, [_P(Pic), C.c_int32, _P(GradientAgent), _P(Action), C.c_void_p]),
     'die_conv2d_circular': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,
                                       C.c_void_p, C.c_int32, C.c_void_p]),
+    'die_conv2d': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,
+                             C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     'die_gather_scale': (C.c_int, [_P(Medium), _P(Agents), _P(C.c_void_p), _P(C.c_float), _P(Action), C.c_void_p]),
     'die_sort_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int32, C.c_int64]),
     'die_agents_sort': (C.c_int, [_P(Medium), _P(Agents), _P(Agents), C.c_int32, _P(C.c_void_p), _P(C.c_void_p), C.c_void_p,

@@ -112,8 +112,8 @@ class NeuralAutomataAgent(TorchAgent):
     def _device_weights(self, device):
         layers = self._model.conv_layers()
         for k in layers:
-            if k.padding_mode != 'circular':
-                raise NotImplementedError(f"boundary={k.padding_mode!r}: the device path implements 'circular' padding")
+            if k.padding_mode not in _lib.PAD_MODES:
+                raise NotImplementedError(f"boundary={k.padding_mode!r}: one of {sorted(_lib.PAD_MODES)}")
         # uploaded on every call (≈ 100 floats): in-place writes through `param.data` — how evotorch's fill_parameters
         # loads each candidate — change neither `_version` nor `data_ptr()`, so no cheap key tells a stale copy apart
         return [k.weight.detach().to(device=device, dtype=th.float32).contiguous() for k in layers]
@@ -143,8 +143,8 @@ class NeuralAutomataAgent(TorchAgent):
             dst = sets[li % 2]
             cin_arr = (_lib.ConvPlane * cin)(*[_lib.ConvPlane(t.data_ptr(), kind, 0) for t, kind in planes])
             out_arr = (C.c_void_p * cout)(*[dst[o].data_ptr() for o in range(cout)])
-            _lib.check(_lib.lib.die_conv2d_circular(W, H, cin, cin_arr, medium.epoch, cout, out_arr, k, _ptr(w),
-                                                    int(li == len(weights) - 1), sp), 'die_conv2d_circular')
+            _lib.check(_lib.lib.die_conv2d(W, H, cin, cin_arr, medium.epoch, cout, out_arr, k, _ptr(w), int(li == len(weights) - 1),
+                                           _lib.PAD_MODES[self._model.conv_layers()[li].padding_mode], sp), 'die_conv2d')
             planes = [(dst[o], _lib.DIE_PLANE_F32) for o in range(cout)]
         out = sets[(len(weights) - 1) % 2][:len(planes)]         # the last layer's planes (scratch: valid until the next call)
         p = self._model.agent_dropout.p

@@ -1,5 +1,5 @@
 // NeuralAutomataAgent sensing (gfx950) — core/agent/evo.py:45-118 (ConvolutionModel: a stack of bias-free Conv2d with
-// 'same' circular padding, one Tanh at the end) and :150-174 (forward: per-agent gather of the transformed medium at
+// 'same' padding — `boundary` = torch's padding_mode: 'circular' by default, 'zeros' / 'reflect' / 'replicate' —, one Tanh at the end) and :150-174 (forward: per-agent gather of the transformed medium at
 // the agent's cell, core/utils.py:56-65, times the action coefficients).
 //
 //   k_conv_circular   one layer: out[o, x, y] = Σ_i Σ_a Σ_b w[o, i, a, b] · in[i, (x + a − r) mod W, (y + b − r) mod H]
@@ -26,7 +26,21 @@ struct ConvArgs {
     float* out[NCA_MAXC];
     const float* w;              // [cout][cin][k][k]
     int W, H, cin, cout, k, epoch, apply_tanh;
+    int pad;                     // die_pad_mode: how cells beyond the field are read ('same' padding of torch's Conv2d)
 };
+
+// index of the cell that stands in for coordinate v of an axis of n cells, or −1 for "reads as zero" (torch.nn.functional.pad:
+// 'circular' wraps, 'zeros' pads with 0, 'reflect' mirrors WITHOUT repeating the edge cell, 'replicate' repeats it)
+__device__ __forceinline__ int nca_pad_index(int v, int n, int mode) {
+    if (v >= 0 && v < n) return v;
+    if (mode == DIE_PAD_CIRCULAR) { v %= n; return v < 0 ? v + n : v; }
+    if (mode == DIE_PAD_ZEROS) return -1;
+    if (mode == DIE_PAD_REPLICATE) return v < 0 ? 0 : n - 1;
+    if (n == 1) return 0;
+    const int period = 2 * (n - 1);                  // 'reflect': … 2 1 | 0 1 2 … n−1 | n−2 n−3 …
+    v %= period; v = v < 0 ? v + period : v;
+    return v < n ? v : period - v;
+}
 
 __device__ __forceinline__ float nca_load(const void* p, int kind, int64_t i, int epoch) {
     if (kind == DIE_PLANE_F32) return ((const float*)p)[i];
@@ -47,10 +61,10 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_conv_circular(ConvArgs a) {
     for (int c = 0; c < a.cin; ++c) {
         for (int i = threadIdx.x; i < LX * LYV; i += DIE_BLOCK) {
             const int li = i / LYV, lj = i - li * LYV;
-            int gx = (x0 - R + li) % a.W, gy = (y0 - R + lj) % a.H;
-            gx = gx < 0 ? gx + a.W : gx;
-            gy = gy < 0 ? gy + a.H : gy;
-            s_in[(c * LX + li) * LY + lj] = nca_load(a.in[c], a.kind[c], (int64_t)gx * a.H + gy, a.epoch);
+            // (rows / columns past the last tile's outputs wrap like a circular field whatever the mode: never used)
+            const int vx = x0 - R + li, vy = y0 - R + lj;
+            const int gx = nca_pad_index(vx < a.W + R ? vx : vx % a.W, a.W, a.pad), gy = nca_pad_index(vy < a.H + R ? vy : vy % a.H, a.H, a.pad);
+            s_in[(c * LX + li) * LY + lj] = (gx < 0 || gy < 0) ? 0.f : nca_load(a.in[c], a.kind[c], (int64_t)gx * a.H + gy, a.epoch);
         }
     }
     __syncthreads();
@@ -99,6 +113,16 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_conv_circular(ConvArgs a) {
 
 extern "C" int die_conv2d_circular(int32_t W, int32_t H, int32_t cin, const die_conv_plane* in, int32_t epoch, int32_t cout,
                                    float* const* out, int32_t k, const float* weights, int32_t apply_tanh, void* stream) {
+    return die_conv2d(W, H, cin, in, epoch, cout, out, k, weights, apply_tanh, DIE_PAD_CIRCULAR, stream);
+}
+
+extern "C" int die_conv2d(int32_t W, int32_t H, int32_t cin, const die_conv_plane* in, int32_t epoch, int32_t cout,
+                          float* const* out, int32_t k, const float* weights, int32_t apply_tanh, int32_t padding_mode, void* stream) {
+    DIE_REQUIRE(padding_mode >= DIE_PAD_CIRCULAR && padding_mode <= DIE_PAD_REPLICATE, "die_conv2d: bad padding mode %d", padding_mode);
+    if (padding_mode == DIE_PAD_REFLECT && (k / 2 >= W || k / 2 >= H)) {      // (torch refuses it too)
+        die_set_error("die_conv2d: 'reflect' padding of %d cells needs a field larger than that (%dx%d)", k / 2, W, H);
+        return DIE_ERR_ARG;
+    }
     DIE_REQUIRE(W >= 1 && H >= 1, "die_conv2d_circular: bad size %dx%d", W, H);
     DIE_REQUIRE(cin >= 1 && cin <= NCA_MAXC && cout >= 1 && cout <= NCA_MAXC, "die_conv2d_circular: 1..%d channels (got %d -> %d)",
                 NCA_MAXC, cin, cout);
@@ -116,7 +140,7 @@ extern "C" int die_conv2d_circular(int32_t W, int32_t H, int32_t cin, const die_
         DIE_REQUIRE(c >= cout || out[c], "die_conv2d_circular: null output plane %d", c);
         for (int q = 0; q < cout && c < cin; ++q) DIE_REQUIRE((const void*)out[q] != in[c].data, "die_conv2d_circular: in-place convolution");
     }
-    a.w = weights; a.W = W; a.H = H; a.cin = cin; a.cout = cout; a.k = k; a.epoch = epoch; a.apply_tanh = apply_tanh;
+    a.w = weights; a.W = W; a.H = H; a.cin = cin; a.cout = cout; a.k = k; a.epoch = epoch; a.apply_tanh = apply_tanh; a.pad = padding_mode;
     const int R = k / 2;
     const size_t lds = ((size_t)cin * (NCA_TX + 2 * R) * (NCA_TY + 2 * R + 1) + (size_t)cout * cin * k * k) * sizeof(float);
     dim3 grid((H + NCA_TY - 1) / NCA_TY, (W + NCA_TX - 1) / NCA_TX);

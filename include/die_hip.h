@@ -458,6 +458,10 @@ typedef struct die_conv_plane {
 } die_conv_plane;
 int die_conv2d_circular(int32_t W, int32_t H, int32_t cin, const die_conv_plane* in, int32_t epoch, int32_t cout,
                         float* const* out, int32_t k, const float* weights, int32_t apply_tanh, void* stream);
+/* The same layer with any `boundary` of ConvolutionModel (core/agent/evo.py:51,86 → torch.nn.Conv2d padding_mode). */
+typedef enum die_pad_mode { DIE_PAD_CIRCULAR = 0, DIE_PAD_ZEROS = 1, DIE_PAD_REFLECT = 2, DIE_PAD_REPLICATE = 3 } die_pad_mode;
+int die_conv2d(int32_t W, int32_t H, int32_t cin, const die_conv_plane* in, int32_t epoch, int32_t cout,
+               float* const* out, int32_t k, const float* weights, int32_t apply_tanh, int32_t padding_mode, void* stream);
 /* NeuralAutomataAgent.forward's per-agent read-out (core/agent/evo.py:161-170, core/utils.py:56-65): for EVERY slot
  * action[c, n] = planes[c][cell(x_n), cell(y_n)] * coefs[c], c = dx, dy, deposit1. */
 int die_gather_scale(const die_medium* m, const die_agents* a, const float* const* planes, const float* coefs,

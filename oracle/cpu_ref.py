@@ -549,36 +549,45 @@ def wave_field(W: int, H: int, t: float) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 # NeuralAutomataAgent sensing: core/agent/evo.py:45-118,150-174
 # --------------------------------------------------------------------------------------
-def conv2d_circular(x: np.ndarray, w: np.ndarray) -> np.ndarray:
-    """One bias-free Conv2d with padding='same', padding_mode='circular' (core/agent/evo.py:81-92) on a (cin, W, H)
-    array: torch's convolution is a cross-correlation, out[o, x, y] = Σ_i Σ_a Σ_b w[o, i, a, b] · in[i, x + a − r, y + b − r]
-    with indices taken modulo the field size (odd kernels: r = k // 2 on both sides)."""
+_NP_PAD = {'circular': 'wrap', 'zeros': 'constant', 'reflect': 'reflect', 'replicate': 'edge'}
+
+
+def conv2d_same(x: np.ndarray, w: np.ndarray, mode: str = 'circular') -> np.ndarray:
+    """One bias-free Conv2d with padding='same', padding_mode=`mode` (core/agent/evo.py:51,81-92: `boundary`) on a
+    (cin, W, H) array: torch's convolution is a cross-correlation, out[o, x, y] = Σ_i Σ_a Σ_b w[o, i, a, b] · in[i, x + a − r,
+    y + b − r] over the field padded by r = k // 2 cells per side as torch.nn.functional.pad does ('circular' wraps,
+    'zeros' pads with 0, 'reflect' mirrors without repeating the edge, 'replicate' repeats it)."""
     cout, cin, k, k2 = w.shape
     assert k == k2 and k % 2 == 1 and x.shape[0] == cin
     r = k // 2
-    out = np.zeros((cout,) + x.shape[1:])
+    W, H = x.shape[1:]
+    xp = np.pad(x, ((0, 0), (r, r), (r, r)), mode=_NP_PAD[mode]) if r else x
+    out = np.zeros((cout, W, H))
     for a in range(k):
         for b in range(k):
-            shifted = np.roll(x, (r - a, r - b), axis=(1, 2))          # shifted[i, x, y] = in[i, x + a − r, y + b − r]
-            out += np.einsum('oi,ixy->oxy', w[:, :, a, b], shifted)
+            out += np.einsum('oi,ixy->oxy', w[:, :, a, b], xp[:, a:a + W, b:b + H])
     return out
 
 
-def nca_sense(medium: np.ndarray, weights, with_agent_channel: bool = True) -> np.ndarray:
+def conv2d_circular(x: np.ndarray, w: np.ndarray) -> np.ndarray:
+    return conv2d_same(x, w, 'circular')
+
+
+def nca_sense(medium: np.ndarray, weights, with_agent_channel: bool = True, boundary: str = 'circular') -> np.ndarray:
     """ConvolutionModel.forward (core/agent/evo.py:110-118, dropout p = 0): the kernels one after the other, no
     activation in between (:81-99), Tanh at the end."""
     x = np.asarray(medium if with_agent_channel else medium[1:], dtype=np.float64)
     for w in weights:
-        x = conv2d_circular(x, np.asarray(w, dtype=np.float64))
+        x = conv2d_same(x, np.asarray(w, dtype=np.float64), boundary)
     return np.tanh(x)
 
 
-def nca_forward(obs, weights, scale=0.1, deposit=1.0, with_agent_channel=True) -> np.ndarray:
+def nca_forward(obs, weights, scale=0.1, deposit=1.0, with_agent_channel=True, boundary: str = 'circular') -> np.ndarray:
     """NeuralAutomataAgent.forward (core/agent/evo.py:150-174): the transformed medium read at every slot's nearest
     cell (core/utils.py:56-65, only_alive=False), times (scale, scale, deposit)."""
     agents, medium = obs
     W, H = medium.shape[1:]
-    sense = nca_sense(medium, weights, with_agent_channel)
+    sense = nca_sense(medium, weights, with_agent_channel, boundary)
     ix, iy = cell(agents[A_X], W), cell(agents[A_Y], H)
     return sense[:, ix, iy] * np.array([scale, scale, deposit])[:, None]
 

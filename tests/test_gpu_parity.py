@@ -1621,6 +1621,29 @@ def test_neural_automata_forward_parity(die, W, H, kernel_sizes):
         env.step(action)
 
 
+@pytest.mark.parametrize('boundary', ['zeros', 'reflect', 'replicate'])
+@pytest.mark.parametrize('W,H,kernel_sizes', [(48, 40, (3, 5)), (250, 132, (7, 3)), (12, 8, (5,))])
+def test_neural_automata_boundaries(die, boundary, W, H, kernel_sizes):
+    """`ConvolutionModel(boundary=…)` (core/agent/evo.py:51,86: torch's padding_mode; the reference's default and its
+    examples use 'circular') — die_conv2d with the other three modes against the oracle (itself checked against torch for
+    every mode in tests/test_nca_cpu.py) and against the torch evaluation of the same model: 1e-5."""
+    import torch as th
+    N = max(W * H // 4, 8)
+    rs = np.random.RandomState(W + H + len(boundary))
+    medium, agents = random_state(W, H, N, N, rs, collide=0.2)
+    th.manual_seed(W)
+    ag = die.NeuralAutomataAgent(scale=0.07, deposit=1.5, kernel_sizes=kernel_sizes, boundary=boundary)
+    ag.model.init_weights()
+    env = die.Env.from_numpy(medium, agents)
+    action = ag.forward(env._get_current_obs)
+    ws = [k.weight.detach().numpy().astype(np.float64) for k in ag.model.conv_layers()]
+    got_sense = ag._sense_output.cpu().numpy().astype(np.float64)
+    assert np.allclose(got_sense, R.nca_sense(medium, ws, True, boundary), rtol=RTOL, atol=1e-5)
+    assert np.allclose(action.to_numpy(), R.nca_forward((agents, medium), ws, 0.07, 1.5, True, boundary), rtol=RTOL, atol=1e-5)
+    x = th.from_numpy(medium.astype(np.float32))[None]
+    assert np.allclose(got_sense, ag.model.forward(x)[0].detach().numpy(), rtol=RTOL, atol=1e-5)
+
+
 def test_neural_automata_weights_written_in_place_are_seen(die):
     """The evolution loop loads every candidate through `param.data.view(-1)[:] = …` (core/agent/evo.py is driven that way
     by evotorch's NEProblem, examples/learning_agents.py): neither `_version` nor `data_ptr()` of the weight changes, so a

@@ -29,6 +29,21 @@ def test_oracle_conv_stack_equals_torch_conv2d(field_size, kernel_sizes):
     assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
 
 
+@pytest.mark.parametrize('boundary', ['circular', 'zeros', 'reflect', 'replicate'])
+@pytest.mark.parametrize('field_size,kernel_sizes', [((12, 8), (3, 5)), ((9, 7), (7,)), ((16, 16), (3, 3, 3))])
+def test_oracle_conv_boundaries_equal_torch_padding_modes(boundary, field_size, kernel_sizes):
+    """ConvolutionModel(boundary=…) (core/agent/evo.py:51,86): every padding_mode torch's Conv2d knows, oracle vs torch."""
+    th.manual_seed(len(boundary) + sum(field_size))
+    convs = [nn.Conv2d(3, 3, k, padding='same', padding_mode=boundary, bias=False).double() for k in kernel_sizes]
+    x = th.rand(1, 3, *field_size, dtype=th.float64)
+    y = x
+    for c in convs:
+        y = c(y)
+    want = th.tanh(y)[0].detach().numpy()
+    got = R.nca_sense(x[0].numpy(), [c.weight.detach().numpy() for c in convs], boundary=boundary)
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-14)
+
+
 def test_oracle_conv_known_answers():
     """A single 3×3 kernel with one non-zero tap is a circular shift; the identity tap returns the input; channels mix
     by the (o, i) entry."""
