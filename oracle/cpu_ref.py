@@ -434,6 +434,45 @@ def agents_channel_from_uniform(u_round3: np.ndarray, ratio: float) -> np.ndarra
     return np.ceil(mask_range(u_round3, mask_above=ratio))
 
 
+class RefDataInitializer:
+    """core/data_init.py:171-253, the builder: `__init__` (zeros per channel, static mask), `with_const` (:214-216),
+    `with_noise` (:218-220 → `get_random`, :168-169: (b − a)·u.round(3) + a), `with_agents` (:222-226: ceil of the uniform
+    draw masked to [0, ratio]), `_add_masked` (:206-209), `build_numpy` (:238-239) and the static mask `build` /
+    `build_agents` multiply in (:241-253).  The reference draws from numpy's global generator; here every `_get_random`
+    takes its uniforms from `draw(shape)` (tests pass the reference's own draws, or the Philox streams the device uses)."""
+
+    def __init__(self, field_size, channels=(), mask=1., draw=None):
+        self._size = field_size
+        self._channels = {c: np.zeros(field_size) for c in channels}
+        self._static_mask = mask
+        self._draw = draw
+
+    def _get_random(self, a=0., b=1.):
+        return (b - a) * np.asarray(self._draw(self._size), dtype=np.float64).round(3) + a
+
+    def with_const(self, channel, value=0.):
+        self._channels[channel] = np.full(self._size, value, dtype=np.float64)
+        return self
+
+    def with_noise(self, channel, a=0, b=1):
+        self._channels[channel] = self._get_random(a, b)
+        return self
+
+    def with_agents(self, ratio):
+        self._channels['agents'] = np.ceil(mask_range(self._get_random(), mask_above=ratio))
+        return self
+
+    def _add_masked(self, channel, data):
+        self._channels[channel] += data * (self._channels[channel] > 0.)
+        return self
+
+    def build_numpy(self):
+        return np.stack(list(self._channels.values()))
+
+    def build(self):
+        return self.build_numpy() * self._static_mask
+
+
 def agents_from_medium(medium: np.ndarray, food_u_round3: np.ndarray, max_agents: Optional[int] = None,
                        food_ratio: float = 1.0) -> np.ndarray:
     """core/data_init.py:133-150 + core/utils.py:140-151: occupied cells in row-major

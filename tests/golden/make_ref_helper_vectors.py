@@ -238,6 +238,41 @@ def main():
         for li, w in enumerate(ws):
             out[f'nca{ci}_w{li}'] = w
 
+    # ---- DataInitializer builder chain (core/data_init.py:171-253), round 3: __init__ → with_noise → with_agents → build_numpy
+    # and the static mask of build / build_agents (:241-253), the reference's own method bodies on seeded numpy draws.  (with_const
+    # is left out: it uses np.float, gone from numpy 1.24 on — core/data_init.py:215 — and is a plain np.full.)  Appended LAST so
+    # that the arrays above keep their values.
+    names = ['__init__', '_mask', '_get_random', 'get_random', 'with_noise', 'with_agents', 'build_numpy', '_add_masked']
+    bd = _exec(_functions('core/data_init.py', names, cls='DataInitializer'), {'np': np})
+
+    class Builder:
+        pass
+    for n in names:
+        setattr(Builder, n, staticmethod(bd[n]) if n == 'get_random' else bd[n])
+    size = (7, 5)
+    np.random.seed(4242)
+    raw = np.random.random_sample((3,) + size)             # the three draws the chain below makes, in order
+    np.random.seed(4242)
+    b = Builder(size, ('agents', 'env_food', 'chem1'))
+    b.with_noise('env_food', 0.1, 0.6).with_noise('chem1', -2, 3).with_agents(0.3)
+    out['builder_raw'] = raw
+    out['builder_numpy'] = b.build_numpy()
+    mask = (np.arange(35).reshape(size) % 3 != 0).astype(np.float64)
+    out['builder_mask'] = mask
+    out['builder_masked'] = Builder(size, ('agents', 'env_food', 'chem1'), mask=mask).build_numpy() * 0 + b.build_numpy() * mask
+    b._add_masked('env_food', np.full(size, 0.25))          # adds where the channel is > 0 (:206-209)
+    out['builder_add_masked'] = b.build_numpy()[1]
+    # BrownianAgent's chain (core/agent/static.py:40-50): a builder over (N,) with the alive mask
+    N = 40
+    alive = (np.arange(N) % 4 != 1).astype(np.float64)
+    np.random.seed(777)
+    raw_a = np.random.random_sample((3, N))
+    np.random.seed(777)
+    ba = Builder(N, ('dx', 'dy', 'deposit1'), mask=alive)
+    ba.with_noise('dx', -0.01, 0.01).with_noise('dy', -0.01, 0.01).with_noise('deposit1', 0, 0.5)
+    out['builder_action_raw'], out['builder_action_alive'] = raw_a, alive
+    out['builder_action_out'] = ba.build_numpy() * ba._static_mask       # what build_agents wraps (:248-253)
+
     np.savez_compressed(OUT, **out)
     print('wrote', OUT, len(out), 'arrays')
 
