@@ -57,6 +57,8 @@ class PicState:
         self.k1_threads = 0          # tuning knob of die_pic (0 = library default)
         self.cur = 0                 # layout index that holds the agents
         self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
+        self._held_layout = self._out_layout = None      # their die_pic_layout struct / the one of the buffers being written
+        self._two_key = self._two = None
         self.agent = None
         self.steps_since_check = 0   # binned steps whose error word nobody has read yet
         self.lazy_actions = True     # PhysarumAgent: the step keeps the action in registers, PendingAction re-derives it on demand
@@ -69,8 +71,11 @@ class PicState:
 
     def _struct(self, cur_tensors, other_tensors, stages: int = 0, status_out=None) -> _lib.Pic:
         lay = [None, None]
-        lay[self.cur] = self._layout(cur_tensors, self.meta[self.cur])
-        lay[1 - self.cur] = self._layout(other_tensors, self.meta[1 - self.cur])
+        # (the layout a step writes is the one the next step reads: its struct is kept with `held` — host time per step
+        # matters to Env(sync=True), where nothing hides it)
+        kept = self._held_layout if cur_tensors is self.held else None
+        lay[self.cur] = kept if kept is not None else self._layout(cur_tensors, self.meta[self.cur])
+        lay[1 - self.cur] = self._out_layout = self._layout(other_tensors, self.meta[1 - self.cur])
         return _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
                         _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code), _ptr(self.rim_cnt), status_out)
 
@@ -79,6 +84,13 @@ class PicState:
         here it only settles whether the deposit plane of the three-launch form has to exist.)"""
         if not self.fused:
             return False
+        key = (agent._scale, env.dynamics.diffuse_sigma)
+        if key == self._two_key:
+            return self._two
+        self._two_key, self._two = key, self._two_launch(env, agent)
+        return self._two
+
+    def _two_launch(self, env, agent) -> bool:
         W, H = self._world_shape
         reach = float(np.float32(abs(agent._scale)) * np.float32(max(W, H) - 1))      # (float32, as the library computes it)
         R = int(4.0 * float(np.float32(env.dynamics.diffuse_sigma)) + 0.5)
@@ -98,6 +110,7 @@ class PicState:
         agent._hd_hi, agent._hd_lo = new[4], new[5]
         agent._order = A.slot
         self.held, self.agent = tuple(new), agent
+        self._held_layout, self._out_layout = self._out_layout, None
 
     def _out_tensors(self, env):
         slot = torch.empty(self.cap, dtype=torch.int32, device=env.device)
