@@ -38,24 +38,74 @@
 #ifndef PIC_K2_FEED
 #define PIC_K2_FEED 1
 #endif
+// A/B knobs (scratch/build_variant.sh).  PIC_NT: which streams of the two step kernels are non-temporal accesses (`nt`:
+// the line is first in line for eviction from L2) — one bit per stream, see the pic_ld / pic_st call sites:
+//   0 agent kernel: the six agent streams it reads      1 … the agent_food / heading streams it writes
+//   2 … x, y, slot, deposit, rim lists it writes         3 field kernel: agent streams and rim lists it reads
+//   4 field kernel: food tile read   5 agent kernel: food tile read   6 field kernel: chem store   7 agent kernel: chem window
+//   8 field kernel: chem window      9 field kernel: food store
+// PIC_PRIO = s_setprio around the phases that issue the long loads.
+#ifndef PIC_NT
+#define PIC_NT 3      // (0 → 3: the field kernel 67.6 → 65.1 µs — more of what it re-reads survives in L2; every other bit: nothing or worse)
+#endif
+typedef uint32_t pic_u4v __attribute__((ext_vector_type(4)));
+typedef uint32_t pic_u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ constexpr bool pic_nt(int bit) { return bit >= 0 && ((PIC_NT >> bit) & 1); }
+template <int BIT, class V> __device__ __forceinline__ V pic_ld(const V* a) {
+    if constexpr (pic_nt(BIT)) return __builtin_nontemporal_load(a); else return *a;
+}
+template <int BIT, class V> __device__ __forceinline__ void pic_st(V* a, V v) {
+    if constexpr (pic_nt(BIT)) __builtin_nontemporal_store(v, a); else *a = v;
+}
+template <int BIT> __device__ __forceinline__ uint4 pic_ld4(const void* a) {
+    if constexpr (pic_nt(BIT)) { const pic_u4v t = __builtin_nontemporal_load((const pic_u4v*)a); return make_uint4(t.x, t.y, t.z, t.w); }
+    else return *(const uint4*)a;
+}
+template <int BIT> __device__ __forceinline__ void pic_st4(void* a, uint4 v) {
+    if constexpr (pic_nt(BIT)) { pic_u4v t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; __builtin_nontemporal_store(t, (pic_u4v*)a); }
+    else *(uint4*)a = v;
+}
+template <int BIT> __device__ __forceinline__ uint2 pic_ld2(const void* a) {
+    if constexpr (pic_nt(BIT)) { const pic_u2v t = __builtin_nontemporal_load((const pic_u2v*)a); return make_uint2(t.x, t.y); }
+    else return *(const uint2*)a;
+}
+template <int BIT> __device__ __forceinline__ void pic_st2(void* a, uint2 v) {
+    if constexpr (pic_nt(BIT)) { pic_u2v t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, (pic_u2v*)a); }
+    else *(uint2*)a = v;
+}
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
-    static __device__ __forceinline__ void ld(const float* p, float v[4]) { const float4 t = *(const float4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    static __device__ __forceinline__ void st(float* p, const float v[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+    template <int BIT = -1> static __device__ __forceinline__ void ld(const float* p, float v[4]) {
+        const uint4 t = pic_ld4<BIT>(p);
+        v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+    }
+    template <int BIT = -1> static __device__ __forceinline__ void st(float* p, const float v[4]) {
+        pic_st4<BIT>(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    }
 };
 template <> struct Vec4<__half> {
-    static __device__ __forceinline__ void ld(const __half* p, float v[4]) {
-        const uint2 t = *(const uint2*)p;
+    template <int BIT = -1> static __device__ __forceinline__ void ld(const __half* p, float v[4]) {
+        const uint2 t = pic_ld2<BIT>(p);
         const __half2 a = *(const __half2*)&t.x, b = *(const __half2*)&t.y;
         v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
     }
-    static __device__ __forceinline__ void st(__half* p, const float v[4]) {
+    template <int BIT = -1> static __device__ __forceinline__ void st(__half* p, const float v[4]) {
         const __half2 a = __halves2half2(die_f2h(v[0]), die_f2h(v[1])), b = __halves2half2(die_f2h(v[2]), die_f2h(v[3]));
         uint2 t; t.x = *(const uint32_t*)&a; t.y = *(const uint32_t*)&b;
-        *(uint2*)p = t;
+        pic_st2<BIT>(p, t);
     }
 };
 
+// PIC_PRIO_K1 / PIC_PRIO_KB: s_setprio levels, one hex digit per point of the kernel (agent kernel: start, agent streams
+// issued, chunk loop, after the chunk loop; field kernel: start, window loads issued, x pass, unused)
+#ifndef PIC_PRIO_K1
+#define PIC_PRIO_K1 0x3000      // (the waves of a starting workgroup issue their loads ahead of the resident workgroups' chunk loops: 83.5 → 81.4 µs;
+#endif                          //  raising the chunk loop, or the waves that take a second chunk: worse — DESIGN §3.1)
+#ifndef PIC_PRIO_KB
+#define PIC_PRIO_KB 0x0000
+#endif
+#define PIC_SETPRIO(word, i) do { if ((i) == 0 ? (((word) >> 12) & 3) != 0 : ((((word) >> (12 - 4 * (i))) & 3) != (((word) >> (16 - 4 * (i))) & 3))) \
+                                      __builtin_amdgcn_s_setprio(((word) >> (12 - 4 * (i))) & 3); } while (0)
 #ifndef PIC_K1_BLOCK
 #define PIC_K1_BLOCK 512       // ≈ 614 agents stand on a 64×64 tile at ratio 0.15: one or two trips of the loop
 #endif
@@ -161,13 +211,13 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
 // of blockDim >> cs: per vector one add, two clamps, a multiply-add and the address — the first cut, with a division for
 // the row and tests around every load, spent a quarter of the kernel's instructions here.  Rows / columns outside the
 // world are never read by anybody (probes clamp at the world's edge): their loads are clamped into the plane, no branch.
-template <typename T>
+template <typename T, int NTB = -1>
 struct PicStage {
     const T* plane;
     int gx0, gy0, vpr, rows, W, H, cs;
     __device__ __forceinline__ uint4 load(int row, int gyc) const {
         const int gx = min(max(gx0 + min(row, rows - 1), 0), W - 1);
-        return *(const uint4*)(plane + (__mul24(gx, H) + gyc));
+        return pic_ld4<NTB>(plane + (__mul24(gx, H) + gyc));
     }
     __device__ __forceinline__ int column() const { return min((int)threadIdx.x & ((1 << cs) - 1), vpr - 1); }
     __device__ __forceinline__ int col_cell(int cv) const { return min(max(gy0 + cv * (16 / (int)sizeof(T)), 0), H - 16 / (int)sizeof(T)); }
@@ -232,6 +282,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
     if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
     PIC_STAMP(0);
+    PIC_SETPRIO(PIC_PRIO_K1, 0);
     // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
     // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
     const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
@@ -239,8 +290,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const T* food = (const T*)p.food;
     constexpr int SV = 16 / (int)sizeof(T);
     const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
-    const PicStage<T> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.cs_c};
-    const PicStage<T> st_f = {food, x0, y0, TY / SV, TX, p.g.W, p.g.H, p.cs_f};
+    const PicStage<T, 7> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.cs_c};
+    const PicStage<T, 5> st_f = {food, x0, y0, TY / SV, TX, p.g.W, p.g.H, p.cs_f};
     uint4 sc[6], sf[2];                   // 64×64 tile, margin 12, 512 threads: 88 rows / 16 per pass, 64 rows / 32 per pass
     if (STAGE) {
         st_c.issue(sc);
@@ -259,8 +310,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         int r = 1;
         while (idx >= s_pre[r + 1]) ++r;
         cj = s_base[r] + (idx - s_pre[r]);
-        cX = p.in.x[cj];
-        cY = p.in.y[cj];
+        cX = pic_ld<0>(&p.in.x[cj]);
+        cY = pic_ld<0>(&p.in.y[cj]);
     }
     const uint32_t pidx = (uint32_t)(wave * DIE_WAVE + lane);
     const bool phas = pidx < own;
@@ -268,8 +319,10 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     float pA = 0.f;
     if (phas) {
         const uint32_t j = base0 + pidx;
-        pX = p.in.x[j]; pY = p.in.y[j]; pS = p.in.slot[j]; pHh = p.in.hhi[j]; pHl = p.in.hlo[j]; pA = p.in.agent_food[j];
+        pX = pic_ld<0>(&p.in.x[j]); pY = pic_ld<0>(&p.in.y[j]); pS = pic_ld<0>(&p.in.slot[j]); pHh = pic_ld<0>(&p.in.hhi[j]); pHl = pic_ld<0>(&p.in.hlo[j]);
+        pA = pic_ld<0>(&p.in.agent_food[j]);
     }
+    PIC_SETPRIO(PIC_PRIO_K1, 1);
     FwdTileMem<T, TILED> tm;
     tm.g = p.g;
     if (STAGE) {
@@ -313,6 +366,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         }
         __syncthreads();                                           // publishes the staged tiles and the list
         PIC_STAMP(3);
+        PIC_SETPRIO(PIC_PRIO_K1, 2);
         const uint32_t n_own = cb == 0 ? own : 0u, count = n_own + s_nlist;
         bool first = cb == 0;
         for (;;) {                         // a wave's first chunk is fixed (its streams are already here), then it takes
@@ -337,12 +391,12 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 if (first && idx < n_own) {
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
                 } else {
-                    X = p.in.x[j];                                 // all six streams in flight together
-                    Y = p.in.y[j];
-                    sid = p.in.slot[j];
-                    hh = p.in.hhi[j];
-                    hl = p.in.hlo[j];
-                    af = p.in.agent_food[j];
+                    X = pic_ld<0>(&p.in.x[j]);                       // all six streams in flight together
+                    Y = pic_ld<0>(&p.in.y[j]);
+                    sid = pic_ld<0>(&p.in.slot[j]);
+                    hh = pic_ld<0>(&p.in.hhi[j]);
+                    hl = pic_ld<0>(&p.in.hlo[j]);
+                    af = pic_ld<0>(&p.in.agent_food[j]);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
                 const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
@@ -404,19 +458,19 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
                 if (at < (uint32_t)p.rim_cap) {
                     s_rimc[at] = (uint8_t)code;
-                    p.rim[(size_t)tile * p.rim_cap + at] = make_uint4(X, Y, sid, __float_as_uint(dep));
+                    pic_st4<2>(&p.rim[(size_t)tile * p.rim_cap + at], make_uint4(X, Y, sid, __float_as_uint(dep)));
                 }
             }
             if (act) {
                 if (k < on) {
                     const uint32_t q = obase + k;
-                    p.out.x[q] = X;
-                    p.out.y[q] = Y;
-                    p.out.agent_food[q] = af;
-                    p.out.slot[q] = sid;
-                    p.out.hhi[q] = (uint32_t)__double2hiint(hd);
-                    p.out.hlo[q] = (uint32_t)__double2loint(hd);
-                    p.dep[q] = dep;
+                    pic_st<2>(&p.out.x[q], X);                     // (x, y, slot, deposit are read again by the field kernel)
+                    pic_st<2>(&p.out.y[q], Y);
+                    pic_st<1>(&p.out.agent_food[q], af);
+                    pic_st<2>(&p.out.slot[q], sid);
+                    pic_st<1>(&p.out.hhi[q], (uint32_t)__double2hiint(hd));
+                    pic_st<1>(&p.out.hlo[q], (uint32_t)__double2loint(hd));
+                    pic_st<2>(&p.dep[q], dep);
                 } else {
                     atomicOr(p.error, 1u);
                 }
@@ -430,6 +484,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         }
     }
     PIC_STAMP(4);
+    PIC_SETPRIO(PIC_PRIO_K1, 3);
     gsum = die_wave_sum(gsum);
     if (lane == 0) s_gain[threadIdx.x / DIE_WAVE] = gsum;
     if (TILED) {
@@ -446,7 +501,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         // (a segment too long for the 24-bit positions counts as an overflowing list: the reader scans it)
         const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(s_cnt >> 42) & 0x1FFFFFu;
         for (uint32_t i = threadIdx.x; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += blockDim.x)
-            ((uint32_t*)p.rim_code)[((size_t)tile * p.rim_cap) / 4 + i] = ((const uint32_t*)s_rimc)[i];
+            pic_st<2>(&((uint32_t*)p.rim_code)[((size_t)tile * p.rim_cap) / 4 + i], ((const uint32_t*)s_rimc)[i]);
         if (threadIdx.x == 0) p.rim_cnt[tile] = nr;
     }
     if (threadIdx.x == 0) {
@@ -691,6 +746,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     const int W = p.g.W, H = p.g.H;
     [[maybe_unused]] const int tile = tx * p.nty + ty;
     PIC_STAMP(8);
+    PIC_SETPRIO(PIC_PRIO_KB, 0);
     const T* chem = (const T*)a.chem;
     T* food = (T*)p.food;
     // 1. everything that depends on the tile index only goes out first: the per-tile words, the rim lists, the chem window,
@@ -708,17 +764,18 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     // exists is known once the counts are here)
     static_assert(NE == 4 && CAPR % 4 == 0 && 9 * CAPR <= 4 * BLOCK, "one word of codes per thread");
     const int rl = 4 * (int)threadIdx.x / CAPR, ri = 4 * (int)threadIdx.x - rl * CAPR;
-    const uint32_t rcodes = rl < 9 ? ((const uint32_t*)a.rim_code)[((size_t)ring_tile(rl) * CAPR + ri) / 4] : 0u;
+    const uint32_t rcodes = rl < 9 ? pic_ld<3>(&((const uint32_t*)a.rim_code)[((size_t)ring_tile(rl) * CAPR + ri) / 4]) : 0u;
     constexpr int NCV = (WR * NV + BLOCK - 1) / BLOCK;
     static_assert(NCV <= 3, "three window vectors per thread at most");       // (named registers: as an array they went to scratch)
     auto window_load = [&](int q) {
         const int i = min((int)threadIdx.x + q * BLOCK, WR * NV - 1);       // (surplus threads load the last vector again: no branch)
         const int r = i / NV, v = i - r * NV;
-        return *(const uint4*)(chem + ((int64_t)pic_wrap(x0 - R + r, W) * H + pic_wrap(y0 - A + v * A, H)));
+        return pic_ld4<8>(chem + ((int64_t)pic_wrap(x0 - R + r, W) * H + pic_wrap(y0 - A + v * A, H)));
     };
     uint4 cv0 = window_load(0), cv1 = cv0, cv2 = cv0;
     if constexpr (NCV > 1) cv1 = window_load(1);
     if constexpr (NCV > 2) cv2 = window_load(2);
+    PIC_SETPRIO(PIC_PRIO_KB, 1);
     for (int i = threadIdx.x; i < WR * WC / 4; i += BLOCK) ((uint4*)s_claim)[i] = make_uint4(0u, 0u, 0u, 0u);
     static_assert((WR * WC) % 4 == 0, "16-byte zeroing");
     if (threadIdx.x < 9) {
@@ -810,10 +867,10 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             if (u < 2) {
                 if (threadIdx.x + u * BLOCK < nown) {
                     const uint32_t j = own0 + threadIdx.x + u * BLOCK;
-                    X[u] = p.out.x[j]; Y[u] = p.out.y[j]; cs[u] = p.out.slot[j] + 1u; cd[u] = __float_as_uint(p.dep[j]); cw[u] = 0u;
+                    X[u] = pic_ld<3>(&p.out.x[j]); Y[u] = pic_ld<3>(&p.out.y[j]); cs[u] = pic_ld<3>(&p.out.slot[j]) + 1u; cd[u] = __float_as_uint(pic_ld<3>(&p.dep[j])); cw[u] = 0u;
                 }
             } else if (rj[u - 2] != 0xFFFFFFFFu) {
-                const uint4 q = rrec[rj[u - 2]];
+                const uint4 q = pic_ld4<3>(&rrec[rj[u - 2]]);
                 X[u] = q.x; Y[u] = q.y; cs[u] = q.z + 1u; cd[u] = q.w; cw[u] = 0u;
             }
         }
@@ -822,7 +879,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 #pragma unroll
             for (int q = 0; q < FG; ++q) {
                 const int i = ((int)threadIdx.x + q * BLOCK) * 4;
-                if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::ld(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
+                if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::template ld<4>(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
             }
         }
 #pragma unroll
@@ -865,12 +922,13 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             if (occ[0] || occ[1] || occ[2] || occ[3]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
-                Vec4<T>::st(food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
+                Vec4<T>::template st<9>(food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
             }
         }
     }
     __syncthreads();
     PIC_STAMP(12);
+    PIC_SETPRIO(PIC_PRIO_KB, 2);
     // 5. x pass (axis 0): column c of the window, RB output rows per item, the 2R + 1 rows of the stencil in registers
     constexpr int RB = TX >= 64 ? 16 : 8;
     for (int item = threadIdx.x; item < WC * (TX / RB); item += BLOCK) {
@@ -912,7 +970,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             for (int k = 0; k < R; ++k) t += (xf[cc - R + k] + xf[cc + R - k]) * a.w[k];
             o[j] = t * a.keep;
         }
-        Vec4<T>::st(dst + (int64_t)(x0 + row) * H + y0 + 4 * cg, o);
+        Vec4<T>::template st<6>(dst + (int64_t)(x0 + row) * H + y0 + 4 * cg, o);
     }
     PIC_STAMP(14);
 }
