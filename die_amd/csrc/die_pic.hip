@@ -46,7 +46,7 @@
 //   8 field kernel: chem window      9 field kernel: food store
 // PIC_PRIO = s_setprio around the phases that issue the long loads.
 #ifndef PIC_NT
-#define PIC_NT 3      // (0 → 3: the field kernel 67.6 → 65.1 µs — more of what it re-reads survives in L2; every other bit: nothing or worse)
+#define PIC_NT 0      // (3 buys the field kernel 2.5 µs at 4096² fp32 and costs the agent kernel 3–5 % at 8192² and with fp16 planes: DESIGN §3.1)
 #endif
 typedef uint32_t pic_u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t pic_u2v __attribute__((ext_vector_type(2)));

@@ -760,16 +760,16 @@ class DistEnv:
     def _refresh_ghosts(self, action, after_step: bool = False):
         """Re-seat owners, ghosts and the chem / food halos (see _step_ghost)."""
         from .device_array import PendingAction
+        if not self.geo.DIRS:                      # one rank: the tile is the world, nobody to exchange with (and the tile order stays)
+            self._owned = self.agents.N
+            self._ghosts_fresh = True
+            return
         self._pic_void()                    # arrays are edited in place below: an un-read lazy action first, then no tile order
         # a consumed action, or one whose forward() has not run yet, holds nothing worth sending
         self._send_action = not after_step and not (isinstance(action, PendingAction) and action.pending)
         if self._send_action and action.data.shape[1] < self.capacity:
             raise ValueError(f'the action arrays hold {action.data.shape[1]} slots, the local agent arrays {self.capacity}: arriving '
                              f'ghosts bring their action with them (build the action for `env.capacity` slots)')
-        if not self.geo.DIRS:                      # one rank: the tile is the world, nobody to exchange with
-            self._owned = self.agents.N
-            self._ghosts_fresh = True
-            return
         if self.device.type == 'cuda' and os.environ.get('DIE_GHOST_REFRESH', 'native') != 'torch':
             return self._refresh_ghosts_native(action)
         return self._refresh_ghosts_torch(action)
