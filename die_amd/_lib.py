@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class Medium(C.Structure):
@@ -74,6 +74,16 @@ class Pic(C.Structure):
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p)]
+
+
+class PicSide(C.Structure):          # die_pic_side: one neighbour of the ghost refresh by tiles
+    _fields_ = [('tx0', C.c_int32), ('ty0', C.c_int32), ('ntx', C.c_int32), ('nty', C.c_int32), ('hx0', C.c_int32), ('hy0', C.c_int32),
+                ('cap', C.c_int64), ('send_counts', C.c_void_p), ('send_rec', C.c_void_p), ('recv_counts', C.c_void_p), ('recv_rec', C.c_void_p)]
+
+
+PIC_GHOST_SUMMARY_WORDS = 19
+PIC_GHOST_FLAGS = {1: 'a tile holds another number of agents than its per-tile words say', 2: 'a band holds more agents than a message',
+                   4: 'a received count is impossible', 8: 'the agents do not fit the local arrays'}
 
 
 class Batch(C.Structure):
@@ -173,6 +183,8 @@ _SIGNATURES = {
                                            C.c_void_p]),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),
     'die_pic_action_physarum': (C.c_int, [_P(Pic), C.c_int32, _P(GradientAgent), _P(Action), C.c_void_p]),
+    'die_pic_ghost_pack': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_void_p, C.c_void_p]),
+    'die_pic_ghost_merge': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_int64, C.c_void_p, C.c_void_p]),
     'die_conv2d_circular': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,
                                       C.c_void_p, C.c_int32, C.c_void_p]),
     'die_conv2d': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,

@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'libdie_hip.so')
-SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip', 'die_pack.hip', 'die_ghost.hip', 'die_render.hip', 'die_pic.hip', 'die_nca.hip']
+SOURCES = ['die_agents.hip', 'die_env.hip', 'die_init.hip', 'die_sort.hip', 'die_pack.hip', 'die_ghost.hip', 'die_render.hip', 'die_pic.hip', 'die_pic_refresh.hip', 'die_nca.hip']
 HEADERS = ['die_common.h', 'die_rng.h', 'die_forward.h', os.path.join('..', '..', 'include', 'die_hip.h')]
 # -ffp-contract=on: fuse a*b+c only inside one source expression.  hipcc's default (fast) fuses across
 # statements, so the same inlined device function could round differently in two kernels (the fused and the

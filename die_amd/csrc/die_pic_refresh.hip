@@ -1,0 +1,304 @@
+// Ghost refresh of a decomposed rank BY TILES (include/die_hip.h die_pic_ghost_pack / die_pic_ghost_merge; die_amd/dist.py
+// DistEnv._refresh_ghosts_tiles).  No reference counterpart (the reference has no distributed code).
+//
+// The agents of a rank are held in a tile-binned layout (die_pic_layout: per tile a segment of stayers, then of the agents
+// that left the tile in the last step) over planes whose halo is a whole number of tiles deep.  Then nothing about a refresh
+// needs a look at every agent:
+//   * an agent is OWNED iff it stands on an interior tile — the interior tiles' agents are kept, the halo tiles' are dropped;
+//   * what a neighbour needs as its ghosts are the agents standing on the interior tiles next to that side (the band), tile
+//     by tile: its halo tiles become copies of them (agent coordinates are global: nothing is translated);
+//   * the new layout is, tile by tile, either "what stands on this interior tile now" or "what arrived for this halo tile".
+// "What stands on tile t" = t's stayers + the leavers of the 8 tiles around it that landed on t — the gather the agent kernel
+// of the step does anyway (csrc/die_pic.hip k_pic_forward_move); the counts are known before anything is copied (s + inc).
+#include "die_common.h"
+
+#define RF_BLOCK 256
+#define RF_SIDES 8
+// words of the summary (int64): [0] agents after the refresh, [1] of them owned, [2, 10) sent per side, [10, 18) arrived
+// per side, [18] flags
+#define RF_SUM_SENT 2
+#define RF_SUM_ARRIVED 10
+#define RF_SUM_FLAGS 18
+#define RF_FLAG_COUNT 1u        // a tile holds another number of agents than its per-tile words say
+#define RF_FLAG_SEND_CAP 2u     // a band holds more agents than a message
+#define RF_FLAG_RECV 4u         // a received count is impossible (more than the message holds)
+#define RF_FLAG_CAPACITY 8u     // the agents do not fit the local arrays
+
+struct RfSide {
+    int tx0, ty0, ntx, nty;     // band: tiles of the interior next to this side (what the neighbour gets) …
+    int hx0, hy0;               // … halo: same shape, where the message arriving from that neighbour goes
+    uint32_t cap;
+    uint32_t *send_counts, *send_rec;
+    const uint32_t *recv_counts, *recv_rec;
+};
+
+struct RfArgs {
+    die_geo g;
+    int xs, ys, NTX, NTY;
+    int ix0, ix1, iy0, iy1;     // interior tiles [ix0, ix1) × [iy0, iy1)
+    int n_sides;
+    int first[RF_SIDES + 1];    // band tiles of the sides before side k
+    die_pic_layout src, dst;
+    RfSide side[RF_SIDES];
+    long long* summary;
+    uint32_t capacity;
+};
+
+__device__ __forceinline__ int rf_wrap(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
+__device__ __forceinline__ int rf_tile_of(const RfArgs& a, uint32_t X, uint32_t Y) {
+    const int r = die_plane_coord(die_cell((int64_t)X, a.g.gW), a.g.ox, a.g.W, a.g.gW);
+    const int c = die_plane_coord(die_cell((int64_t)Y, a.g.gH), a.g.oy, a.g.H, a.g.gH);
+    return (r >> a.xs) * a.NTY + (c >> a.ys);
+}
+__device__ __forceinline__ void rf_flag(const RfArgs& a, uint32_t f) { atomicOr((unsigned long long*)&a.summary[RF_SUM_FLAGS], (unsigned long long)f); }
+
+// Σ v(i) over i < n, by the whole workgroup (n is small: the tiles of one side)
+template <class F> __device__ __forceinline__ uint32_t rf_block_sum(int n, F v) {
+    __shared__ uint32_t s_red[RF_BLOCK / DIE_WAVE];
+    uint32_t t = 0;
+    for (int i = threadIdx.x; i < n; i += RF_BLOCK) t += v(i);
+    t = (uint32_t)die_wave_sum((long long)t);
+    __syncthreads();
+    if ((threadIdx.x & (DIE_WAVE - 1)) == 0) s_red[threadIdx.x / DIE_WAVE] = t;
+    __syncthreads();
+    uint32_t r = 0;
+    for (int w = 0; w < RF_BLOCK / DIE_WAVE; ++w) r += s_red[w];
+    return r;
+}
+
+// The agents standing on tile (tx, ty) in layout L → put(i, x, y, agent_food, slot, heading_hi, heading_lo), i = 0 … count − 1
+// (stayers first, in their order; arrivals in any order — nothing depends on the order inside a tile: results are keyed by slot).
+// Returns the count (uniform).  Three dependent round trips: the 9 tiles' words, then every stayer and every candidate
+// arrival (the leavers of the 8 tiles around, as ONE index range) with all six streams in flight, then the stores.
+template <class PUT> __device__ __forceinline__ uint32_t rf_gather(const RfArgs& a, const die_pic_layout& L, int tx, int ty, PUT put) {
+    __shared__ uint32_t s_cnt, s_base[9], s_pre[10];
+    const int t = tx * a.NTY + ty;
+    __syncthreads();                                            // (s_* may still be read by a previous call's stragglers)
+    if (threadIdx.x < 9) {
+        const int k = threadIdx.x, nb = rf_wrap(tx + k / 3 - 1, a.NTX) * a.NTY + rf_wrap(ty + k % 3 - 1, a.NTY);
+        uint32_t o = L.off[nb], s = L.s[nb], n = L.n[nb];
+        if (s > n) { s = n = 0; rf_flag(a, RF_FLAG_COUNT); }
+        // [4] = the tile itself: its stayers; the others: their leavers (a neighbour that IS the tile — fewer than 3 tiles along
+        // an axis — cannot occur: die_pic needs 3×3)
+        s_base[k] = k == 4 ? o : o + s;
+        s_pre[k] = k == 4 ? s : (nb == t ? 0u : n - s);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t own = s_pre[4];
+        uint32_t run = 0;
+        for (int k = 0; k < 9; ++k) { const uint32_t len = k == 4 ? 0u : s_pre[k]; s_pre[k] = run; run += len; }
+        s_pre[9] = run;                                         // candidates; s_pre[k] = first candidate of neighbour k (k = 4: empty)
+        s_cnt = own;
+    }
+    __syncthreads();
+    const uint32_t o = s_base[4], own = s_cnt, ncand = s_pre[9];
+    for (uint32_t i = threadIdx.x; i < own; i += RF_BLOCK) {
+        const uint32_t j = o + i;
+        put(i, L.x[j], L.y[j], __float_as_uint(L.agent_food[j]), L.slot[j], L.heading_hi[j], L.heading_lo[j]);
+    }
+    __syncthreads();                                            // (s_cnt is read above, added to below)
+    const int lane = threadIdx.x & (DIE_WAVE - 1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t c0 = threadIdx.x - lane; c0 < ncand; c0 += RF_BLOCK) {                 // wave-uniform trip count
+        const uint32_t c = c0 + lane;
+        uint32_t X = 0, Y = 0, af = 0, sl = 0, hh = 0, hl = 0;
+        bool hit = false;
+        if (c < ncand) {
+            int k = 0;
+            while (k < 8 && c >= s_pre[k + 1]) ++k;
+            const uint32_t j = s_base[k] + (c - s_pre[k]);
+            X = L.x[j]; Y = L.y[j]; af = __float_as_uint(L.agent_food[j]); sl = L.slot[j]; hh = L.heading_hi[j]; hl = L.heading_lo[j];
+            hit = rf_tile_of(a, X, Y) == t;
+        }
+        const unsigned long long m = __ballot(hit);
+        if (!m) continue;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+        at = __shfl(at, 0, DIE_WAVE);
+        if (hit) put(at + (uint32_t)__popcll(m & below), X, Y, af, sl, hh, hl);
+    }
+    __syncthreads();
+    return s_cnt;
+}
+
+// one workgroup per band tile: the tile's agents → the message of its side, behind those of the side's earlier tiles
+__global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_pack(RfArgs a) {
+    int k = 0;
+    while (k + 1 < a.n_sides && (int)blockIdx.x >= a.first[k + 1]) ++k;
+    const RfSide& S = a.side[k];
+    const int i = (int)blockIdx.x - a.first[k], ti = i / S.nty, tj = i - ti * S.nty;
+    const die_pic_layout& L = a.src;
+    auto expect = [&](int q) { const int t = (S.tx0 + q / S.nty) * a.NTY + S.ty0 + q % S.nty; return L.s[t] + L.inc[t]; };
+    const uint32_t before = rf_block_sum(i, expect), cap = S.cap;
+    uint32_t* rec = S.send_rec;
+    const uint32_t c = rf_gather(a, L, S.tx0 + ti, S.ty0 + tj, [&](uint32_t q, uint32_t X, uint32_t Y, uint32_t af, uint32_t sl, uint32_t hh, uint32_t hl) {
+        const uint32_t at = before + q;
+        if (at >= cap) return;
+        rec[at] = X; rec[cap + at] = Y; rec[2 * cap + at] = af; rec[3 * cap + at] = sl; rec[4 * cap + at] = hh; rec[5 * cap + at] = hl;
+    });
+    if (threadIdx.x == 0) {
+        S.send_counts[i] = c;
+        if (c != expect(i)) rf_flag(a, RF_FLAG_COUNT);
+        if (before + c > cap) rf_flag(a, RF_FLAG_SEND_CAP);
+        atomicAdd((unsigned long long*)&a.summary[RF_SUM_SENT + k], (unsigned long long)c);
+    }
+}
+
+// which side's message fills halo tile (tx, ty), and which of its tiles; −1: an interior tile (or no neighbour there)
+__device__ __forceinline__ int rf_halo_side(const RfArgs& a, int tx, int ty, int& i) {
+    for (int k = 0; k < a.n_sides; ++k) {
+        const RfSide& S = a.side[k];
+        if (tx >= S.hx0 && tx < S.hx0 + S.ntx && ty >= S.hy0 && ty < S.hy0 + S.nty) { i = (tx - S.hx0) * S.nty + ty - S.hy0; return k; }
+    }
+    i = 0;
+    return -1;
+}
+
+// one workgroup: the new segment sizes and offsets (dst's per-tile words: every agent a stayer), the totals
+__global__ __launch_bounds__(1024) void k_pic_ghost_scan(RfArgs a) {
+    __shared__ uint32_t s[1024], s_own[1024];
+    const int NT = a.NTX * a.NTY, per = (NT + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, NT);
+    auto count = [&](int t, bool& interior) {
+        const int tx = t / a.NTY, ty = t - tx * a.NTY;
+        interior = tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1;
+        if (interior) return a.src.s[t] + a.src.inc[t];
+        int i;
+        const int k = rf_halo_side(a, tx, ty, i);
+        if (k < 0) return 0u;
+        const uint32_t c = a.side[k].recv_counts[i];
+        if (c > a.side[k].cap) { rf_flag(a, RF_FLAG_RECV); return 0u; }
+        return c;
+    };
+    uint32_t sum = 0, own = 0;
+    for (int t = lo; t < hi; ++t) { bool in; const uint32_t c = count(t, in); sum += c; own += in ? c : 0u; }
+    s[threadIdx.x] = sum; s_own[threadIdx.x] = own;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u, w = (int)threadIdx.x >= o ? s_own[threadIdx.x - o] : 0u;
+        __syncthreads();
+        s[threadIdx.x] += v; s_own[threadIdx.x] += w;
+        __syncthreads();
+    }
+    uint32_t run = s[threadIdx.x] - sum;
+    for (int t = lo; t < hi; ++t) {
+        bool in;
+        const uint32_t c = count(t, in);
+        a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+        run += c;
+    }
+    if (threadIdx.x == 1023) {
+        a.summary[0] = (long long)s[1023]; a.summary[1] = (long long)s_own[1023];
+        if (s[1023] > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
+    }
+    if ((int)threadIdx.x < a.n_sides) {
+        const RfSide& S = a.side[threadIdx.x];
+        long long t = 0;
+        for (int i = 0; i < S.ntx * S.nty; ++i) t += (long long)S.recv_counts[i];
+        a.summary[RF_SUM_ARRIVED + threadIdx.x] = t;
+    }
+}
+
+// one workgroup per tile of the planes: its segment of the new layout
+__global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_merge(RfArgs a) {
+    const int tx = blockIdx.y, ty = blockIdx.x, t = tx * a.NTY + ty;
+    const uint32_t base = a.dst.off[t], c = a.dst.n[t], capacity = a.capacity;
+    const die_pic_layout& D = a.dst;
+    if (tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1) {
+        const uint32_t got = rf_gather(a, a.src, tx, ty, [&](uint32_t q, uint32_t X, uint32_t Y, uint32_t af, uint32_t sl, uint32_t hh, uint32_t hl) {
+            const uint32_t at = base + q;
+            if (q >= c || at >= capacity) return;
+            D.x[at] = X; D.y[at] = Y; D.agent_food[at] = __uint_as_float(af); D.slot[at] = sl; D.heading_hi[at] = hh; D.heading_lo[at] = hl;
+        });
+        if (threadIdx.x == 0 && got != c) rf_flag(a, RF_FLAG_COUNT);
+        return;
+    }
+    int i;
+    const int k = rf_halo_side(a, tx, ty, i);
+    if (k < 0 || c == 0) return;
+    const RfSide& S = a.side[k];
+    const uint32_t* counts = S.recv_counts;
+    const uint32_t before = rf_block_sum(i, [&](int q) { return counts[q]; }), cap = S.cap;
+    const uint32_t* rec = S.recv_rec;
+    for (uint32_t q = threadIdx.x; q < c; q += RF_BLOCK) {
+        const uint32_t from = before + q, at = base + q;
+        if (from >= cap || at >= capacity) { rf_flag(a, from >= cap ? RF_FLAG_RECV : RF_FLAG_CAPACITY); continue; }
+        D.x[at] = rec[from]; D.y[at] = rec[cap + from]; D.agent_food[at] = __uint_as_float(rec[2 * cap + from]);
+        D.slot[at] = rec[3 * cap + from]; D.heading_hi[at] = rec[4 * cap + from]; D.heading_lo[at] = rec[5 * cap + from];
+    }
+}
+
+// the layout the next step WRITES gets the same segments (die_pic_bin leaves the two layouts in the same state)
+__global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_words(RfArgs a) {
+    const int t = blockIdx.x * RF_BLOCK + threadIdx.x;
+    if (t >= a.NTX * a.NTY) return;
+    const uint32_t c = a.dst.n[t];
+    a.src.off[t] = a.dst.off[t]; a.src.n[t] = c; a.src.s[t] = c; a.src.inc[t] = 0;
+}
+
+static int rf_fill(RfArgs& a, const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                   int64_t* summary, const char* who) {
+    DIE_REQUIRE(m && p && summary && (from == 0 || from == 1) && n_sides >= 0 && n_sides <= RF_SIDES && (sides || n_sides == 0), "%s: bad argument", who);
+    DIE_REQUIRE(m->gW > 0 && m->own_x1 > 0, "%s: the planes must be a tile of a decomposed world with its owned cells set (die_medium.gW, own_*)", who);
+    const int xs = p->tile_xs, ys = p->tile_ys, TX = 1 << xs, TY = 1 << ys;
+    DIE_REQUIRE(xs >= 2 && xs <= 8 && ys >= 2 && ys <= 8 && m->W % TX == 0 && m->H % TY == 0 && m->W / TX >= 3 && m->H / TY >= 3,
+                "%s: the planes do not split into at least 3x3 whole tiles", who);
+    DIE_REQUIRE(m->own_x0 % TX == 0 && m->own_x1 % TX == 0 && m->own_y0 % TY == 0 && m->own_y1 % TY == 0,
+                "%s: the owned cells [%d, %d) x [%d, %d) are not whole %dx%d tiles", who, m->own_x0, m->own_x1, m->own_y0, m->own_y1, TX, TY);
+    a.g = die_geo_of(m);
+    a.xs = xs; a.ys = ys; a.NTX = m->W >> xs; a.NTY = m->H >> ys;
+    a.ix0 = m->own_x0 >> xs; a.ix1 = m->own_x1 >> xs; a.iy0 = m->own_y0 >> ys; a.iy1 = m->own_y1 >> ys;
+    a.n_sides = n_sides;
+    a.src = p->layout[from]; a.dst = p->layout[1 - from];
+    for (int l = 0; l < 2; ++l) {
+        const die_pic_layout& L = p->layout[l];
+        DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
+    }
+    DIE_REQUIRE(a.src.x != a.dst.x && a.src.off != a.dst.off, "%s: the two layouts must be different arrays", who);
+    a.first[0] = 0;
+    for (int k = 0; k < n_sides; ++k) {
+        const die_pic_side& S = sides[k];
+        DIE_REQUIRE(S.ntx > 0 && S.nty > 0 && S.cap > 0 && S.cap < ((int64_t)1 << 31) && S.send_counts && S.send_rec && S.recv_counts && S.recv_rec,
+                    "%s: side %d: bad shape or null pointer", who, k);
+        DIE_REQUIRE(S.tx0 >= a.ix0 && S.tx0 + S.ntx <= a.ix1 && S.ty0 >= a.iy0 && S.ty0 + S.nty <= a.iy1, "%s: side %d: the band must lie inside the interior tiles", who, k);
+        DIE_REQUIRE(S.hx0 >= 0 && S.hx0 + S.ntx <= a.NTX && S.hy0 >= 0 && S.hy0 + S.nty <= a.NTY &&
+                    (S.hx0 + S.ntx <= a.ix0 || S.hx0 >= a.ix1 || S.hy0 + S.nty <= a.iy0 || S.hy0 >= a.iy1), "%s: side %d: the halo block must lie outside the interior tiles", who, k);
+        RfSide& R = a.side[k];
+        R.tx0 = S.tx0; R.ty0 = S.ty0; R.ntx = S.ntx; R.nty = S.nty; R.hx0 = S.hx0; R.hy0 = S.hy0; R.cap = (uint32_t)S.cap;
+        R.send_counts = S.send_counts; R.send_rec = S.send_rec; R.recv_counts = S.recv_counts; R.recv_rec = S.recv_rec;
+        a.first[k + 1] = a.first[k] + S.ntx * S.nty;
+    }
+    for (int k = n_sides; k < RF_SIDES; ++k) { a.side[k] = RfSide{}; a.first[k + 1] = a.first[n_sides]; }
+    a.summary = (long long*)summary;
+    a.capacity = 0;
+    return DIE_OK;
+}
+
+extern "C" int die_pic_ghost_pack(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                                  int64_t* summary, void* stream) {
+    RfArgs a;
+    const int rc = rf_fill(a, m, p, from, n_sides, sides, summary, "die_pic_ghost_pack");
+    if (rc != DIE_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(summary, 0, (size_t)DIE_PIC_GHOST_SUMMARY_WORDS * 8, s);
+    if (e != hipSuccess) { die_set_error("die_pic_ghost_pack: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
+    if (a.first[n_sides] > 0) k_pic_ghost_pack<<<a.first[n_sides], RF_BLOCK, 0, s>>>(a);
+    DIE_CHECK_LAUNCH("die_pic_ghost_pack");
+    return DIE_OK;
+}
+
+extern "C" int die_pic_ghost_merge(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                                   int64_t capacity, int64_t* summary, void* stream) {
+    RfArgs a;
+    const int rc = rf_fill(a, m, p, from, n_sides, sides, summary, "die_pic_ghost_merge");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(capacity > 0 && capacity < ((int64_t)1 << 31), "die_pic_ghost_merge: capacity %lld", (long long)capacity);
+    a.capacity = (uint32_t)capacity;
+    hipStream_t s = (hipStream_t)stream;
+    k_pic_ghost_scan<<<1, 1024, 0, s>>>(a);
+    k_pic_ghost_merge<<<dim3(a.NTY, a.NTX), RF_BLOCK, 0, s>>>(a);
+    k_pic_ghost_words<<<(a.NTX * a.NTY + RF_BLOCK - 1) / RF_BLOCK, RF_BLOCK, 0, s>>>(a);
+    DIE_CHECK_LAUNCH("die_pic_ghost_merge");
+    return DIE_OK;
+}

@@ -349,12 +349,17 @@ class DistEnv:
                                  f'{(world[0] // grid[0], world[1] // grid[1])}): lower migrate_every')
             # tile-binned step on the padded tile (die_amd/pic.py; the N = 1 step on a padded tile): the planes must split
             # into whole tiles — a deeper halo is always valid, so it is rounded up to the next fit of the largest shape
+            # — preferably to WHOLE TILES of halo (first pass): the refresh then goes by tiles (_refresh_ghosts_tiles)
             self._pic_tile = None
             if pic:
                 from .pic import TILE_SHAPES
-                for xs, ys in TILE_SHAPES:
+                for aligned, (xs, ys) in [(True, t) for t in TILE_SHAPES] + [(False, t) for t in TILE_SHAPES]:
                     TX, TY = 1 << xs, 1 << ys
                     fx, fy = hx, hy
+                    if aligned:
+                        fx, fy = -(-hx // TX) * TX, -(-hy // TY) * TY
+                        if (world[0] // grid[0]) % TX or (world[1] // grid[1]) % TY:
+                            continue
                     while fx and (world[0] // grid[0] + 2 * fx) % TX:
                         fx += 1
                     while fy and ((world[1] // grid[1] + 2 * fy) % TY or (world[1] // grid[1] + 2 * fy) % 4):
@@ -746,12 +751,17 @@ class DistEnv:
         lx, ly = self._cells()
         return (lx < self.geo.Wi) & (ly < self.geo.Hi)
 
-    def _tick(self, name=None):
-        """DIE_DIST_PROFILE=1: synchronising phase timer for _refresh_ghosts (scratch/ghost_phases.py reads self._prof)."""
+    def _tick(self, name=None, stagger=False):
+        """DIE_DIST_PROFILE=1: synchronising phase timer for _refresh_ghosts (scratch/ghost_phases.py reads self._prof).
+        `stagger` (DIE_DIST_PROFILE_STAGGER=1, ranks sharing one GPU): the ranks take the next phases one after the other, so
+        that a phase's time is its own and not its share of a GPU that the other ranks use at the same moment."""
         if not self._profile:
             return
         import time
         torch.cuda.synchronize(self.device)
+        if stagger and os.environ.get('DIE_DIST_PROFILE_STAGGER', '0') == '1':
+            dist.barrier(self.comm.group)
+            time.sleep(0.004 * self.comm.rank)
         now = time.perf_counter()
         if name is not None:
             self._prof[name] = self._prof.get(name, 0.0) + now - self._t_last
@@ -764,15 +774,126 @@ class DistEnv:
             self._owned = self.agents.N
             self._ghosts_fresh = True
             return
-        self._pic_void()                    # arrays are edited in place below: an un-read lazy action first, then no tile order
         # a consumed action, or one whose forward() has not run yet, holds nothing worth sending
         self._send_action = not after_step and not (isinstance(action, PendingAction) and action.pending)
         if self._send_action and action.data.shape[1] < self.capacity:
             raise ValueError(f'the action arrays hold {action.data.shape[1]} slots, the local agent arrays {self.capacity}: arriving '
                              f'ghosts bring their action with them (build the action for `env.capacity` slots)')
+        if self._tile_refresh_applies():
+            return self._refresh_ghosts_tiles(action)
+        self._pic_void()                    # arrays are edited in place below: an un-read lazy action first, then no tile order
         if self.device.type == 'cuda' and os.environ.get('DIE_GHOST_REFRESH', 'native') != 'torch':
             return self._refresh_ghosts_native(action)
         return self._refresh_ghosts_torch(action)
+
+    # -- refresh by tiles (csrc/die_pic_refresh.hip): the agents are in tile order and the halo is whole tiles deep, so "owned"
+    #    and "in the band of side d" are properties of a TILE — nothing classifies agents, nothing re-bins afterwards ----------
+    def _tile_refresh_applies(self) -> bool:
+        pic = self._pic
+        if pic is None or pic.held is None or pic.agent is None or self.device.type != 'cuda' or not self.ghosts:
+            return False
+        if os.environ.get('DIE_GHOST_REFRESH', 'native') in ('torch', 'agents') or self._send_action:
+            return False
+        g = self.geo
+        TX, TY = 1 << pic.xs, 1 << pic.ys
+        if g.hx % TX or g.hy % TY or g.Wi % TX or g.Hi % TY or (g.hx and g.Wi < 2 * g.hx) or (g.hy and g.Hi < 2 * g.hy):
+            return False
+        return pic.is_current(self, pic.agent)
+
+    def _build_tile_plan(self):
+        from types import SimpleNamespace
+        lib, g, dev, pic = self._lib, self.geo, self.device, self._pic
+        TX, TY = 1 << pic.xs, 1 << pic.ys
+        nd = len(g.DIRS)
+        P = SimpleNamespace(nd=nd, rects={})
+        dens = self.world_agents / float(g.gW * g.gH)
+        esz = self.medium.chem.element_size()
+        P.caps, P.off, P.cnt, geo, off = [], [], [], [], 0       # per side: (header, records, chem block, food block, end), counts
+        for dx, dy in g.DIRS:                         # identical on every rank: depends on the side's shape only
+            (rs, cs), (hr, hc) = g._band(dx, dy), g._halo(dx, dy)
+            cells = (rs.stop - rs.start) * (cs.stop - cs.start)
+            cap = int(min(self.capacity, np.ceil(cells * dens * self._ghost_headroom) + 1024))
+            ntx, nty = (rs.stop - rs.start) // TX, (cs.stop - cs.start) // TY
+            blk = (cells * esz + 7) & ~7
+            hdr, cnt = off, off + 16
+            rec = (cnt + ntx * nty * 4 + 7) & ~7
+            chem = (rec + 6 * cap * 4 + 7) & ~7
+            food = chem + blk
+            off = food + blk
+            P.caps.append(cap); P.off.append((hdr, rec, chem, food, off)); P.cnt.append(cnt)
+            geo.append((rs.start // TX, cs.start // TY, ntx, nty, hr.start // TX, hc.start // TY))
+        P.sbuf = torch.zeros(max(off, 8), dtype=torch.uint8, device=dev)
+        P.rbuf = torch.zeros(max(off, 8), dtype=torch.uint8, device=dev)
+        sb, rb = P.sbuf.data_ptr(), P.rbuf.data_ptr()
+        P.sides = (lib.PicSide * max(nd, 1))(*[lib.PicSide(*geo[k], P.caps[k], sb + P.cnt[k], sb + P.off[k][1], rb + P.cnt[k], rb + P.off[k][1])
+                                               for k in range(nd)])
+        P.recv_order = list(reversed(range(nd)))       # (see _build_ghost_plan / plan8)
+        P.smsg = [(g.neighbour(*g.DIRS[k]), P.sbuf[P.off[k][0]:P.off[k][4]]) for k in range(nd)]
+        P.rmsg = [(g.neighbour(*g.DIRS[k]), P.rbuf[P.off[k][0]:P.off[k][4]]) for k in P.recv_order]
+        P.summary = torch.zeros(lib.PIC_GHOST_SUMMARY_WORDS, dtype=torch.int64, device=dev)
+        P.ops = None
+        if nd and not self.comm.stage_cpu:
+            P.ops = ([dist.P2POp(dist.isend, t, p_, self.comm.group) for p_, t in P.smsg] +
+                     [dist.P2POp(dist.irecv, t, p_, self.comm.group) for p_, t in P.rmsg])
+        return P
+
+    def _refresh_ghosts_tiles(self, action):
+        from .device_array import _ptr, stream_ptr
+        A, g, comm, lib, dev, pic = self.agents, self.geo, self.comm, self._lib, self.device, self._pic
+        n = A.N
+        self._tick(stagger=True)
+        pic.flush_lazy()                                   # (an un-read lazy action refers to the arrays that are replaced below)
+        P = self.__dict__.get('_tplan')
+        if P is None:
+            P = self._tplan = self._build_tile_plan()
+        nd, sp = P.nd, stream_ptr(dev)
+        m = self.medium.c_struct(need_owner=False)
+        pic._n_agents = int(n)
+        out = pic._out_tensors(self)
+        p = pic._struct(pic.held, out)
+        # everything below is enqueued without looking at a count; the host reads the summary once, at the end
+        lib.check(lib.lib.die_pic_ghost_pack(C.byref(m), C.byref(p), pic.cur, nd, P.sides, _ptr(P.summary), sp), 'die_pic_ghost_pack')
+        self._tick('band tiles packed')
+        send_r, recv_r, _ = self._ghost_field_rects(P)
+        sb, rb = C.c_void_p(P.sbuf.data_ptr()), C.c_void_p(P.rbuf.data_ptr())
+        for arr, cnt in send_r:
+            lib.check(lib.lib.die_rects_pack(arr, cnt, sb, sp), 'die_rects_pack')
+        self._tick('field pack')
+        if P.ops is None:
+            comm.exchange(P.smsg, P.rmsg)
+        else:
+            for req in dist.batch_isend_irecv(P.ops):
+                req.wait()
+        self._tick('exchange (records + fields, one message per side)')
+        self._tick(stagger=True)
+        for arr, cnt in recv_r:
+            lib.check(lib.lib.die_rects_unpack(arr, cnt, rb, sp), 'die_rects_unpack')
+        self._tick('field unpack')
+        lib.check(lib.lib.die_pic_ghost_merge(C.byref(m), C.byref(p), pic.cur, nd, P.sides, self.capacity, _ptr(P.summary), sp),
+                  'die_pic_ghost_merge')
+        self._tick('new layout (scan, merge, words)')
+        t = P.summary.cpu().tolist()                                   # the one host read
+        self._tick('counts to host')
+        n_new, kept, sent, arrived, flags = t[0], t[1], t[2:2 + nd], t[10:10 + nd], int(t[18])
+        for k in range(nd):
+            if sent[k] > P.caps[k] or arrived[k] > P.caps[k]:
+                raise RuntimeError(f'ghost refresh: {max(sent[k], arrived[k])} agents in the band of side {g.DIRS[k]}, the messages hold '
+                                   f'{P.caps[k]}: build DistEnv with a larger ghost_headroom (agents cluster at this border)')
+        if n_new > self.capacity:
+            raise RuntimeError(f'rank {comm.rank}: {n_new} agents (ghosts included) exceed the local capacity {self.capacity}')
+        if flags:
+            raise RuntimeError('ghost refresh by tiles: ' + '; '.join(v for b, v in lib.PIC_GHOST_FLAGS.items() if flags & b))
+        if n_new != kept + sum(arrived):
+            raise RuntimeError(f'ghost refresh: device count {n_new} != {kept} owned + {sum(arrived)} arrived')
+        pic.cur = 1 - pic.cur
+        pic._adopt(self, pic.agent, out)
+        self._owned = kept
+        if nd:
+            self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))
+        A.N = n_new
+        action.N = n_new
+        self.tile_refreshes = getattr(self, 'tile_refreshes', 0) + 1
+        self._ghosts_fresh = True
 
     # -- native refresh: one classification pass, records packed straight into fixed-size messages that also carry the
     #    field bands, ONE grouped send/recv per refresh, one host read (counts) -------------------------------------
@@ -840,7 +961,7 @@ class DistEnv:
         from .device_array import _ptr, stream_ptr
         A, g, comm, lib, dev = self.agents, self.geo, self.comm, self._lib, self.device
         n = A.N
-        self._tick()
+        self._tick(stagger=True)
         tensors = self._per_agent_tensors(action, self._send_action)
         arrs, ptrs, esz = self._record_arrays(tensors)
         F = len(arrs)
@@ -868,6 +989,7 @@ class DistEnv:
                 for req in dist.batch_isend_irecv(P.ops):
                     req.wait()
             self._tick('exchange (records + fields, one message per side)')
+            self._tick(stagger=True)
             for arr, cnt in recv_r:
                 lib.check(lib.lib.die_rects_unpack(arr, cnt, rb, sp), 'die_rects_unpack')
         lib.check(lib.lib.die_ghost_apply(ptrs, esz, F, nd, _ptr(P.totals), P.c_caps, P.c_hdr, P.c_rec, _ptr(P.rbuf),

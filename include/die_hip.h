@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 17
+#define DIE_ABI_VERSION 18
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -440,6 +440,42 @@ int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from
  * WROTE): (dx, dy) = scale * polar2xy(1, heading'), deposit = p->dep; same bits as the action the step would have stored, in
  * the order of layout[lay] (core/agent/gradient.py:110-124: the action PhysarumAgent.forward returns). */
 int die_pic_action_physarum(const die_pic* p, int32_t lay, const die_gradient_agent* g, const die_action* act, void* stream);
+
+/* ---- Ghost refresh by tiles (die_amd/dist.py DistEnv._refresh_ghosts_tiles; no reference counterpart) ----
+ * For a rank of a ghost-agent decomposition whose agents are held in a tile-binned layout (layout[from], as a step or
+ * die_pic_bin left it) over planes whose halo is whole tiles deep (die_medium.own_* on tile borders).  An agent is owned iff it
+ * stands on an interior tile, so a refresh never looks at every agent:
+ *   die_pic_ghost_pack   for every side, tile by tile of its band (tile rectangle [tx0, tx0+ntx) x [ty0, ty0+nty) of the
+ *                        interior, row-major): the agents standing on the tile — its stayers and the neighbouring tiles'
+ *                        leavers that landed on it — go to send_rec (six streams of `cap` words each: x | y | agent_food |
+ *                        slot | heading_hi | heading_lo, the tiles' agents one tile after the other), their number to
+ *                        send_counts[tile];
+ *   (the caller exchanges the messages: what a neighbour packed for its side -d arrives as recv_* of side d)
+ *   die_pic_ghost_merge  layout[1 - from] := tile by tile, the agents standing on an interior tile / the agents that arrived
+ *                        for a halo tile (rectangle [hx0, hx0+ntx) x [hy0, hy0+nty), same shape as the band); every agent a
+ *                        stayer, both layouts' per-tile words equal — the state die_pic_bin leaves.  Halo tiles no side
+ *                        fills become empty.  At most `capacity` array entries are written.
+ * summary (device, DIE_PIC_GHOST_SUMMARY_WORDS int64; cleared by die_pic_ghost_pack): [0] agents after the refresh, [1] of
+ * them owned, [2 + k] agents sent to side k, [10 + k] agents arrived from side k, [18] flags (DIE_PIC_GHOST_*): the caller
+ * reads it once, after die_pic_ghost_merge, and must not use the new layout if a flag is set. */
+#define DIE_PIC_GHOST_SUMMARY_WORDS 19
+#define DIE_PIC_GHOST_BAD_COUNT 1      /* a tile holds another number of agents than its per-tile words say */
+#define DIE_PIC_GHOST_SEND_CAP 2       /* a band holds more agents than `cap` */
+#define DIE_PIC_GHOST_BAD_RECV 4       /* a received count is impossible */
+#define DIE_PIC_GHOST_CAPACITY 8       /* the agents do not fit `capacity` */
+typedef struct die_pic_side {
+    int32_t tx0, ty0, ntx, nty;        /* band (tiles of the planes) */
+    int32_t hx0, hy0;                  /* halo block filled by the message arriving from this side's neighbour */
+    int64_t cap;                       /* agents a message holds */
+    uint32_t* send_counts;             /* ntx * nty */
+    uint32_t* send_rec;                /* 6 * cap */
+    const uint32_t* recv_counts;
+    const uint32_t* recv_rec;
+} die_pic_side;
+int die_pic_ghost_pack(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                       int64_t* summary, void* stream);
+int die_pic_ghost_merge(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                        int64_t capacity, int64_t* summary, void* stream);
 /* Rebuild the 'agents' channel from the agent arrays: atomicMax of (m->epoch, slot) claims (deposit bits 0) for every
  * alive agent.  The caller advances m->epoch (or zeroes the plane) first. */
 int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream);

@@ -79,7 +79,7 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
             env.check()
         if rank == 0:
             np.savez(out_path, medium=world[0], agents=world[1], rewards=np.array(rewards), pic_steps=getattr(env, 'pic_steps', 0),
-                     plane=np.array([env.geo.W, env.geo.H]))
+                     plane=np.array([env.geo.W, env.geo.H]), tile_refreshes=getattr(env, 'tile_refreshes', 0))
     finally:
         dist.destroy_process_group()
 
@@ -164,13 +164,13 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
 
 
 @pytest.mark.parametrize('grid,refresh_every,backend,wave,plane', [
-    ((2, 2), 2, 'gloo', False, (256, 192)), ((1, 2), 3, 'gloo', True, (384, 256)), ((2, 1), 2, 'gloo-f16', False, (256, 256)),
+    ((2, 2), 2, 'gloo', False, (320, 256)), ((1, 2), 3, 'gloo', True, (384, 256)), ((2, 1), 2, 'gloo-f16', False, (320, 256)),
     ((1, 1), 4, 'nccl', False, (384, 256))])
 def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_every, backend, wave, plane):
     """A rank of the ghost-agent decomposition takes the step the single GPU takes: the tile-binned two-launch step on its
     padded tile (die_pic.hip TILED: agents binned by the plane cell that holds their world cell, ownership-masked reward,
-    probes clamped at the WORLD's edge; the halo is rounded up until the planes split into whole tiles), re-binned after
-    every refresh.  Every slot alive (the binned step's precondition).  Gathered world and rewards equal the single-device
+    probes clamped at the WORLD's edge; the halo is rounded up until the planes split into whole tiles); the refresh goes
+    by tiles and leaves the tile order intact.  Every slot alive (the binned step's precondition).  Gathered world and rewards equal the single-device
     run bit for bit; the worker reports how many of its steps took the binned path: all of them."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
@@ -185,6 +185,8 @@ def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_ever
     got = np.load(out)
     assert int(got['pic_steps']) == steps, 'the ranks did not take the tile-binned step'
     assert tuple(got['plane']) == plane                     # (halo rounded up so that the planes are whole tiles)
+    # every refresh after a step went by tiles (csrc/die_pic_refresh.hip: no per-agent classification, no re-bin afterwards)
+    assert int(got['tile_refreshes']) == (steps // refresh_every if size > 1 else 0)
     m, a, r = _single_device_run(W, H, N, N, steps, wave, f16)
     assert np.array_equal(got['agents'], a)
     for c in range(3):
