@@ -85,6 +85,16 @@ def test_argument_validation_without_gpu(built_lib):
     assert _lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(g), C.byref(u), None) == -1
     with pytest.raises(_lib.DieError):
         _lib.check(-1, 'x')
+    # the ghost refresh by tiles: planes that are no tile of a decomposed world / owned cells off the tile borders / a band
+    # outside the interior are refused before any launch
+    p = _lib.Pic(6, 6, 1, (_lib.PicLayout * 2)(), None, None, None, None, 0, 0, None, None, None, None)
+    summary = (C.c_int64 * _lib.PIC_GHOST_SUMMARY_WORDS)()
+    plain = _lib.Medium(256, 256, 0, 1, None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, None)
+    assert _lib.lib.die_pic_ghost_pack(C.byref(plain), C.byref(p), 0, 0, None, summary, None) == -1
+    assert b'decomposed' in _lib.lib.die_last_error()
+    off_grid = _lib.Medium(256, 256, 0, 1, None, None, None, None, 512, 512, 0, 0, 48, 64, 208, 192, None)
+    assert _lib.lib.die_pic_ghost_merge(C.byref(off_grid), C.byref(p), 0, 0, None, 16, summary, None) == -1
+    assert b'whole 64x64 tiles' in _lib.lib.die_last_error()
 
 
 def test_q32_roundtrip_and_cell_formula():
