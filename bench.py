@@ -485,6 +485,9 @@ def main():
         line['config'].update(alive_agents=Kw, agent_slots=Kw, local_agents_rank0=K)
         if getattr(denv, 'ghost_fill', None) is not None:
             line['config']['ghost_message_fill_max_rank0'] = round(denv.ghost_fill, 3)
+        # which step and which refresh the ranks took (rank 0's counts over the whole run: pre-warm, warm-up, timed steps)
+        line['config'].update(steps_total_rank0=int(denv._steps), tile_binned_steps_rank0=int(getattr(denv, 'pic_steps', 0)),
+                              refreshes_by_tiles_rank0=int(getattr(denv, 'tile_refreshes', 0)))
         line['roofline'] = {'bound': 'hbm', 'kernel': 'whole step (all ranks)', 'achieved': round(Bw / (dt / args.steps) / 1e9, 1),
                             'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': round(Bw / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
                             'traffic': None, 'algorithmic_bytes_per_launch': Bw}
