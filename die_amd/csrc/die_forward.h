@@ -129,8 +129,10 @@ struct FwdGlobalMem {
     __device__ __forceinline__ explicit FwdGlobalMem(const FwdArgs& a) : chem((const T*)a.chem), food((const T*)a.food), mask(a.mask), g(a.g) {}
     // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
     __device__ __forceinline__ float seen(const T* p, const int64_t i) const { return (EXT && mask && !mask[i]) ? 0.f : die_ld(p, i); }
-    __device__ __forceinline__ float chem_at(int gx, int gy) const { return seen(chem, die_local(g, gx, gy)); }
-    __device__ __forceinline__ float food_at(int gx, int gy) const { return seen(food, die_local(g, gx, gy)); }
+    struct Home {};                                     // (see FwdTileMem)
+    __device__ __forceinline__ Home home(int, int) const { return Home{}; }
+    __device__ __forceinline__ float chem_at(int gx, int gy, Home) const { return seen(chem, die_local(g, gx, gy)); }
+    __device__ __forceinline__ float food_at(int gx, int gy, Home) const { return seen(food, die_local(g, gx, gy)); }
 };
 // … or a tile staged in LDS (die_pic.hip): chem with a margin of the probe reach around the tile, food of the tile itself
 template <typename T, bool TILED = false>
@@ -140,10 +142,23 @@ struct FwdTileMem {
     const T* food;          // plane element (lx, ly) at (lx − fx0)·fpitch + (ly − fy0)
     int cx0, cy0, pitch, fx0, fy0, fpitch;
     die_geo g;              // TILED (the planes are a tile of a decomposed world): world cell → plane element first
-    __device__ __forceinline__ int lx(int gx) const { return TILED ? die_plane_coord(gx, g.ox, g.W, g.gW) : gx; }
-    __device__ __forceinline__ int ly(int gy) const { return TILED ? die_plane_coord(gy, g.oy, g.H, g.gH) : gy; }
-    __device__ __forceinline__ float chem_at(int gx, int gy) const { return die_ld(chem, (int64_t)((lx(gx) - cx0) * pitch + (ly(gy) - cy0))); }
-    __device__ __forceinline__ float food_at(int gx, int gy) const { return die_ld(food, (int64_t)((lx(gx) - fx0) * fpitch + (ly(gy) - fy0))); }
+    // TILED: where the planes hold the cells around an agent that stands INSIDE them, from ONE mapping of the agent's own cell
+    // (cx, cy): probes clamp at the world's edge, so a tap never lies across the world's seam from the agent, and
+    // die_plane_coord(gx) == clamp(die_plane_coord(cx) + (gx − cx), 0, W − 1) for every tap within the staged margin — provided
+    // the world is larger than the planes by more than twice that margin, or the planes span it (checked on the host,
+    // die_pic_forward_env_step).  Ten mappings per agent were 8 % of the agent kernel's instructions.
+    struct Home { int dx, dy; };
+    __device__ __forceinline__ Home home(int cx, int cy) const {
+        Home h = {0, 0};
+        if (TILED) { h.dx = die_plane_coord(cx, g.ox, g.W, g.gW) - cx; h.dy = die_plane_coord(cy, g.oy, g.H, g.gH) - cy; }
+        return h;
+    }
+    __device__ __forceinline__ int lx(int gx, Home h) const { return TILED ? min(max(gx + h.dx, 0), g.W - 1) : gx; }
+    __device__ __forceinline__ int ly(int gy, Home h) const { return TILED ? min(max(gy + h.dy, 0), g.H - 1) : gy; }
+    __device__ __forceinline__ float chem_at(int gx, int gy, Home h) const { return die_ld(chem, (int64_t)((lx(gx, h) - cx0) * pitch + (ly(gy, h) - cy0))); }
+    __device__ __forceinline__ float food_at(int gx, int gy, Home h) const { return die_ld(food, (int64_t)((lx(gx, h) - fx0) * fpitch + (ly(gy, h) - fy0))); }
+    // … and by plane element, for a caller that has mapped the cell already
+    __device__ __forceinline__ float food_plane(int px_, int py_) const { return die_ld(food, (int64_t)((px_ - fx0) * fpitch + (py_ - fy0))); }
 };
 
 template <typename T, int KIND, bool EXT, class MEM>
@@ -160,11 +175,12 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     // np.gradient at the probe cell: central inside, one-sided at the four edges (gradient.py:57)
     const int xm = px > 0 ? px - 1 : 0, xp = px < W - 1 ? px + 1 : W - 1;
     const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;
-    const float cxm = mem.chem_at(xm, py), cxp = mem.chem_at(xp, py);
-    const float cym = mem.chem_at(px, ym), cyp = mem.chem_at(px, yp);
-    // food under the agent (gradient.py:114-116)
     const int cx = die_cell((int64_t)X, W), cy = die_cell((int64_t)Y, H);
-    const float f_own = mem.food_at(cx, cy);
+    const typename MEM::Home hm = mem.home(cx, cy);
+    const float cxm = mem.chem_at(xm, py, hm), cxp = mem.chem_at(xp, py, hm);
+    const float cym = mem.chem_at(px, ym, hm), cyp = mem.chem_at(px, yp, hm);
+    // food under the agent (gradient.py:114-116)
+    const float f_own = mem.food_at(cx, cy, hm);
     const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
     const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
     const float norm = sqrtf(gx * gx + gy * gy);

@@ -418,12 +418,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 const int ntx_ = cx >> p.xs, nty_ = cy >> p.ys;
                 stay = ntx_ == tx && nty_ == ty;
                 // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption
-                const float fnew = (STAGE && stay) ? tm.food_at(gcx, gcy) : die_ld(food, (int64_t)cx * p.g.H + cy);
+                const float fnew = (STAGE && stay) ? tm.food_plane(cx, cy) : die_ld(food, (int64_t)cx * p.g.H + cy);
                 const float consumed = p.rate_feed * fnew;
                 const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * sqrtf(o.dx * o.dx + o.dy * o.dy) : 0.f;
                 const float gained = consumed - cost;
                 af += gained;
-                if (!TILED || die_owned(p.g, gcx, gcy)) { gsum += die_fix(gained); ++nowned; }       // (a ghost is its owner's to count)
+                // (a ghost is its owner's to count; die_owned on the plane element: a cell beyond the planes maps to an edge element, never owned)
+                if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_fix(gained); ++nowned; }
                 hd = o.heading;
                 dep = o.dep;
                 int ddx = 0, ddy = 0;
@@ -1236,6 +1237,11 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
     if (tiled && !(two && stage)) {
         die_set_error("die_pic_forward_env_step: a decomposed world's tile runs the two-launch form with staged tiles only (probe reach %d, radius %d)", P, R);
+        return DIE_ERR_UNSUPPORTED;
+    }
+    if (tiled && ((m->gW != m->W && m->gW - m->W < 2 * k.margin + 2) || (m->gH != m->H && m->gH - m->H < 2 * k.margin + 2))) {
+        die_set_error("die_pic_forward_env_step: the planes (%d x %d) nearly span the world (%d x %d): the taps around an agent are mapped "
+                      "from its own cell (FwdTileMem::home), which needs %d cells of world beyond the planes", m->W, m->H, m->gW, m->gH, 2 * k.margin + 2);
         return DIE_ERR_UNSUPPORTED;
     }
     k.rim = (uint4*)p->rim; k.rim_code = p->rim_code; k.rim_cnt = p->rim_cnt; k.rim_cap = (int)die_pic_rim_cap(p->tile_xs, p->tile_ys); k.rim_r = R;

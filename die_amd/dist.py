@@ -887,6 +887,8 @@ class DistEnv:
             raise RuntimeError(f'ghost refresh: device count {n_new} != {kept} owned + {sum(arrived)} arrived')
         pic.cur = 1 - pic.cur
         pic._adopt(self, pic.agent, out)
+        if n_new > n:                                      # every slot is alive on this path; readers (gather_world) look at the bytes
+            A.alive[n:n_new] = 1
         self._owned = kept
         if nd:
             self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))

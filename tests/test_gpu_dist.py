@@ -29,6 +29,8 @@ def _state(W, H, N, K, seed):
 def _wave_dynamics(die_amd, W, H, kind=True):
     """'dyn-pred' of examples/simple_agents.py:95-100: food flows in running waves (`kind='perlin'`: in drifting Perlin noise,
     core/data_init.py:55-69)."""
+    if kind == 'limit':                  # (no food flow: agents stop at the world's edge and pile up there — local counts grow)
+        return die_amd.Dynamics(boundary=die_amd.BoundaryCondition.limit)
     if kind == 'perlin':
         seq = die_amd.PerlinNoiseSequence((W, H), dt=0.05, octaves=6, seed=5)
     else:
@@ -74,6 +76,8 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         for _ in range(steps):
             obs, res = env.step(agent.forward(obs))
             rewards.append(env.read_result(res))
+        if ghosts and env._all_alive:       # every local entry is alive, also those a refresh appended beyond the old count
+            assert bool(env.agents.alive[:env.agents.N].all())
         world = env.gather_world()
         if hasattr(env, 'check'):
             env.check()
@@ -165,7 +169,7 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
 
 @pytest.mark.parametrize('grid,refresh_every,backend,wave,plane', [
     ((2, 2), 2, 'gloo', False, (320, 256)), ((1, 2), 3, 'gloo', True, (384, 256)), ((2, 1), 2, 'gloo-f16', False, (320, 256)),
-    ((1, 1), 4, 'nccl', False, (384, 256))])
+    ((1, 1), 4, 'nccl', False, (384, 256)), ((1, 2), 2, 'gloo', 'limit', (384, 256))])
 def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_every, backend, wave, plane):
     """A rank of the ghost-agent decomposition takes the step the single GPU takes: the tile-binned two-launch step on its
     padded tile (die_pic.hip TILED: agents binned by the plane cell that holds their world cell, ownership-masked reward,
