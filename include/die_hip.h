@@ -432,7 +432,9 @@ int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* headin
  * The planes may be a tile of a decomposed world (die_medium.gW > 0; two-launch form only): agents are binned by the plane
  * cell that holds their world cell (nearest edge for agents beyond the planes), the planes are treated as periodic — what
  * that brings in across their outer edge stays in the outermost cells of the halo, which a ghost-agent decomposition
- * discards —, probes clamp at the WORLD's edge, and reward / num_alive count the agents on cells the rank owns (own_*). */
+ * discards —, probes clamp at the WORLD's edge, and reward / num_alive count the agents on cells the rank owns (own_*).  Per axis
+ * the planes must either span the world or leave 2 * (probe margin) + 2 cells of it uncovered (the taps around an agent are
+ * mapped from one mapping of its own cell; else DIE_ERR_UNSUPPORTED). */
 int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g, const die_action* act,
                              const die_dynamics* d, die_step_result* result, void* stream);
 /* `act` of die_pic_forward_env_step may be NULL: the action then stays in registers.  For a normalised PhysarumAgent it can
