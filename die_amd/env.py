@@ -78,7 +78,8 @@ class Dynamics:
 
 
 class Env(_EnvBase):
-    PIC_MIN_CELLS = 1 << 23          # worlds at least this large take the tile-binned step when it applies
+    PIC_MIN_CELLS = 1 << 23          # worlds at least this large take the tile-binned step when it applies …
+    PIC_MIN_CELLS_64 = 1 << 22       # … with 64×64 tiles already from here (scratch/pic_threshold.py)
     SORT_MIN_CELLS = 1 << 19         # smaller worlds live in the L2: re-sorting the agent arrays only costs launches there
 
     @classmethod
@@ -356,10 +357,17 @@ class Env(_EnvBase):
         reach = abs(ag._scale) * (max(W, H) - 1)                 # cells per step, at most
         if self._pic_tile is None:
             from .pic import pick_tile
-            # small worlds are bound by launches and host calls, and the binned step has one launch more than the classic
-            # one (measured: 256² 47.6 vs 29 µs per step, 1024² 69.6 vs 41, 2048² 62.2 vs 57.4, 4096² 181 vs 193): binned
-            # from 2^23 cells upwards
-            self._pic_tile = (pick_tile(W, H, reach) if W * H >= self.PIC_MIN_CELLS else None) or False
+            # small worlds are bound by launches and their gaps, not by what the binned step saves.  Measured (r3, µs per step,
+            # classic / binned with 64×64 / 32×64 tiles, scratch/pic_threshold.py): 1024² 23.8 / 27.7 / 39.5, 1536² 41.2 / 39.5 /
+            # 53.4, 2048² 58.5 / 53.3 / 70.7 (bench.py, with its per-step events: 58.4 / 57.1), 3072×2048 78.0 / 64.5 / 80.5,
+            # 3072² 107 / 90 / 112, 4096×2048 95.6 / 77.6 / 95.2: 64×64 tiles from 2^22 cells upwards, the smaller shapes (worlds
+            # that 64 does not divide) from 2^23
+            if W * H >= self.PIC_MIN_CELLS:
+                self._pic_tile = pick_tile(W, H, reach) or False
+            elif W * H >= self.PIC_MIN_CELLS_64:
+                self._pic_tile = pick_tile(W, H, reach, shapes=((6, 6),)) or False
+            else:
+                self._pic_tile = False
         return bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1
 
     def _pic_step(self, action, result) -> bool:

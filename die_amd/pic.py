@@ -15,9 +15,9 @@ from .device_array import _ptr, stream_ptr
 TILE_SHAPES = ((6, 6), (5, 6), (4, 5))        # log2 (rows, columns), in order of preference; (5, 7) by request only
 
 
-def pick_tile(W: int, H: int, reach_cells: float) -> Optional[Tuple[int, int]]:
-    """Largest compiled tile shape that cuts the world into at least 3×3 whole tiles and is wider than a step."""
-    for xs, ys in TILE_SHAPES:
+def pick_tile(W: int, H: int, reach_cells: float, shapes=TILE_SHAPES) -> Optional[Tuple[int, int]]:
+    """Largest compiled tile shape (of `shapes`) that cuts the world into at least 3×3 whole tiles and is wider than a step."""
+    for xs, ys in shapes:
         TX, TY = 1 << xs, 1 << ys
         if W % TX == 0 and H % TY == 0 and W // TX >= 3 and H // TY >= 3 and reach_cells <= min(TX, TY) - 1:
             return xs, ys
