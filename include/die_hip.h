@@ -411,7 +411,8 @@ typedef struct die_pic {
     uint8_t* rim_code;           /* die_pic_tiles() * die_pic_rim_cap() bytes: where each listed agent stands (see die_pic.hip) */
     uint32_t* rim_cnt;           /* die_pic_tiles() words */
     int64_t* status_out;         /* two-launch form, may be NULL: the step copies *error here next to writing `result` — a caller that
-                                    places it behind its die_step_result reads reward, num_alive and the error word in ONE copy */
+                                    places it behind its die_step_result reads reward, num_alive and the error word in ONE copy (both
+                                    may be device-visible pinned host memory: one thread writes the three words with plain stores) */
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */
