@@ -57,7 +57,7 @@ class PicState:
         self.k1_threads = 0          # tuning knob of die_pic (0 = library default)
         self.cur = 0                 # layout index that holds the agents
         self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
-        self._held_layout = self._out_layout = None      # their die_pic_layout struct / the one of the buffers being written
+        self._structs = {}           # die_pic structs by the device addresses of the two array sets (_struct)
         self._two_key = self._two = None
         self.agent = None
         self.steps_since_check = 0   # binned steps whose error word nobody has read yet
@@ -70,14 +70,29 @@ class PicState:
         return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hh), _ptr(hl), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
 
     def _struct(self, cur_tensors, other_tensors, stages: int = 0, status_out=None) -> _lib.Pic:
-        lay = [None, None]
-        # (the layout a step writes is the one the next step reads: its struct is kept with `held` — host time per step
-        # matters to Env(sync=True), where nothing hides it)
-        kept = self._held_layout if cur_tensors is self.held else None
-        lay[self.cur] = kept if kept is not None else self._layout(cur_tensors, self.meta[self.cur])
-        lay[1 - self.cur] = self._out_layout = self._layout(other_tensors, self.meta[1 - self.cur])
-        return _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane), _ptr(self.part),
-                        _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code), _ptr(self.rim_cnt), status_out)
+        """The die_pic of a call: layout[cur] = `cur_tensors`, layout[1 - cur] = `other_tensors`.  The arrays ping-pong between
+        two fixed sets, so the struct of a (set, set) pair is built once and kept — keyed by the device addresses, not by the
+        tensor objects — and only what changes from step to step is written into it: the two slot arrays (never reused:
+        actions may still refer to them), the agent count, stages, status_out.  (Host time per step matters to
+        Env(sync=True), where nothing hides it: 6.3 → 1.9 µs.)"""
+        ct, ot, cur = cur_tensors, other_tensors, self.cur
+        key = (cur, ct[0].data_ptr(), ct[1].data_ptr(), ct[2].data_ptr(), ct[4].data_ptr(), ct[5].data_ptr(),
+               ot[0].data_ptr(), ot[1].data_ptr(), ot[2].data_ptr(), ot[4].data_ptr(), ot[5].data_ptr(),
+               0 if self._dep_plane is None else self._dep_plane.data_ptr())
+        p = self._structs.get(key)
+        if p is None:
+            if len(self._structs) >= 8:
+                self._structs.clear()
+            lay = [None, None]
+            lay[cur] = self._layout(ct, self.meta[cur])
+            lay[1 - cur] = self._layout(ot, self.meta[1 - cur])
+            p = self._structs[key] = _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane),
+                                              _ptr(self.part), _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code),
+                                              _ptr(self.rim_cnt), status_out)
+        L = p.layout
+        L[cur].slot, L[1 - cur].slot = ct[3].data_ptr(), ot[3].data_ptr()
+        p.N, p.k1_threads, p.stages, p.status_out = self._n_agents, self.k1_threads, stages, status_out
+        return p
 
     def two_launch(self, env, agent) -> bool:
         """Does die_pic_forward_env_step take the two-launch form for this agent?  (The library decides by the same rule;
@@ -110,7 +125,6 @@ class PicState:
         agent._hd_hi, agent._hd_lo = new[4], new[5]
         agent._order = A.slot
         self.held, self.agent = tuple(new), agent
-        self._held_layout, self._out_layout = self._out_layout, None
 
     def _out_tensors(self, env):
         slot = torch.empty(self.cap, dtype=torch.int32, device=env.device)
