@@ -757,6 +757,33 @@ def test_sync_steps_read_the_error_word_with_the_result(die):
         env2.step(ag.forward(env2._get_current_obs))        # … and reads the pending word first
 
 
+@pytest.mark.parametrize('binned', [True, False])
+def test_sync_result_in_pinned_host_memory_equals_the_copied_result(die, binned, monkeypatch):
+    """`Env(sync=True)`: the three result words are written by the device into pinned host memory and waited for there
+    (`Env._read_host_result`); `DIE_HOST_RESULT=0` copies them behind a synchronisation as before.  Same floats, same info,
+    step by step, on the tile-binned and on the classic path; `last_result` is a snapshot, not the live buffer."""
+    W, H, N = 192, 192, 5000
+    rs = np.random.RandomState(21)
+    medium, agents = random_state(W, H, N, N if binned else N - 700, rs)
+    runs = []
+    for host in ('1', '0'):
+        monkeypatch.setenv('DIE_HOST_RESULT', host)
+        env = die.Env.from_numpy(medium, agents, sort_every=3, sync=True)
+        env._pic_tile = (6, 6) if binned else None
+        ag = die.PhysarumAgent(max_agents=N, seed=4, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        obs, out, kept = env._get_current_obs, [], None
+        for t in range(9):
+            obs, reward, term, trunc, info = env.step(ag.forward(obs))
+            out.append((reward, info['num_agents'], float(info['reward']), float(info['mean_reward'])))
+            if t == 3:
+                kept = env.last_result
+        assert (env._host_res is not None) == (host == '1')
+        assert (env._pic is not None and env._pic.held is not None) == binned
+        assert float(kept[0]) == out[3][0]                     # the 4th step's result, not the 9th
+        runs.append(out)
+    assert runs[0] == runs[1]
+
+
 def test_tile_binned_step_with_a_gradient_agent(die):
     """GradientAgent without inertia / noise (normalised gradient: bounded step) takes the binned path too
     (k_pic_forward_move<T, GRADIENT>): same bits as the classic step."""
