@@ -368,9 +368,17 @@ class Env(_EnvBase):
             try:
                 if os.environ.get('DIE_HOST_RESULT', '1') != '0':
                     buf = torch.zeros(3, dtype=torch.float64).pin_memory()
-                    hip = C.CDLL('libamdhip64.so')
+                    # (the runtime instance torch and libdie_hip.so already share: asked for by its SONAME first)
+                    hip = None
+                    for name in ('libamdhip64.so.7', 'libamdhip64.so'):
+                        try:
+                            hip = C.CDLL(name)
+                            break
+                        except OSError:
+                            continue
                     dev = C.c_void_p()
-                    if hip.hipHostGetDevicePointer(C.byref(dev), C.c_void_p(buf.data_ptr()), 0) == 0 and dev.value == buf.data_ptr():
+                    if hip is not None and hip.hipHostGetDevicePointer(C.byref(dev), C.c_void_p(buf.data_ptr()), 0) == 0 \
+                            and dev.value == buf.data_ptr():
                         self._host_res, self._host_i64 = buf, buf.numpy().view(np.int64)
             except Exception:
                 self._host_res = self._host_i64 = None
