@@ -98,6 +98,11 @@ template <> struct Vec4<__half> {
 
 // PIC_PRIO_K1 / PIC_PRIO_KB: s_setprio levels, one hex digit per point of the kernel (agent kernel: start, agent streams
 // issued, chunk loop, after the chunk loop; field kernel: start, window loads issued, x pass, unused)
+// PIC_KARG: the agent kernel reads its array pointers from the kernel-argument segment where it uses them (scalar loads)
+// instead of carrying all 26 of them — most of them spilled to vector lanes — through its chunk loop
+#ifndef PIC_KARG
+#define PIC_KARG 1
+#endif
 #ifndef PIC_PRIO_K1
 #define PIC_PRIO_K1 0x3000      // (the waves of a starting workgroup issue their loads ahead of the resident workgroups' chunk loops: 83.5 → 81.4 µs;
 #endif                          //  raising the chunk loop, or the waves that take a second chunk: worse — DESIGN §3.1)
@@ -267,6 +272,20 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
     f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
     f.g = p.g;                            // one copy of the geometry
+#if PIC_KARG
+    // The array pointers are needed at a few places each — the streams once per chunk, the epilogue's once per tile.  Kept in
+    // scalar registers from the kernel's entry they (106 registers + 70 spilled to vector lanes, every use a v_readlane and a
+    // hazard nop: vector-issue slots of a kernel that is half vector issue) cost more than re-reading them from the
+    // kernel-argument segment right where they are used: volatile, so that the compiler neither hoists nor keeps them.
+    // 2 077 → 1 875 instructions, spilled scalars 70 → 35 (decomposed tiles: 2 461 → 2 129, 107 → 43); 80.7 → 79.2 µs (TILED: 88.8 →
+    // 83.5).  The two by-value arguments lie in the segment one after the other, each 8-byte aligned.
+    struct KArgs { FwdArgs f; PicArgs p; };
+    static_assert(alignof(FwdArgs) == 8 && alignof(PicArgs) == 8 && sizeof(FwdArgs) % 8 == 0, "kernel-argument layout of k_pic_forward_move");
+    const volatile KArgs __attribute__((address_space(4)))* ka = (const volatile KArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+#define PIC_KP(field, type) ((type)ka->p.field)
+#else
+#define PIC_KP(field, type) (p.field)
+#endif
     extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
     __shared__ uint32_t s_base[9], s_pre[10];
     __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
@@ -391,12 +410,12 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 if (first && idx < n_own) {
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
                 } else {
-                    X = pic_ld<0>(&p.in.x[j]);                       // all six streams in flight together
-                    Y = pic_ld<0>(&p.in.y[j]);
-                    sid = pic_ld<0>(&p.in.slot[j]);
-                    hh = pic_ld<0>(&p.in.hhi[j]);
-                    hl = pic_ld<0>(&p.in.hlo[j]);
-                    af = pic_ld<0>(&p.in.agent_food[j]);
+                    X = pic_ld<0>(&PIC_KP(in.x, const uint32_t*)[j]);                       // all six streams in flight together
+                    Y = pic_ld<0>(&PIC_KP(in.y, const uint32_t*)[j]);
+                    sid = pic_ld<0>(&PIC_KP(in.slot, const uint32_t*)[j]);
+                    hh = pic_ld<0>(&PIC_KP(in.hhi, const uint32_t*)[j]);
+                    hl = pic_ld<0>(&PIC_KP(in.hlo, const uint32_t*)[j]);
+                    af = pic_ld<0>(&PIC_KP(in.agent_food, const float*)[j]);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
                 const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
@@ -459,21 +478,21 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
                 if (at < (uint32_t)p.rim_cap) {
                     s_rimc[at] = (uint8_t)code;
-                    pic_st4<2>(&p.rim[(size_t)tile * p.rim_cap + at], make_uint4(X, Y, sid, __float_as_uint(dep)));
+                    pic_st4<2>(&PIC_KP(rim, uint4*)[(size_t)tile * p.rim_cap + at], make_uint4(X, Y, sid, __float_as_uint(dep)));
                 }
             }
             if (act) {
                 if (k < on) {
                     const uint32_t q = obase + k;
-                    pic_st<2>(&p.out.x[q], X);                     // (x, y, slot, deposit are read again by the field kernel)
-                    pic_st<2>(&p.out.y[q], Y);
-                    pic_st<1>(&p.out.agent_food[q], af);
-                    pic_st<2>(&p.out.slot[q], sid);
-                    pic_st<1>(&p.out.hhi[q], (uint32_t)__double2hiint(hd));
-                    pic_st<1>(&p.out.hlo[q], (uint32_t)__double2loint(hd));
-                    pic_st<2>(&p.dep[q], dep);
+                    pic_st<2>(&PIC_KP(out.x, uint32_t*)[q], X);    // (x, y, slot, deposit are read again by the field kernel)
+                    pic_st<2>(&PIC_KP(out.y, uint32_t*)[q], Y);
+                    pic_st<1>(&PIC_KP(out.agent_food, float*)[q], af);
+                    pic_st<2>(&PIC_KP(out.slot, uint32_t*)[q], sid);
+                    pic_st<1>(&PIC_KP(out.hhi, uint32_t*)[q], (uint32_t)__double2hiint(hd));
+                    pic_st<1>(&PIC_KP(out.hlo, uint32_t*)[q], (uint32_t)__double2loint(hd));
+                    pic_st<2>(&PIC_KP(dep, float*)[q], dep);
                 } else {
-                    atomicOr(p.error, 1u);
+                    atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
             }
             first = false;
@@ -496,23 +515,23 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     PIC_STAMP(5);
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
         const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
-        atomicAdd(&p.out.inc[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
+        atomicAdd(&PIC_KP(out.inc, uint32_t*)[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
     }
     if (RIM) {
         // (a segment too long for the 24-bit positions counts as an overflowing list: the reader scans it)
         const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(s_cnt >> 42) & 0x1FFFFFu;
         for (uint32_t i = threadIdx.x; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += blockDim.x)
-            pic_st<2>(&((uint32_t*)p.rim_code)[((size_t)tile * p.rim_cap) / 4 + i], ((const uint32_t*)s_rimc)[i]);
-        if (threadIdx.x == 0) p.rim_cnt[tile] = nr;
+            pic_st<2>(&((uint32_t*)PIC_KP(rim_code, uint8_t*))[((size_t)tile * p.rim_cap) / 4 + i], ((const uint32_t*)s_rimc)[i]);
+        if (threadIdx.x == 0) PIC_KP(rim_cnt, uint32_t*)[tile] = nr;
     }
     if (threadIdx.x == 0) {
         long long t = 0;
         for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) t += s_gain[i];
-        p.part_gain[tile] = t;
+        PIC_KP(part_gain, long long*)[tile] = t;
         if (TILED) {
             long long c = 0;
             for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) c += s_alv[i];
-            p.part_gain[(size_t)p.ntx * p.nty + tile] = c;  // second half of the array: owned agents per tile
+            PIC_KP(part_gain, long long*)[(size_t)p.ntx * p.nty + tile] = c;  // second half of the array: owned agents per tile
         }
         const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
         p.out.s[tile] = nfront;
