@@ -410,12 +410,12 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 if (first && idx < n_own) {
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
                 } else {
-                    X = pic_ld<0>(&PIC_KP(in.x, const uint32_t*)[j]);                       // all six streams in flight together
-                    Y = pic_ld<0>(&PIC_KP(in.y, const uint32_t*)[j]);
-                    sid = pic_ld<0>(&PIC_KP(in.slot, const uint32_t*)[j]);
-                    hh = pic_ld<0>(&PIC_KP(in.hhi, const uint32_t*)[j]);
-                    hl = pic_ld<0>(&PIC_KP(in.hlo, const uint32_t*)[j]);
-                    af = pic_ld<0>(&PIC_KP(in.agent_food, const float*)[j]);
+                    // (the pointers first — their scalar loads go out together —, then all six streams in flight together)
+                    const uint32_t *ix_ = PIC_KP(in.x, const uint32_t*), *iy_ = PIC_KP(in.y, const uint32_t*), *is_ = PIC_KP(in.slot, const uint32_t*);
+                    const uint32_t *ihh_ = PIC_KP(in.hhi, const uint32_t*), *ihl_ = PIC_KP(in.hlo, const uint32_t*);
+                    const float* ia_ = PIC_KP(in.agent_food, const float*);
+                    X = pic_ld<0>(&ix_[j]); Y = pic_ld<0>(&iy_[j]); sid = pic_ld<0>(&is_[j]); hh = pic_ld<0>(&ihh_[j]); hl = pic_ld<0>(&ihl_[j]);
+                    af = pic_ld<0>(&ia_[j]);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
                 const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
@@ -484,13 +484,16 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             if (act) {
                 if (k < on) {
                     const uint32_t q = obase + k;
-                    pic_st<2>(&PIC_KP(out.x, uint32_t*)[q], X);    // (x, y, slot, deposit are read again by the field kernel)
-                    pic_st<2>(&PIC_KP(out.y, uint32_t*)[q], Y);
-                    pic_st<1>(&PIC_KP(out.agent_food, float*)[q], af);
-                    pic_st<2>(&PIC_KP(out.slot, uint32_t*)[q], sid);
-                    pic_st<1>(&PIC_KP(out.hhi, uint32_t*)[q], (uint32_t)__double2hiint(hd));
-                    pic_st<1>(&PIC_KP(out.hlo, uint32_t*)[q], (uint32_t)__double2loint(hd));
-                    pic_st<2>(&PIC_KP(dep, float*)[q], dep);
+                    uint32_t *ox_ = PIC_KP(out.x, uint32_t*), *oy_ = PIC_KP(out.y, uint32_t*), *os_ = PIC_KP(out.slot, uint32_t*);
+                    uint32_t *ohh_ = PIC_KP(out.hhi, uint32_t*), *ohl_ = PIC_KP(out.hlo, uint32_t*);
+                    float *oa_ = PIC_KP(out.agent_food, float*), *od_ = PIC_KP(dep, float*);
+                    pic_st<2>(&ox_[q], X);                         // (x, y, slot, deposit are read again by the field kernel)
+                    pic_st<2>(&oy_[q], Y);
+                    pic_st<1>(&oa_[q], af);
+                    pic_st<2>(&os_[q], sid);
+                    pic_st<1>(&ohh_[q], (uint32_t)__double2hiint(hd));
+                    pic_st<1>(&ohl_[q], (uint32_t)__double2loint(hd));
+                    pic_st<2>(&od_[q], dep);
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
