@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 
 class Medium(C.Structure):
@@ -73,7 +73,8 @@ class Pic(C.Structure):
     _fields_ = [('tile_xs', C.c_int32), ('tile_ys', C.c_int32), ('N', C.c_int64), ('layout', PicLayout * 2),
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
-                ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p)]
+                ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
+                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32)]
 
 
 class PicSide(C.Structure):          # die_pic_side: one neighbour of the ghost refresh by tiles

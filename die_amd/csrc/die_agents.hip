@@ -6,6 +6,8 @@
 // (action), five gathers (4 chem taps around the probe cell + food at the own cell).  No LDS:
 // there is no reuse between slots that the L2 does not already provide.
 #include "die_forward.h"
+#include <math.h>
+#include <string.h>
 
 template <typename T, int KIND>
 __global__ __launch_bounds__(DIE_BLOCK) void k_gradient_forward(FwdArgs a) {
@@ -59,6 +61,29 @@ static int fwd_grid(int64_t N) {
     return (int)(g < cap ? (g > 0 ? g : 1) : cap);
 }
 
+// Largest x >= 0 that np.isclose(0, x, rtol, atol) accepts: |x| <= atol + rtol·|x| as numpy evaluates it (product rounded, then
+// the sum; core/agent/gradient.py:177-178).  The accepted set is an interval [0, X] (for rtol < 1 the right-hand side grows
+// a hundred times slower than x), so X is found by bisection over the bit patterns of the non-negative doubles — the device
+// then decides with ONE comparison per test, and the tie at the threshold falls exactly where numpy puts it.
+static double isclose_bound(double atol, double rtol) {
+    auto ok = [&](double x) { volatile double m = rtol * x; volatile double s = atol + m; return x <= s; };
+    if (!ok(0.0)) return -1.0;
+    if (!(rtol < 1.0)) return HUGE_VAL;
+    uint64_t lo = 0, hi;
+    double top = 2.0 * atol / (1.0 - rtol) + 1e-300;
+    if (ok(top)) return HUGE_VAL;
+    memcpy(&hi, &top, 8);
+    while (hi - lo > 1) {                       // ok(lo), !ok(hi)
+        const uint64_t mid = lo + (hi - lo) / 2;
+        double x;
+        memcpy(&x, &mid, 8);
+        if (ok(x)) lo = mid; else hi = mid;
+    }
+    double x;
+    memcpy(&x, &lo, 8);
+    return x;
+}
+
 int die_fill_fwd_args(FwdArgs& k, const die_medium* m, const die_agents* a, const die_gradient_agent* g,
                       const die_action* out, const char* who) {
     DIE_REQUIRE(m && a && g, "%s: null argument", who);
@@ -79,6 +104,14 @@ int die_fill_fwd_args(FwdArgs& k, const die_medium* m, const die_agents* a, cons
     k.noise_scale = g->noise_scale; k.grad_clip = g->grad_clip; k.turn_rad = g->turn_radians;
     k.sense_rad = g->sense_radians; k.rtol = g->turn_tolerance; k.normalized = g->normalized_grad;
     k.seed = g->seed; k.step = g->step; k.step_base = g->step_base;
+    k.atol = k.turn_rad * k.rtol;
+    k.x_turn = isclose_bound(k.atol, 1e-2);
+    k.x_grad = isclose_bound(1e-8, 1e-5);
+    const double pi = 3.141592653589793;
+    k.c_turn = k.x_turn < 0.0 ? 2.f : (k.x_turn >= pi ? -2.f : (float)cos(k.x_turn));
+    k.c_sense = k.sense_rad < 0.0 ? 2.f : (k.sense_rad >= pi ? -2.f : (float)cos(k.sense_rad));
+    k.t_grad = (float)tan(k.x_grad);
+    k.turn_bits = nullptr;
     return DIE_OK;
 }
 

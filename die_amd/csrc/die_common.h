@@ -67,6 +67,19 @@ __device__ __forceinline__ int die_cell(int64_t P, int n) {
     return hi == 0 ? c : (hi < 0 ? 0 : n - 1);
 }
 
+// nearest label to (X + off) / 2^32 for a coordinate X and a signed 32-bit offset (a probe): the 33-bit sum never
+// materialises — a carry out of the 32-bit add (off >= 0) is "beyond the last label", a borrow (off < 0) "before the first"
+__device__ __forceinline__ int die_cell_off(uint32_t X, int32_t off, int n) {
+    const uint32_t lo = X + (uint32_t)off;
+    const bool out = off >= 0 ? lo < X : lo > X;
+    const int c = die_cell_u(lo, n);
+    return out ? (off >= 0 ? n - 1 : 0) : c;
+}
+
+// square root to 1 ulp (v_sqrt_f32) instead of the correctly rounded library form (15 instructions).  Arguments below
+// 2^-126 (denormals) count as 0: lengths that small are below the resolution of everything they are added to.
+__device__ __forceinline__ float die_sqrt1(float v) { return __builtin_amdgcn_sqrtf(v); }
+
 // float displacement (fraction of the unit square) → Q0.32 increment
 // v·2^32 is exact in fp32 (a power-of-two scaling), so below 2^31 the nearest integer comes from the 32-bit convert;
 // larger displacements take the float64 route.  Same value either way.

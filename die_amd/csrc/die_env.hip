@@ -53,7 +53,7 @@ struct StepArgs {
 
 __device__ __forceinline__ float action_cost(const StepArgs& a, float dx, float dy, float dep) {
     // linear_action_cost (core/env.py:29-35) or zero_cost (:38-39)
-    return a.cost == DIE_COST_LINEAR ? a.w_dep * fabsf(dep) + a.w_dist * sqrtf(dx * dx + dy * dy) : 0.f;
+    return a.cost == DIE_COST_LINEAR ? a.w_dep * fabsf(dep) + a.w_dist * die_sqrt1(dx * dx + dy * dy) : 0.f;
 }
 
 __device__ __forceinline__ void block_sum_store(long long g, long long c, long long* pg, long long* pc) {

@@ -28,6 +28,12 @@ struct FwdArgs {
     uint64_t seed;
     uint32_t step;
     const uint32_t* step_base;   // device word added to step (graph replay), or NULL
+    // The decisions of _choose_turn (gradient.py:168-192) as comparisons with constants (die_fill_fwd_args):
+    double x_turn, x_grad;       // largest |x| that np.isclose(0, x, rtol=1e-2, atol=turn·rtol) / np.isclose(0, x, rtol=1e-5) accept
+    double atol;                 // turn_rad · rtol
+    float c_turn, c_sense;       // cos(x_turn), cos(sense_rad): the same tests on the cosine of the angle (generic directions)
+    float t_grad;                // tan(x_grad)
+    const uint32_t* turn_bits;   // the step's random turn bits, one per slot id (die_rng.h die_turn_word), or NULL: evaluate Philox
 };
 
 #define DIE_PI_F 3.14159265358979323846f
@@ -72,6 +78,17 @@ __device__ __forceinline__ double renorm_rad(double r) {
     return m + DIE_PI_D;
 }
 
+// The same value for the arguments this path produces (a heading in (−π, 2π] plus or minus an angle in [−π, π]: a = r − π
+// in (−3π, 2π)): there fmod's quotient is 0 or 1 and the function is a − 2π (a > 0), a + 2π (a <= −2π, exact) or a, then
+// + π — three additions instead of the general form's twenty-odd float64 operations (two of these per agent and step were a
+// tenth of the agent kernel's vector-issue time).  Arguments outside that range take the general form.
+__device__ __forceinline__ double renorm_rad_fast(double r) {
+    const double a = r - DIE_PI_D;
+    if (__builtin_expect(!(fabs(a + 0.75 * DIE_PI_D) < 2.75 * DIE_PI_D), 0)) return renorm_rad(r);      // a outside (−3.5π, 2π)
+    const double k = a > 0.0 ? -DIE_2PI_D : (a <= -DIE_2PI_D ? DIE_2PI_D : 0.0);
+    return (a + k) + DIE_PI_D;
+}
+
 __device__ __forceinline__ double die_heading_ld(const uint32_t* hi, const uint32_t* lo, int64_t n) {
     return __hiloint2double((int)hi[n], (int)lo[n]);
 }
@@ -89,17 +106,6 @@ __device__ __forceinline__ float die_np_angle(float x, float y) {
     return atan2f(im, re);
 }
 
-// np.angle(x + 1j*y) in float64 for float32 components: exact constants where a component is an exact zero (the
-// symmetric cases in which the reference's decisions are ties), the fp32 arctangent elsewhere (1e-7: a generic angle is
-// that far from every threshold).
-__device__ __forceinline__ double die_np_angle64(float x, float y) {
-    const float re = x + (0.f * y - 0.f);
-    const float im = 0.f + (0.f + y);
-    if (im == 0.f) return copysign((re < 0.f || (re == 0.f && signbit(re))) ? DIE_PI_D : 0.0, (double)im);
-    if (re == 0.f) return copysign(0.5 * DIE_PI_D, (double)im);
-    return (double)atan2f(im, re);
-}
-
 // polar2xy(r, heading) of _discrete_turn (core/utils.py:158-169): (r + 0j)·(cos + i·sin) with its zero signs, on the
 // float64 heading rounded to fp32.  One function, because die_pic_action_physarum (die_pic.hip) re-derives a PhysarumAgent's
 // action from the stored heading with it and must reproduce the step's bits.
@@ -115,6 +121,10 @@ struct FwdOut {
     double heading;
 };
 
+// The 4 chem taps of np.gradient at the probe cell (px, py) — central inside the world, one-sided at its four edges
+// (gradient.py:57) — and the food under the agent's own cell (cx, cy).
+struct FwdTaps { float cxm, cxp, cym, cyp, f_own; };
+
 // Reads the 4 chem taps around the probe cell and the food under the agent, decides the turn,
 // applies momentum, updates _prev_grad in place (when kept) and returns heading' and the action.
 // EXT = false compiles the sense-mask test out (the benchmark path; chosen at launch when mask == NULL).
@@ -129,10 +139,13 @@ struct FwdGlobalMem {
     __device__ __forceinline__ explicit FwdGlobalMem(const FwdArgs& a) : chem((const T*)a.chem), food((const T*)a.food), mask(a.mask), g(a.g) {}
     // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
     __device__ __forceinline__ float seen(const T* p, const int64_t i) const { return (EXT && mask && !mask[i]) ? 0.f : die_ld(p, i); }
-    struct Home {};                                     // (see FwdTileMem)
-    __device__ __forceinline__ Home home(int, int) const { return Home{}; }
-    __device__ __forceinline__ float chem_at(int gx, int gy, Home) const { return seen(chem, die_local(g, gx, gy)); }
-    __device__ __forceinline__ float food_at(int gx, int gy, Home) const { return seen(food, die_local(g, gx, gy)); }
+    __device__ __forceinline__ FwdTaps taps(int px, int py, int xm, int xp, int ym, int yp, int cx, int cy) const {
+        FwdTaps t;
+        t.cxm = seen(chem, die_local(g, xm, py)); t.cxp = seen(chem, die_local(g, xp, py));
+        t.cym = seen(chem, die_local(g, px, ym)); t.cyp = seen(chem, die_local(g, px, yp));
+        t.f_own = seen(food, die_local(g, cx, cy));
+        return t;
+    }
 };
 // … or a tile staged in LDS (die_pic.hip): chem with a margin of the probe reach around the tile, food of the tile itself
 template <typename T, bool TILED = false>
@@ -147,74 +160,119 @@ struct FwdTileMem {
     // die_plane_coord(gx) == clamp(die_plane_coord(cx) + (gx − cx), 0, W − 1) for every tap within the staged margin — provided
     // the world is larger than the planes by more than twice that margin, or the planes span it (checked on the host,
     // die_pic_forward_env_step).  Ten mappings per agent were 8 % of the agent kernel's instructions.
-    struct Home { int dx, dy; };
-    __device__ __forceinline__ Home home(int cx, int cy) const {
-        Home h = {0, 0};
-        if (TILED) { h.dx = die_plane_coord(cx, g.ox, g.W, g.gW) - cx; h.dy = die_plane_coord(cy, g.oy, g.H, g.gH) - cy; }
-        return h;
+    __device__ __forceinline__ FwdTaps taps(int px, int py, int xm, int xp, int ym, int yp, int cx, int cy) const {
+        FwdTaps t;
+        if (TILED) {
+            const int hx = die_plane_coord(cx, g.ox, g.W, g.gW) - cx, hy = die_plane_coord(cy, g.oy, g.H, g.gH) - cy;
+            auto lx = [&](int gx) { return min(max(gx + hx, 0), g.W - 1) - cx0; };
+            auto ly = [&](int gy) { return min(max(gy + hy, 0), g.H - 1) - cy0; };
+            const int rp = lx(px) * pitch, cp = ly(py);
+            t.cxm = die_ld(chem, (int64_t)(lx(xm) * pitch + cp)); t.cxp = die_ld(chem, (int64_t)(lx(xp) * pitch + cp));
+            t.cym = die_ld(chem, (int64_t)(rp + ly(ym))); t.cyp = die_ld(chem, (int64_t)(rp + ly(yp)));
+            t.f_own = die_ld(food, (int64_t)((cx + hx - fx0) * fpitch + (cy + hy - fy0)));
+        } else {
+            // one multiply for the probe cell, the four taps by their distance from it (0 where the world ends)
+            const int c = (px - cx0) * pitch + (py - cy0);
+            t.cxm = die_ld(chem, (int64_t)(c - (px - xm) * pitch)); t.cxp = die_ld(chem, (int64_t)(c + (xp - px) * pitch));
+            t.cym = die_ld(chem, (int64_t)(c - (py - ym))); t.cyp = die_ld(chem, (int64_t)(c + (yp - py)));
+            t.f_own = die_ld(food, (int64_t)((cx - fx0) * fpitch + (cy - fy0)));
+        }
+        return t;
     }
-    __device__ __forceinline__ int lx(int gx, Home h) const { return TILED ? min(max(gx + h.dx, 0), g.W - 1) : gx; }
-    __device__ __forceinline__ int ly(int gy, Home h) const { return TILED ? min(max(gy + h.dy, 0), g.H - 1) : gy; }
-    __device__ __forceinline__ float chem_at(int gx, int gy, Home h) const { return die_ld(chem, (int64_t)((lx(gx, h) - cx0) * pitch + (ly(gy, h) - cy0))); }
-    __device__ __forceinline__ float food_at(int gx, int gy, Home h) const { return die_ld(food, (int64_t)((lx(gx, h) - fx0) * fpitch + (ly(gy, h) - fy0))); }
     // … and by plane element, for a caller that has mapped the cell already
     __device__ __forceinline__ float food_plane(int px_, int py_) const { return die_ld(food, (int64_t)((px_ - fx0) * fpitch + (py_ - fy0))); }
 };
 
-template <typename T, int KIND, bool EXT, class MEM>
+// g / |g| with 0/0 → 0 (gradient.py:60-63) and |g| itself, to ≈ 2 ulp: the components are scaled by a power of two that
+// brings the larger one to [0.5, 1) (exact; no square overflows or vanishes, whatever the chem values' magnitude — they
+// decay towards the denormals), then one v_rsq_f32 and two products.  (The correctly rounded sqrt and two IEEE divisions
+// this replaces were 50 instructions of every forward.)
+__device__ __forceinline__ void die_normalize2(float gx, float gy, float* ux, float* uy, float* norm) {
+    const float gm = fmaxf(fabsf(gx), fabsf(gy));
+    const int e = __builtin_amdgcn_frexp_expf(gm);
+    const float sx = ldexpf(gx, -e), sy = ldexpf(gy, -e);
+    const float n2 = sx * sx + sy * sy;
+    const float inv = __builtin_amdgcn_rsqf(n2);
+    const bool ok = n2 > 0.f;
+    *ux = ok ? sx * inv : 0.f;
+    *uy = ok ? sy * inv : 0.f;
+    *norm = ok ? ldexpf(n2 * inv, e) : 0.f;
+}
+
+// TB: the random turn bits come from the step's table (FwdArgs.turn_bits, filled by die_turn_bits_fill) instead of a Philox
+// evaluation per agent — the same bits (die_rng.h).
+template <typename T, int KIND, bool EXT, class MEM, bool TB = false>
 __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const MEM& mem, const uint32_t X, const uint32_t Y, const double d64,
                                                        const uint32_t sid, const int64_t n) {
     const float d = (float)d64;             // trigonometry in fp32 (1e-7 of a cell on the probe), decisions in float64
     const die_geo g = a.g;
     const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
+    uint32_t tbits = 0;
+    if (TB && KIND == DIE_AGENT_PHYSARUM) tbits = a.turn_bits[sid >> 5];      // (requested first: needed last)
     float sd, cd;
     die_sincos(d, &sd, &cd);
     // probe cell: agents + sense_offset·(cos d, sin d), nearest label, clamped (gradient.py:73-76,105)
-    const int px = die_cell((int64_t)X + (MEM::kSmallOffsets ? die_q32_small(a.sense_offset * cd) : die_q32(a.sense_offset * cd)), W);
-    const int py = die_cell((int64_t)Y + (MEM::kSmallOffsets ? die_q32_small(a.sense_offset * sd) : die_q32(a.sense_offset * sd)), H);
+    const int px = MEM::kSmallOffsets ? die_cell_off(X, (int32_t)die_q32_small(a.sense_offset * cd), W) : die_cell((int64_t)X + die_q32(a.sense_offset * cd), W);
+    const int py = MEM::kSmallOffsets ? die_cell_off(Y, (int32_t)die_q32_small(a.sense_offset * sd), H) : die_cell((int64_t)Y + die_q32(a.sense_offset * sd), H);
     // np.gradient at the probe cell: central inside, one-sided at the four edges (gradient.py:57)
     const int xm = px > 0 ? px - 1 : 0, xp = px < W - 1 ? px + 1 : W - 1;
     const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;
-    const int cx = die_cell((int64_t)X, W), cy = die_cell((int64_t)Y, H);
-    const typename MEM::Home hm = mem.home(cx, cy);
-    const float cxm = mem.chem_at(xm, py, hm), cxp = mem.chem_at(xp, py, hm);
-    const float cym = mem.chem_at(px, ym, hm), cyp = mem.chem_at(px, yp, hm);
-    // food under the agent (gradient.py:114-116)
-    const float f_own = mem.food_at(cx, cy, hm);
-    const float gx = (cxp - cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
-    const float gy = (cyp - cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
-    const float norm = sqrtf(gx * gx + gy * gy);
-    float ux = gx, uy = gy;
-    if (a.normalized) {                       // g / |g| with 0/0 → 0 (gradient.py:60-63)
-        ux = norm > 0.f ? gx / norm : 0.f;
-        uy = norm > 0.f ? gy / norm : 0.f;
-    }
+    const int cx = die_cell_u(X, W), cy = die_cell_u(Y, H);
+    // the taps, and the food under the agent (gradient.py:114-116)
+    const FwdTaps t = mem.taps(px, py, xm, xp, ym, yp, cx, cy);
+    const float gx = (t.cxp - t.cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
+    const float gy = (t.cyp - t.cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
+    float nx, ny, norm;
+    die_normalize2(gx, gy, &nx, &ny, &norm);
+    float ux = a.normalized ? nx : gx, uy = a.normalized ? ny : gy;
     // grad *= (norm >= grad_clip) (gradient.py:64-66): a masked component becomes a SIGNED zero, and
     // np.angle(∓0 ∓0j) below is 0, −0, π or −π by quadrant — a sub-threshold gradient with gx < 0 is
     // therefore NOT "undetermined" in the reference.  Keep the signs.
-    if (a.grad_clip >= 0.f && !(norm >= a.grad_clip)) { ux = copysignf(0.f, ux); uy = copysignf(0.f, uy); }
+    const bool clipped = a.grad_clip >= 0.f && !(norm >= a.grad_clip);
+    if (clipped) { ux = copysignf(0.f, ux); uy = copysignf(0.f, uy); }
 
     double d_new = d64;
     float dep_mask = 1.0f;
     bool heading_from_vector = true;
     if (KIND == DIE_AGENT_PHYSARUM) {
-        // _discrete_turn / _choose_turn (gradient.py:168-208), in float64 like the reference
-        const double drads = die_np_angle64(ux, uy);
-        const double delta = renorm_rad(d64 - drads);
-        const double atol = a.turn_rad * a.rtol;
-        const bool und_grad = fabs(drads) <= 1e-8 + 1e-5 * fabs(drads);
-        const bool und_turn = fabs(delta) <= atol + 1e-2 * fabs(delta);
-        const bool unseen = fabs(delta) > a.sense_rad;
+        // _discrete_turn / _choose_turn (gradient.py:168-208).  np.angle(ux + 1j·uy) (core/utils.py:158-169): 1j·uy is
+        // (0·uy − 0) + (0 + uy)j and the sum with ux adds the real parts, so uy = −0 becomes +0 and ux = −0 survives only
+        // next to a negative uy.
+        const float re = ux + (0.f * uy - 0.f);
+        const float im = 0.f + (0.f + uy);
+        bool und_grad, und_turn, unseen, right;
+        if (im == 0.f || re == 0.f) {
+            // an axis-aligned direction — every sub-threshold gradient, and the symmetric situations in which the reference's
+            // decisions are exact ties (a probe on the axis of an isolated deposit sees a gradient exactly 90° off the heading):
+            // the angle is an exact float64 constant and the tests are the reference's float64 operations
+            const double drads = im == 0.f ? ((re < 0.f || (re == 0.f && signbit(re))) ? DIE_PI_D : 0.0) : copysign(0.5 * DIE_PI_D, (double)im);
+            const double delta = renorm_rad_fast(d64 - drads);
+            und_grad = fabs(drads) <= a.x_grad;
+            und_turn = fabs(delta) <= a.x_turn;
+            unseen = fabs(delta) > a.sense_rad;
+            right = delta > a.atol;
+        } else {
+            // any other direction: the same tests on |u|·cos and |u|·sin of delta = heading − angle(u), from the heading's
+            // (cos, sin) — no arctangent, no float64.  A decision differs from the float64 one only within ≈ 3e-7 rad of a
+            // threshold (the fp32 arctangent this replaces was no closer).
+            const float nrm = a.normalized ? 1.f : norm;
+            const float c = cd * ux + sd * uy, s = sd * ux - cd * uy;
+            und_grad = ux > 0.f && fabsf(uy) <= a.t_grad * ux;
+            und_turn = c >= a.c_turn * nrm;
+            unseen = c < a.c_sense * nrm;
+            right = s > 0.f;
+        }
         const bool und = und_grad || und_turn || unseen;
         double sgn;
         if (und) {
             if (a.turn_sign) sgn = (double)a.turn_sign[sid];
-            else sgn = (die_draw(a.seed, a.step + (a.step_base ? *a.step_base : 0u), (uint64_t)sid, DIE_STREAM_TURN).v[0] & 1u) ? 1.0 : -1.0;
+            else if (TB) sgn = ((tbits >> (sid & 31u)) & 1u) ? 1.0 : -1.0;
+            else sgn = die_turn_bit(a.seed, a.step + (a.step_base ? *a.step_base : 0u), sid) ? 1.0 : -1.0;
         } else {
-            sgn = delta > atol ? -1.0 : 1.0;  // right (clockwise) / left
+            sgn = right ? -1.0 : 1.0;         // right (clockwise) / left
         }
-        const double d2_64 = renorm_rad(d64 + sgn * a.turn_rad);
-        const float r = a.normalized ? 1.f : sqrtf(ux * ux + uy * uy);
+        const double d2_64 = renorm_rad_fast(d64 + sgn * a.turn_rad);
+        const float r = a.normalized ? 1.f : (clipped ? 0.f : norm);      // abs(z) of _discrete_turn
         die_polar2xy_heading(d2_64, r, &ux, &uy);
         dep_mask = (und_grad || und_turn) ? 0.1f : 1.0f;   // clip(mask, .1, 1) (gradient.py:210-214)
         d_new = d2_64;            // (the reference re-derives it as angle(exp(i·d2)): the same value up to one ulp of libm noise)
@@ -222,7 +280,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     }
     // _process_momentum (gradient.py:82-91)
     if (a.inertia != 0.f || a.noise_scale != 0.f) {
-        float nx = 0.f, ny = 0.f;
+        float nx_ = 0.f, ny_ = 0.f;
         if (a.noise_scale != 0.f) {
             const die_u32x4 r = die_draw(a.seed, a.step + (a.step_base ? *a.step_base : 0u), (uint64_t)sid, DIE_STREAM_NOISE);
             const float u1 = ((float)r.v[0] + 1.0f) * 2.3283064365386963e-10f;
@@ -230,12 +288,12 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
             const float rad = 0.4f * sqrtf(-2.0f * logf(u1));
             float sn, cn;
             sincosf(DIE_2PI_F * u2, &sn, &cn);
-            nx = rad * cn;
-            ny = rad * sn;
+            nx_ = rad * cn;
+            ny_ = rad * sn;
         }
         const float ox = a.pgx ? a.pgx[n] : 0.f, oy = a.pgy ? a.pgy[n] : 0.f;
-        ux = (1.f - a.inertia) * ux + a.inertia * ox + a.noise_scale * nx;
-        uy = (1.f - a.inertia) * uy + a.inertia * oy + a.noise_scale * ny;
+        ux = (1.f - a.inertia) * ux + a.inertia * ox + a.noise_scale * nx_;
+        uy = (1.f - a.inertia) * uy + a.inertia * oy + a.noise_scale * ny_;
         heading_from_vector = true;
     }
     else {                                                 // (1−0)·g + 0·prev + 0·noise: the sum ends with "+ (+0)", which turns −0 into +0
@@ -248,7 +306,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     o.heading = d_new;
     o.dx = ux * a.scale;
     o.dy = uy * a.scale;
-    o.dep = a.deposit * f_own * dep_mask;
+    o.dep = a.deposit * t.f_own * dep_mask;
     return o;
 }
 

@@ -134,7 +134,8 @@ struct PicArgs {
     die_geo g;
     int ntx, nty, xs, ys;           // tiles per axis, log2 of the tile shape
     int margin;                     // K1 stages chem of the tile ± margin cells (a multiple of the 16-byte vector width)
-    int cs_c, cs_f;                 // log2 of the lanes that share a staged row of the chem / food tile (2^cs >= 16-byte vectors per row)
+    int fm_r, fm_c;                 // … and food of the tile ± fm_r rows / fm_c columns (periodic): the cells an agent of the tile can walk onto
+    uint32_t mg_c, mg_f;            // ceil(2^20 / 16-byte vectors per staged row) of the chem / food block (PicStageRows)
     PicLayout in, out;
     float* dep;                     // N: deposit of every agent, `out` order (K1 → K2)
     float *adx, *ady, *adep;        // the action handed back to the caller, `in` order
@@ -216,16 +217,24 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
 // of blockDim >> cs: per vector one add, two clamps, a multiply-add and the address — the first cut, with a division for
 // the row and tests around every load, spent a quarter of the kernel's instructions here.  Rows / columns outside the
 // world are never read by anybody (probes clamp at the world's edge): their loads are clamped into the plane, no branch.
-template <typename T, int NTB = -1>
+// WRAP: rows / columns beyond the plane are their periodic images (the food under an agent that has just walked across the
+// world's seam; H is a multiple of the vector width, so a column vector never straddles the seam).
+template <typename T, int NTB = -1, bool WRAP = false>
 struct PicStage {
     const T* plane;
     int gx0, gy0, vpr, rows, W, H, cs;
     __device__ __forceinline__ uint4 load(int row, int gyc) const {
-        const int gx = min(max(gx0 + min(row, rows - 1), 0), W - 1);
+        int gx = gx0 + min(row, rows - 1);
+        if (WRAP) { gx += gx < 0 ? W : 0; gx -= gx >= W ? W : 0; }
+        else gx = min(max(gx, 0), W - 1);
         return pic_ld4<NTB>(plane + (__mul24(gx, H) + gyc));
     }
     __device__ __forceinline__ int column() const { return min((int)threadIdx.x & ((1 << cs) - 1), vpr - 1); }
-    __device__ __forceinline__ int col_cell(int cv) const { return min(max(gy0 + cv * (16 / (int)sizeof(T)), 0), H - 16 / (int)sizeof(T)); }
+    __device__ __forceinline__ int col_cell(int cv) const {
+        int gy = gy0 + cv * (16 / (int)sizeof(T));
+        if (WRAP) { gy += gy < 0 ? H : 0; gy -= gy >= H ? H : 0; return gy; }
+        return min(max(gy, 0), H - 16 / (int)sizeof(T));
+    }
     // the first NB rows of every thread: requested at the very top of the kernel (issue), written to LDS once the
     // per-tile words and the agent streams have been requested too (commit) …
     template <int NB> __device__ __forceinline__ void issue(uint4 (&v)[NB]) const {
@@ -243,8 +252,54 @@ struct PicStage {
     }
 };
 
+// The same copy with lane groups of EXACTLY `vpr` threads per row (row r0 = thread / vpr by a multiply-shift the host has
+// verified, blockDim / vpr rows per pass; the last blockDim % vpr threads idle): the power-of-two groups above leave the lanes
+// beyond `vpr` idle — 10 of 32 for the 88-cell chem rows, 14 of 32 for the food rows — so the chem tile ± 12 cells takes 4
+// vectors per thread instead of 6 and the food tile with its margin 3.  A thread keeps its column; per vector: one add, the
+// row's wrap or clamp, a multiply-add, the address.
+template <typename T, int NTB, bool WRAP>
+struct PicStageRows {
+    const T* plane;
+    int gx0, gy0, vpr, rows, W, H;
+    uint32_t mg;                    // ceil(2^20 / vpr)
+    int rp;                         // rows per pass = blockDim / vpr
+    __device__ __forceinline__ uint4 load(int row, int gy) const {
+        int gx = gx0 + min(row, rows - 1);
+        if (WRAP) { gx += gx < 0 ? W : 0; gx -= gx >= W ? W : 0; }
+        else gx = min(max(gx, 0), W - 1);
+        return pic_ld4<NTB>(plane + (__mul24(gx, H) + gy));
+    }
+    __device__ __forceinline__ void where(int& r0, int& cv, int& gy) const {
+        r0 = (int)(((uint32_t)threadIdx.x * mg) >> 20);
+        cv = (int)threadIdx.x - r0 * vpr;
+        gy = gy0 + cv * (16 / (int)sizeof(T));
+        if (WRAP) { gy += gy < 0 ? H : 0; gy -= gy >= H ? H : 0; }
+        else gy = min(max(gy, 0), H - 16 / (int)sizeof(T));
+    }
+    // the first NB rows of every thread: requested at the very top of the kernel (issue), written to LDS once the
+    // per-tile words and the agent streams have been requested too (commit) …
+    template <int NB> __device__ __forceinline__ void issue(uint4 (&v)[NB]) const {
+        int r0, cv, gy;
+        where(r0, cv, gy);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) v[q] = load(r0 + q * rp, gy);          // (idle threads: r0 = rp, rows clamp: a harmless copy)
+    }
+    template <int NB> __device__ __forceinline__ void commit(T* dst, const uint4 (&v)[NB]) const {
+        int r0, cv, gy;
+        where(r0, cv, gy);
+        if (r0 >= rp) return;                                            // the blockDim % vpr threads without a column
+        uint4* d = (uint4*)dst + (r0 * vpr + cv);
+#pragma unroll
+        for (int q = 0; q < NB; ++q) if (r0 + q * rp < rows) d[q * rp * vpr] = v[q];
+        // … and whatever a larger tile / a smaller workgroup leaves over
+        for (int row = r0 + NB * rp; row < rows; row += rp) ((uint4*)dst)[row * vpr + cv] = load(row, gy);
+    }
+};
+
 #define PIC_RIM_CAP_MAX 224      // entries of a tile's rim list (k_pic_resolve_diffuse reads the codes of 9 lists with one word per thread)
-#define PIC_LIST_CAP 1024       // arrivals of one tile compacted per round (≈ 30 arrive in the benchmark world)
+#ifndef PIC_LIST_CAP
+#define PIC_LIST_CAP 512        // arrivals of one tile compacted per round (≈ 80 arrive in the benchmark world)
+#endif
 // (The first round appends up to one candidate per thread: a list shorter than the workgroup is written past its end.  A
 // round-2 experiment build with a shorter list faulted that way — most probably the `n1` run of gpurun_out/sw3_n1.err,
 // DESIGN.md §10 — hence the assertion; tests/test_gpu_parity.py::test_tile_binned_step_with_a_crowd_crossing_one_border
@@ -264,6 +319,12 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_K1_MINW
 #define PIC_K1_MINW 6
 #endif
+#ifndef PIC_STATIC_CHUNKS
+#define PIC_STATIC_CHUNKS 0     // 1: wave w takes chunks w, w + waves, … instead of drawing them from an LDS counter
+#endif
+// element `idx` of a 4-byte-per-agent array: a 32-bit byte offset on the array's (scalar) base — the host refuses worlds of
+// 2^30 agents —, so every stream of an agent shares ONE offset register instead of a 64-bit address of its own
+#define PIC_AT(base, type, idx) (*(type*)((char*)(base) + (size_t)(uint32_t)((uint32_t)(idx) << 2)))
 template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
@@ -277,8 +338,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     // scalar registers from the kernel's entry they (106 registers + 70 spilled to vector lanes, every use a v_readlane and a
     // hazard nop: vector-issue slots of a kernel that is half vector issue) cost more than re-reading them from the
     // kernel-argument segment right where they are used: volatile, so that the compiler neither hoists nor keeps them.
-    // 2 077 → 1 875 instructions, spilled scalars 70 → 35 (decomposed tiles: 2 461 → 2 129, 107 → 43); 80.7 → 79.2 µs (TILED: 88.8 →
-    // 83.5).  The two by-value arguments lie in the segment one after the other, each 8-byte aligned.
+    // The two by-value arguments lie in the segment one after the other, each 8-byte aligned.
     struct KArgs { FwdArgs f; PicArgs p; };
     static_assert(alignof(FwdArgs) == 8 && alignof(PicArgs) == 8 && sizeof(FwdArgs) % 8 == 0, "kernel-argument layout of k_pic_forward_move");
     const volatile KArgs __attribute__((address_space(4)))* ka = (const volatile KArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -286,7 +346,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
 #else
 #define PIC_KP(field, type) (p.field)
 #endif
-    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile
+    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile ± its margin
     __shared__ uint32_t s_base[9], s_pre[10];
     __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
     __shared__ uint32_t s_next, s_nlist;
@@ -309,12 +369,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const T* food = (const T*)p.food;
     constexpr int SV = 16 / (int)sizeof(T);
     const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
-    const PicStage<T, 7> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.cs_c};
-    const PicStage<T, 5> st_f = {food, x0, y0, TY / SV, TX, p.g.W, p.g.H, p.cs_f};
-    uint4 sc[6], sf[2];                   // 64×64 tile, margin 12, 512 threads: 88 rows / 16 per pass, 64 rows / 32 per pass
+    const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
+    const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, (int)blockDim.x / (pitch / SV)};
+    const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, (int)blockDim.x / (fpitch / SV)};
+    uint4 sc[4], sf[3];                   // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
     if (STAGE) {
         st_c.issue(sc);
-        if (PIC_STAGE_FOOD) st_f.issue(sf);
+        st_f.issue(sf);
     }
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
     pic_ranges_finish(mt, s_base, s_pre);
@@ -329,8 +390,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         int r = 1;
         while (idx >= s_pre[r + 1]) ++r;
         cj = s_base[r] + (idx - s_pre[r]);
-        cX = pic_ld<0>(&p.in.x[cj]);
-        cY = pic_ld<0>(&p.in.y[cj]);
+        cX = PIC_AT(p.in.x, const uint32_t, cj);
+        cY = PIC_AT(p.in.y, const uint32_t, cj);
     }
     const uint32_t pidx = (uint32_t)(wave * DIE_WAVE + lane);
     const bool phas = pidx < own;
@@ -338,22 +399,20 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     float pA = 0.f;
     if (phas) {
         const uint32_t j = base0 + pidx;
-        pX = pic_ld<0>(&p.in.x[j]); pY = pic_ld<0>(&p.in.y[j]); pS = pic_ld<0>(&p.in.slot[j]); pHh = pic_ld<0>(&p.in.hhi[j]); pHl = pic_ld<0>(&p.in.hlo[j]);
-        pA = pic_ld<0>(&p.in.agent_food[j]);
+        pX = PIC_AT(p.in.x, const uint32_t, j); pY = PIC_AT(p.in.y, const uint32_t, j); pS = PIC_AT(p.in.slot, const uint32_t, j);
+        pHh = PIC_AT(p.in.hhi, const uint32_t, j); pHl = PIC_AT(p.in.hlo, const uint32_t, j);
+        pA = PIC_AT(p.in.agent_food, const float, j);
     }
     PIC_SETPRIO(PIC_PRIO_K1, 1);
     FwdTileMem<T, TILED> tm;
     tm.g = p.g;
+    T* s_food = nullptr;
     if (STAGE) {
         T* s_chem = (T*)pic_smem;
-        T* s_food = s_chem + rows * pitch;
+        s_food = s_chem + rows * pitch;
         st_c.commit(s_chem, sc);
-        if (PIC_STAGE_FOOD) {
-            st_f.commit(s_food, sf);
-            tm.food = s_food; tm.fx0 = x0; tm.fy0 = y0; tm.fpitch = TY;
-        } else {
-            tm.food = food; tm.fx0 = 0; tm.fy0 = 0; tm.fpitch = p.g.H;
-        }
+        st_f.commit(s_food, sf);
+        tm.food = s_food; tm.fx0 = x0 - FR; tm.fy0 = y0 - FC; tm.fpitch = fpitch;
         tm.chem = s_chem; tm.cx0 = x0 - P; tm.cy0 = y0 - P; tm.pitch = pitch;
     }
     PIC_STAMP(2);
@@ -375,7 +434,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 int r = 1;
                 while (idx >= s_pre[r + 1]) ++r;
                 j = s_base[r] + (idx - s_pre[r]);
-                hit = pic_tile_of<TILED>(p, p.in.x[j], p.in.y[j]) == tile;
+                hit = pic_tile_of<TILED>(p, PIC_AT(p.in.x, const uint32_t, j), PIC_AT(p.in.y, const uint32_t, j)) == tile;
             }
             const unsigned long long m = __ballot(hit);
             uint32_t at = 0;
@@ -388,14 +447,18 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         PIC_SETPRIO(PIC_PRIO_K1, 2);
         const uint32_t n_own = cb == 0 ? own : 0u, count = n_own + s_nlist;
         bool first = cb == 0;
+        uint32_t cprev = 0;
         for (;;) {                         // a wave's first chunk is fixed (its streams are already here), then it takes
             uint32_t c = 0;                // chunks of 64 items from the counter until none are left
             if (first) {
                 c = (uint32_t)(wave * DIE_WAVE);
+            } else if (PIC_STATIC_CHUNKS) {
+                c = cprev + (uint32_t)(nwaves * DIE_WAVE);
             } else {
                 if (lane == 0) c = atomicAdd(&s_next, (uint32_t)DIE_WAVE);
                 c = __shfl(c, 0, DIE_WAVE);
             }
+            cprev = c;
             if (c >= count) break;
             const uint32_t idx = c + lane;
             const bool act = idx < count;
@@ -414,13 +477,14 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     const uint32_t *ix_ = PIC_KP(in.x, const uint32_t*), *iy_ = PIC_KP(in.y, const uint32_t*), *is_ = PIC_KP(in.slot, const uint32_t*);
                     const uint32_t *ihh_ = PIC_KP(in.hhi, const uint32_t*), *ihl_ = PIC_KP(in.hlo, const uint32_t*);
                     const float* ia_ = PIC_KP(in.agent_food, const float*);
-                    X = pic_ld<0>(&ix_[j]); Y = pic_ld<0>(&iy_[j]); sid = pic_ld<0>(&is_[j]); hh = pic_ld<0>(&ihh_[j]); hl = pic_ld<0>(&ihl_[j]);
-                    af = pic_ld<0>(&ia_[j]);
+                    X = PIC_AT(ix_, const uint32_t, j); Y = PIC_AT(iy_, const uint32_t, j); sid = PIC_AT(is_, const uint32_t, j);
+                    hh = PIC_AT(ihh_, const uint32_t, j); hl = PIC_AT(ihl_, const uint32_t, j);
+                    af = PIC_AT(ia_, const float, j);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
-                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false>(f, tm, X, Y, hd, sid, (int64_t)j)
-                                       : die_forward_agent<T, KIND, false>(f, X, Y, hd, sid, (int64_t)j);
-                if (ACT && p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }   // ACT = false: the caller passed no action arrays
+                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, true>(f, tm, X, Y, hd, sid, (int64_t)j)
+                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, true>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
+                if (ACT && p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
                 // (a step is shorter than a tile — checked on the host — so the fixed-point increment needs no float64 path)
                 if (p.boundary == DIE_BOUNDARY_WRAP) {
@@ -431,15 +495,26 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
                     Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
                 }
-                const int gcx = die_cell((int64_t)X, p.g.gW), gcy = die_cell((int64_t)Y, p.g.gH);      // world cell …
+                const int gcx = die_cell_u(X, p.g.gW), gcy = die_cell_u(Y, p.g.gH);                      // world cell …
                 const int cx = TILED ? die_plane_coord(gcx, p.g.ox, p.g.W, p.g.gW) : gcx;                // … and where the planes hold it
                 const int cy = TILED ? die_plane_coord(gcy, p.g.oy, p.g.H, p.g.gH) : gcy;
                 const int ntx_ = cx >> p.xs, nty_ = cy >> p.ys;
                 stay = ntx_ == tx && nty_ == ty;
-                // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption
-                const float fnew = (STAGE && stay) ? tm.food_plane(cx, cy) : die_ld(food, (int64_t)cx * p.g.H + cy);
+                // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption —
+                // from the staged food block, whose margin holds every cell an agent of the tile can reach in one step (a flat
+                // load from "LDS or global memory" here made every wave drain its outstanding stores before each chunk)
+                float fnew;
+                if (STAGE) {
+                    int rx = cx - x0, ry = cy - y0;                                    // relative to the tile, periodic
+                    rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
+                    ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
+                    rx = min(max(rx + FR, 0), frows - 1); ry = min(max(ry + FC, 0), fpitch - 1);   // (a longer jump is an error, flagged below: never out of the block)
+                    fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry));
+                } else {
+                    fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
+                }
                 const float consumed = p.rate_feed * fnew;
-                const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * sqrtf(o.dx * o.dx + o.dy * o.dy) : 0.f;
+                const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
                 const float gained = consumed - cost;
                 af += gained;
                 // (a ghost is its owner's to count; die_owned on the plane element: a cell beyond the planes maps to an edge element, never owned)
@@ -487,13 +562,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     uint32_t *ox_ = PIC_KP(out.x, uint32_t*), *oy_ = PIC_KP(out.y, uint32_t*), *os_ = PIC_KP(out.slot, uint32_t*);
                     uint32_t *ohh_ = PIC_KP(out.hhi, uint32_t*), *ohl_ = PIC_KP(out.hlo, uint32_t*);
                     float *oa_ = PIC_KP(out.agent_food, float*), *od_ = PIC_KP(dep, float*);
-                    pic_st<2>(&ox_[q], X);                         // (x, y, slot, deposit are read again by the field kernel)
-                    pic_st<2>(&oy_[q], Y);
-                    pic_st<1>(&oa_[q], af);
-                    pic_st<2>(&os_[q], sid);
-                    pic_st<1>(&ohh_[q], (uint32_t)__double2hiint(hd));
-                    pic_st<1>(&ohl_[q], (uint32_t)__double2loint(hd));
-                    pic_st<2>(&od_[q], dep);
+                    PIC_AT(ox_, uint32_t, q) = X;                  // (x, y, slot, deposit are read again by the field kernel)
+                    PIC_AT(oy_, uint32_t, q) = Y;
+                    PIC_AT(oa_, float, q) = af;
+                    PIC_AT(os_, uint32_t, q) = sid;
+                    PIC_AT(ohh_, uint32_t, q) = (uint32_t)__double2hiint(hd);
+                    PIC_AT(ohl_, uint32_t, q) = (uint32_t)__double2loint(hd);
+                    PIC_AT(od_, float, q) = dep;
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
@@ -540,6 +615,20 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         p.out.s[tile] = nfront;
         if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
     }
+}
+
+// The random turn bits of one step, one Philox block per 128 slot ids (die_rng.h die_turn_word): word w of the table for
+// w < words.  Launched by die_pic_forward_env_step when the table does not hold this step's bits yet; in steady state the
+// field kernel's spare workgroups fill it for the NEXT step.
+__device__ __forceinline__ void pic_turn_bits_fill(uint32_t* table, int64_t words, uint64_t seed, uint32_t step, int64_t first, int64_t stride) {
+    for (int64_t b = first; b * 4 < words; b += stride) {
+        const die_u32x4 r = die_philox((uint32_t)b, 0u, step, DIE_STREAM_TURN, (uint32_t)seed, (uint32_t)(seed >> 32));
+        if (b * 4 + 3 < words) *(uint4*)(table + b * 4) = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        else for (int q = 0; q < 4 && b * 4 + q < words; ++q) table[b * 4 + q] = r.v[q];
+    }
+}
+__global__ __launch_bounds__(DIE_BLOCK) void k_turn_bits(uint32_t* table, int64_t words, uint64_t seed, uint32_t step) {
+    pic_turn_bits_fill(table, words, seed, step, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
 }
 
 // K2.  blockIdx.x == number of tiles: the scan workgroup (sizes and offsets of the layout the NEXT step writes:
@@ -673,6 +762,10 @@ struct KbArgs {
     long long alive_const;
     long long* status_out;                                  // where the reduction workgroup copies the error word (die_pic.status_out), or NULL
     const uint32_t* error;
+    uint32_t* turn_bits;                                    // the NEXT step's random turn bits (pic_turn_bits_fill), or NULL
+    int64_t turn_words;
+    uint64_t turn_seed;
+    uint32_t turn_step;
 };
 
 template <int XS, int YS> struct KbShape {
@@ -762,6 +855,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
                 if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
             }
+        } else if (blockIdx.x >= 2 && a.turn_bits) {        // the rest of the row: the next step's turn bits (this step's agent kernel is done with the table)
+            pic_turn_bits_fill(a.turn_bits, a.turn_words, a.turn_seed, a.turn_step, (int64_t)(blockIdx.x - 2) * BLOCK + threadIdx.x,
+                               (int64_t)(gridDim.x - 2) * BLOCK);
         }
         return;
     }
@@ -1096,7 +1192,7 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
         die_set_error("%s: a %dx%d world does not split into at least 3x3 whole tiles of %dx%d cells", who, m->W, m->H, TX, TY);
         return DIE_ERR_UNSUPPORTED;
     }
-    DIE_REQUIRE(p->N > 0 && p->N < ((int64_t)1 << 31), "%s: bad agent count", who);
+    DIE_REQUIRE(p->N > 0 && p->N < ((int64_t)1 << 30), "%s: bad agent count (32-bit byte offsets into the agent arrays)", who);
     for (int l = 0; l < 2; ++l) {
         const die_pic_layout& L = p->layout[l];
         DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
@@ -1241,12 +1337,22 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     P = (P + V - 1) / V * V;
     const bool stage = P <= PIC_MAX_MARGIN;
     k.margin = stage ? P : 0;
-    const int vpr_c = (TY + 2 * P) / V, vpr_f = TY / V;     // 16-byte vectors per staged row
-    k.cs_c = 0; while ((1 << k.cs_c) < vpr_c) ++k.cs_c;
-    k.cs_f = 0; while ((1 << k.cs_f) < vpr_f) ++k.cs_f;
+    // the food block: the tile ± the cells an agent can walk onto in one step (floor(reach) + 1 by the move, one more across the
+    // world's seam), columns in whole vectors
+    k.fm_r = stage ? (int)floorf(reach) + 2 : 0;
+    k.fm_c = (k.fm_r + V - 1) / V * V;
+    const int vpr_c = (TY + 2 * k.margin) / V, vpr_f = (TY + 2 * k.fm_c) / V;     // 16-byte vectors per staged row
+    k.mg_c = ((1u << 20) + (uint32_t)vpr_c - 1u) / (uint32_t)vpr_c;
+    k.mg_f = ((1u << 20) + (uint32_t)vpr_f - 1u) / (uint32_t)vpr_f;
+    if (stage) {                                            // (the multiply-shift division of PicStageRows, checked for every thread)
+        bool ok = true;
+        for (int i = 0; ok && i < PIC_K1_BLOCK; ++i) ok = (int)(((uint32_t)i * k.mg_c) >> 20) == i / vpr_c && (int)(((uint32_t)i * k.mg_f) >> 20) == i / vpr_f;
+        DIE_REQUIRE(ok && vpr_c <= 64 && vpr_f <= 64, "die_pic_forward_env_step: staged rows of %d / %d vectors", vpr_c, vpr_f);
+    }
     DIE_REQUIRE(!stage || (m->W < (1 << 23) && m->H < (1 << 23) && (int64_t)m->W * m->H < (1ll << 31)),
                 "die_pic_forward_env_step: plane too large for the 24-bit index arithmetic of the staging loop");
-    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (PIC_STAGE_FOOD ? (size_t)TX * TY : 0)) * esz : 0;
+    DIE_REQUIRE(!stage || m->H % V == 0, "die_pic_forward_env_step: plane rows must be whole 16-byte vectors");
+    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (size_t)(TX + 2 * k.fm_r) * (TY + 2 * k.fm_c)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
     // two launches (one field kernel per tile, fed by the agent kernel's rim lists) when the caller gave the lists and every
     // agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
@@ -1269,8 +1375,19 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.rim = (uint4*)p->rim; k.rim_code = p->rim_code; k.rim_cnt = p->rim_cnt; k.rim_cap = (int)die_pic_rim_cap(p->tile_xs, p->tile_ys); k.rim_r = R;
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
-    DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK && (1 << k.cs_c) <= DIE_WAVE && (1 << k.cs_f) <= DIE_WAVE,
-                "die_pic_forward_env_step: k1_threads %d", block);
+    DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK, "die_pic_forward_env_step: k1_threads %d", block);
+    // the random turn bits of this step (PhysarumAgent): a table over the slot ids, filled by the previous step's field kernel
+    // or — the first step, a changed seed, a step counter that did not advance by one — right here
+    const bool physarum = g->kind == DIE_AGENT_PHYSARUM;
+    const int64_t turn_words = (p->turn_slots + 127) / 128 * 4;
+    if (physarum) {
+        DIE_REQUIRE(p->turn_bits && p->turn_slots > 0, "die_pic_forward_env_step: turn_bits / turn_slots (a table over every slot id) missing");
+        f.turn_bits = p->turn_bits;
+        if ((stages & 1) && (!p->turn_ready || !two) && !g->turn_sign) {      // (only the two-launch form's field kernel fills it ahead)
+            const int64_t blocks = (turn_words / 4 + DIE_BLOCK - 1) / DIE_BLOCK;
+            k_turn_bits<<<(int)(blocks < 1024 ? blocks : 1024), DIE_BLOCK, 0, s>>>(p->turn_bits, turn_words, g->seed, g->step);
+        }
+    }
     if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s); \
                                        else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s); } while (0)
@@ -1299,6 +1416,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             a.food_infinite = d->food_infinite; a.keep = (float)(1.0 - (double)d->rate_decay_chem);
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
             a.result = result; a.alive_const = p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
+            a.turn_bits = physarum && !g->turn_sign && k.nty > 2 ? p->turn_bits : nullptr;
+            a.turn_words = turn_words; a.turn_seed = g->seed; a.turn_step = g->step + 1u;
             if (tiled) {
                 if (m->dtype == DIE_F32) launch_resolve_diffuse_shape<float, true>(p->tile_xs, p->tile_ys, k, a, R, s);
                 else launch_resolve_diffuse_shape<__half, true>(p->tile_xs, p->tile_ys, k, a, R, s);

@@ -37,6 +37,18 @@ __host__ __device__ inline die_u32x4 die_draw(uint64_t seed, uint32_t step, uint
     return die_philox((uint32_t)slot, (uint32_t)(slot >> 32), step, stream, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
+// Random turn sign of PhysarumAgent._choose_turn (core/agent/gradient.py:183: np.random.randint(0, 2) per slot, from an
+// unseeded global generator).  One Philox block serves 128 slots: word w = slot >> 5 of the step's bit table is word
+// (w & 3) of Philox(counter = (w >> 2, 0, step, TURN), key = seed), slot's bit is bit (slot & 31) of it.  A kernel either
+// evaluates the block itself (die_turn_bit) or reads the table a generator kernel has filled (die_turn_bits_fill,
+// die_pic.hip: 1/128 of the Philox work per step) — same bits; oracle/rng.py turn_signs is the numpy twin.
+__host__ __device__ inline uint32_t die_turn_word(uint64_t seed, uint32_t step, uint32_t w) {
+    return die_philox(w >> 2, 0u, step, DIE_STREAM_TURN, (uint32_t)seed, (uint32_t)(seed >> 32)).v[w & 3u];
+}
+__host__ __device__ inline uint32_t die_turn_bit(uint64_t seed, uint32_t step, uint32_t slot) {
+    return (die_turn_word(seed, step, slot >> 5) >> (slot & 31u)) & 1u;
+}
+
 // numerator r in [0, 1000] of `random_sample().round(3)` (core/data_init.py:168-169)
 __host__ __device__ inline int die_round3_units(uint32_t bits) {
     return (int)(((uint64_t)bits * 1000ull + 0x80000000ull) >> 32);

@@ -24,6 +24,11 @@ def pick_tile(W: int, H: int, reach_cells: float, shapes=TILE_SHAPES) -> Optiona
     return None
 
 
+def lazy_ok(agent) -> bool:
+    """Does the field kernel leave the next step's turn bits behind for this agent?  (A PhysarumAgent drawing from Philox.)"""
+    return agent._kind == _lib.DIE_AGENT_PHYSARUM and agent._turn_sign is None
+
+
 class PicState:
     """`env`: a die_amd.Env, or a die_amd.dist.DistEnv in ghost-agent mode (its planes are a padded tile of the world, its agent
     arrays hold `capacity` entries of which the first `env.agents.N` are agents: the buffers here are sized by the arrays,
@@ -50,6 +55,11 @@ class PicState:
         self._n_agents = int(env.agents.N)
         # three-launch form only (else allocated when a step turns out to need it: a long step on small tiles)
         self._dep_plane = None if self.fused else torch.empty((W, H), dtype=torch.float32, device=dev)
+        # PhysarumAgent's random turn bits, one per slot id (include/die_hip.h `die_pic.turn_bits`); `_turn_for`: the (seed, step)
+        # whose bits the table holds — a step's field kernel leaves the next step's behind
+        self.turn_slots = max(N, int(getattr(env, 'world_agents', 0) or 0))
+        self.turn_bits = torch.zeros(4 * ((self.turn_slots + 127) // 128), dtype=torch.int32, device=dev)
+        self._turn_for = None
         self.part = torch.zeros(2 * self.NT, dtype=torch.int64, device=dev)       # reward partials | owned agents (decomposed tiles)
         self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
@@ -88,7 +98,7 @@ class PicState:
             lay[1 - cur] = self._layout(ot, self.meta[1 - cur])
             p = self._structs[key] = _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane),
                                               _ptr(self.part), _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code),
-                                              _ptr(self.rim_cnt), status_out)
+                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0)
         L = p.layout
         L[cur].slot, L[1 - cur].slot = ct[3].data_ptr(), ot[3].data_ptr()
         p.N, p.k1_threads, p.stages, p.status_out = self._n_agents, self.k1_threads, stages, status_out
@@ -163,7 +173,7 @@ class PicState:
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None, None, 0, 0, 0)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),
@@ -187,8 +197,11 @@ class PicState:
         m = env.medium.c_struct(need_owner=False)
         u = None if lazy else C.byref(action.raw_struct())
         two = self.two_launch(env, agent)
+        g = action.g_struct
+        turn_key = (int(g.seed), int(g.step))
         for i, stages in enumerate((0,) if events is None else ((1, 2) if two else (1, 2, 4))):
             p = self._struct(self.held, out, stages, status_out if two else None)
+            p.turn_ready = int(self._turn_for == turn_key)
             if events is not None:
                 events[i].record()
             rc = _lib.lib.die_pic_forward_env_step(C.byref(m), C.byref(p), self.cur, C.byref(action.g_struct), u, C.byref(dyn),
@@ -197,6 +210,8 @@ class PicState:
                 return rc
         if events is not None:
             events[2 if two else 3].record()
+        # (the field kernel of the two-launch form has filled the table for the next step of this seed)
+        self._turn_for = (turn_key[0], (turn_key[1] + 1) & 0xFFFFFFFF) if two and lazy_ok(agent) else None
         self.cur = 1 - self.cur
         self.steps_since_check += 1
         self._adopt(env, agent, out)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 18
+#define DIE_ABI_VERSION 19
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -413,6 +413,14 @@ typedef struct die_pic {
     int64_t* status_out;         /* two-launch form, may be NULL: the step copies *error here next to writing `result` — a caller that
                                     places it behind its die_step_result reads reward, num_alive and the error word in ONE copy (both
                                     may be device-visible pinned host memory: one thread writes the three words with plain stores) */
+    /* PhysarumAgent's random turn (core/agent/gradient.py:183) on this path: one bit per slot id from a table the library
+     * fills, one Philox block per 128 slots (same bits as the stand-alone forward evaluates per agent: csrc/die_rng.h
+     * die_turn_word).  The field kernel of a step fills it for (g->seed, g->step + 1); a caller that steps with the same
+     * seed and consecutive g->step sets turn_ready = 1 from the second step on, else the step fills the table first. */
+    uint32_t* turn_bits;         /* 4 * ceil(turn_slots / 128) words */
+    int64_t turn_slots;          /* slot ids are < turn_slots (>= N; a decomposed world: the world's slot count) */
+    int32_t turn_ready;          /* the table already holds the bits of (g->seed, g->step) */
+    int32_t reserved3;
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */

@@ -12,7 +12,7 @@ function is written in HIP in die_amd/csrc/die_rng.h; `tests/test_rng.py` pins t
 numpy version with the published Random123 known-answer vectors.
 
 Streams (the 4th counter word):
-  STREAM_TURN      per-slot random turn sign of PhysarumAgent._choose_turn
+  STREAM_TURN      per-slot random turn sign of PhysarumAgent._choose_turn (one block of 128 bits per 128 slots: turn_bits)
   STREAM_BROWNIAN  three rounded uniforms of BrownianAgent.forward
   STREAM_NOISE     two normals N(0, .4) of GradientAgent._get_some_noise
   STREAM_INIT_*    synthetic initial fields / agents / headings (data_init)
@@ -62,9 +62,19 @@ def _draw(seed, step, slot, stream):
 def turn_signs(seed: int, step: int, n: int, slots=None) -> np.ndarray:
     """±1 per slot; stands in for `(np.random.randint(0, 2, n) - 0.5) * 2`
     (core/agent/gradient.py:183)."""
-    slots = np.arange(n, dtype=np.uint64) if slots is None else slots
-    r0 = _draw(seed, step, slots, STREAM_TURN)[0]
-    return np.where(r0 & np.uint32(1), 1.0, -1.0)
+    slots = np.arange(n, dtype=np.uint64) if slots is None else np.asarray(slots, dtype=np.uint64)
+    return np.where(turn_bits(seed, step, slots), 1.0, -1.0)
+
+
+def turn_bits(seed: int, step: int, slots: np.ndarray) -> np.ndarray:
+    """The random turn bit of each slot id.  One Philox block serves 128 slots (die_amd/csrc/die_rng.h die_turn_word): word
+    w = slot >> 5 of the step's bit table is word (w & 3) of Philox(counter = (w >> 2, 0, step, STREAM_TURN), key = seed);
+    the slot's bit is bit (slot & 31) of it."""
+    slots = np.asarray(slots, dtype=np.uint64)
+    w = slots >> np.uint64(5)
+    r = philox4x32_10(w >> np.uint64(2), 0, np.uint64(step & 0xFFFFFFFF), np.uint64(STREAM_TURN), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    words = np.choose((w & np.uint64(3)).astype(np.int64), [r[0], r[1], r[2], r[3]])
+    return ((words >> (slots & np.uint64(31)).astype(np.uint32)) & np.uint32(1)).astype(bool)
 
 
 def round3_units(bits: np.ndarray) -> np.ndarray:
