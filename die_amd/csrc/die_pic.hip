@@ -309,7 +309,7 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 // Diagnostic build only (-DPIC_STAMPS; scratch/pic_stamps.py): s_memtime at the phase boundaries of K1, written by lane 0
 // of wave 0 behind the error word (the caller allocates 2 + 32·tiles words: 16 64-bit stamps per tile, [0, 8) the agent
 // kernel's, [8, 16) the field kernel's).  No stamp executes in the shipped kernel.
-#ifdef PIC_STAMPS
+#if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
 #define PIC_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
                           ((unsigned long long*)(p.error + 2))[(size_t)tile * 16 + (k)] = t_; } } while (0)
 #else
@@ -615,6 +615,533 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         p.out.s[tile] = nfront;
         if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
     }
+}
+
+// ---- the agent kernel as ONE persistent workgroup per CU (two-launch form, 64×64 tiles, PhysarumAgent) ---------------------------
+// k_pic_forward_move above lives 24 000 cycles per tile of which 10 000 compute: the rest is a chain of four memory round
+// trips (per-tile words → agent streams and candidate arrivals → the arrivals' records → stores) that its three workgroups per
+// CU cannot overlap, and cutting a sixth of its instructions changed nothing (round 4: 81.6 vs 80.7 µs).  Here the chain runs
+// AHEAD of the arithmetic: a workgroup of 16 waves walks over its tiles t_0, t_1, … (tile = blockIdx.x + k·gridDim.x);
+// 4 LOADER waves (one per SIMD) move everything a tile needs into LDS by LDS-DMA (global_load_lds: no staging registers, no
+// ds_write pass) one to three tiles ahead, 12 COMPUTE waves read LDS only and store the results.  In iteration k:
+//     loaders   chem window ± probe reach and food block of t_{k+1}        (16-byte DMA, two buffers)
+//               the six streams of t_{k+1}'s stayers                        (4-byte DMA, two buffers)
+//               (x, y) of the candidate arrivals of t_{k+2}                 (three buffers; needs the per-tile words of t_{k+2})
+//               the per-tile words of t_{k+3}                               (ring of four)
+//               filter of t_{k+1}'s candidates (landed during iteration k − 1) → list → the hits' records (gather DMA)
+//               flush of t_{k−1}'s counters (arrival counts, rim codes, reward partial, stayers)
+//     compute   one chunk of 64 agents of t_k per wave (stayers, then arrivals) — forward, move, feeding, positions, stores —
+//               exactly the arithmetic and the outputs of k_pic_forward_move
+//   ONE workgroup barrier per tile; every loader drains its DMAs (s_waitcnt vmcnt(0)) before it, the compute waves never wait
+//   for memory (their stores are fire-and-forget, they issue no loads).  Tiles that exceed the staged capacities (640 stayers,
+//   512 candidates, 128 arrivals: crowds) finish with passes that load directly — slower, same results.
+#define PA_WAVES 16
+#define PA_LOADERS 4
+#define PA_CW (PA_WAVES - PA_LOADERS)
+#define PA_SCAP 640
+#define PA_CCAP 512
+#define PA_ACAP 128
+#define PA_MWORDS 32            // per-tile words of a tile's neighbourhood: off[9], s[9], n[9] (own tile first, then the ring), out.off, out.n
+
+struct PaTileIn {               // what the loaders leave for the compute waves of a tile
+    uint32_t tile, own, ncand, nh, cstop, obase, on, base0;
+    int32_t tx, ty;
+    uint32_t base[9], pre[10];
+    uint32_t pad;
+};
+struct PaTileAcc {              // what the compute waves leave for the flush
+    unsigned long long cnt;     // stayers | leavers << 21 | rim entries << 42
+    uint32_t inc[9];
+    uint32_t alv[PA_CW];
+    uint32_t pad;
+    long long gain[PA_CW];
+    uint8_t rimc[PIC_RIM_CAP_MAX];
+};
+static_assert(sizeof(PaTileIn) % 8 == 0 && sizeof(PaTileAcc) % 8 == 0, "LDS carve-up of k_pic_agents");
+
+struct PaLds {                  // byte offsets into the dynamic LDS block (host: pa_lds_layout)
+    uint32_t w[2], s[2], c[3], a[2], mr, tin, tacc, ranges, total;
+    uint32_t food_off;          // food block inside a w buffer
+};
+
+#ifdef PIC_STAMPS
+#define PA_STAMP(k, tile_) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                                 ((unsigned long long*)(p.error + 2))[(size_t)(tile_) * 16 + (k)] = t_; } } while (0)
+#else
+#define PA_STAMP(k, tile_) do { } while (0)
+#endif
+#define PA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PA_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef const void __attribute__((address_space(1)))* pa_gptr;
+typedef void __attribute__((address_space(3)))* pa_lptr;
+__device__ __forceinline__ void pa_dma16(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 16, 0, 0); }
+__device__ __forceinline__ void pa_dma4(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 4, 0, 0); }
+__device__ __forceinline__ uint32_t pa_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// per-tile words of `tile`'s neighbourhood → LDS (one DMA instruction, lanes 0..28)
+__device__ __forceinline__ void pa_meta_issue(const PicArgs& p, int tile, uint32_t* mr_slot, int lane) {
+    const int tx = tile / p.nty, ty = tile - tx * p.nty;
+    if (lane < 29) {
+        const uint32_t* src;
+        if (lane < 27) {
+            const int which = lane / 9, q = lane - which * 9;
+            const int k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
+            const int t = pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty);
+            src = (which == 0 ? p.in.off : (which == 1 ? p.in.s : p.in.n)) + t;
+        } else {
+            src = (lane == 27 ? p.out.off : p.out.n) + tile;
+        }
+        pa_dma4(src, mr_slot);
+    }
+}
+// base[r] = first array index of range r, pre[r] = exclusive prefix of the lengths ([0] own stayers, [1..8] the ring's leavers)
+__device__ __forceinline__ void pa_ranges(const uint32_t* mr_slot, uint32_t* base, uint32_t* pre, int lane) {
+    uint32_t len = 0;
+    if (lane < 9) {
+        const uint32_t o = mr_slot[lane], st = mr_slot[9 + lane], n = mr_slot[18 + lane];
+        base[lane] = lane == 0 ? o : o + st;
+        len = st > n ? 0u : (lane == 0 ? st : n - st);              // (s > n: broken bookkeeping — never loop over garbage)
+    }
+    uint32_t run = len;                                             // inclusive scan over lanes 0..8 (wave shuffles)
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) { const uint32_t v = __shfl_up(run, o, DIE_WAVE); if (lane >= o) run += v; }
+    if (lane < 9) pre[lane + 1] = run;
+    if (lane == 0) pre[0] = 0;
+}
+
+template <typename T, bool TILED>
+__global__ __launch_bounds__(PA_WAVES * DIE_WAVE, 4) void k_pic_agents(FwdArgs f, PicArgs p, PaLds L) {
+    f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
+    f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
+    f.g = p.g;
+    struct KArgs { FwdArgs f; PicArgs p; };
+    const volatile KArgs __attribute__((address_space(4)))* ka = (const volatile KArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
+    extern __shared__ __align__(16) unsigned char pic_smem[];
+    constexpr int XS = 6, YS = 6, TX = 1 << XS, TY = 1 << YS, SV = 16 / (int)sizeof(T);
+    const int lane = threadIdx.x & (DIE_WAVE - 1), wave = (int)pa_uni(threadIdx.x / DIE_WAVE);
+    const int NT = p.ntx * p.nty, G = (int)gridDim.x, bid = (int)blockIdx.x;
+    const int nk = bid < NT ? (NT - bid + G - 1) / G : 0;            // tiles of this workgroup: bid, bid + G, …
+    const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P, vpr_c = pitch / SV;
+    const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR, vpr_f = fpitch / SV;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t* mr = (uint32_t*)(pic_smem + L.mr);
+    PaTileIn* tin = (PaTileIn*)(pic_smem + L.tin);
+    PaTileAcc* tacc = (PaTileAcc*)(pic_smem + L.tacc);
+    if (threadIdx.x < 2 * sizeof(PaTileAcc) / 4) ((uint32_t*)tacc)[threadIdx.x] = 0u;
+    if (nk == 0) return;
+
+    // ---------------------------------------------------------------- loaders' work items
+    // A wave issues an instruction every 5–8 cycles, so a loader's budget per tile is a few hundred instructions: everything
+    // below is shaped for few instructions per DMA (first cut: 40 per DMA, 16 000 cycles per tile — stamps, round 4).
+    // The chem window and food block of `tile` → w buffer `b`, waves 1..3.  The image of a block is the same for every tile:
+    // instruction q of a wave copies vectors q·64 .. q·64 + 63, lane l the vector at (row, column vector) = divmod(q·64 + l,
+    // vectors per row).  Each lane keeps that vector's offset from the block's first element for its (up to) PA_NWC + PA_NWF
+    // instructions in registers; for a tile whose blocks lie inside the planes a DMA is then one scalar base + that offset.
+    // Tiles at the planes' edge (6 % at 4096²) recompute every vector's address with the clamp / the periodic wrap.
+    const int nvc = rows * vpr_c, nvf = frows * vpr_f;
+    // one block (chem window: wave 2; food block: wave 3) of `tile` → w buffer `b`
+    auto issue_block = [&](const T* plane, int gx0, int gy0, int nv, int vpr, uint32_t mg, bool wrap, unsigned char* dst) {
+        const bool inside = gx0 >= 0 && gx0 + nv / vpr <= p.g.W && gy0 >= 0 && gy0 + vpr * SV <= p.g.H;
+        if (inside) {
+            const char* base = (const char*)(plane + ((int64_t)gx0 * p.g.H + gy0));
+            const int full = nv / DIE_WAVE;
+            int i = lane;
+            for (int q = 0; q < full; ++q, i += DIE_WAVE, dst += DIE_WAVE * 16) {
+                const int row = (int)(((uint32_t)i * mg) >> 20), cv = i - row * vpr;
+                pa_dma16(base + (size_t)((uint32_t)(row * p.g.H + cv * SV) * (uint32_t)sizeof(T)), dst);
+            }
+            if (i < nv) {
+                const int row = (int)(((uint32_t)i * mg) >> 20), cv = i - row * vpr;
+                pa_dma16(base + (size_t)((uint32_t)(row * p.g.H + cv * SV) * (uint32_t)sizeof(T)), dst);
+            }
+        } else {
+            for (int q = 0; q * DIE_WAVE < nv; ++q) {
+                const int i = q * DIE_WAVE + lane;
+                if (i < nv) {
+                    const int row = (int)(((uint32_t)i * mg) >> 20), cv = i - row * vpr;
+                    int gx = gx0 + row, gy = gy0 + cv * SV;
+                    if (wrap) {
+                        gx += gx < 0 ? p.g.W : 0; gx -= gx >= p.g.W ? p.g.W : 0;
+                        gy += gy < 0 ? p.g.H : 0; gy -= gy >= p.g.H ? p.g.H : 0;
+                    } else {
+                        gx = min(max(gx, 0), p.g.W - 1); gy = min(max(gy, 0), p.g.H - SV);
+                    }
+                    pa_dma16(plane + (__mul24(gx, p.g.H) + gy), dst + (size_t)q * DIE_WAVE * 16);
+                }
+            }
+        }
+    };
+    auto issue_window = [&](int tile, int b) {                     // waves 2 (chem) and 3 (food)
+        const int tx = tile / p.nty, ty = tile - tx * p.nty, x0 = tx << XS, y0 = ty << YS;
+        unsigned char* wb = pic_smem + L.w[b];
+        if (wave == 2) issue_block((const T*)f.chem, x0 - P, y0 - P, nvc, vpr_c, p.mg_c, false, wb);
+        else issue_block((const T*)p.food, x0 - FR, y0 - FC, nvf, vpr_f, p.mg_f, true, wb + L.food_off);
+    };
+    // the six streams of the tile's first PA_SCAP stayers → s buffer `b`: wave 2 takes x, y, slot, wave 3 the heading halves and
+    // agent_food.  16-byte DMAs — four agents per lane, 256 per instruction: an LDS-DMA costs its wave ≈ 110 cycles whatever its
+    // width (stamps, round 4), and its SOURCE needs no more than 4-byte alignment (scratch/kbench_dma/dma_unaligned.hip) — and one
+    // 4-byte DMA for the last own % 4 agents (a vector must not read past the end of the arrays).
+    auto issue_stayers = [&](const uint32_t* mr_slot, int b) {
+        const uint32_t o = pa_uni(mr_slot[0]), st = pa_uni(mr_slot[9]), n = pa_uni(mr_slot[18]);
+        const uint32_t own = st > n ? 0u : min(st, (uint32_t)PA_SCAP), nvec = own >> 2, tail = own & 3u;
+        const char *a0, *a1, *a2;
+        if (wave == 2) { a0 = (const char*)p.in.x; a1 = (const char*)p.in.y; a2 = (const char*)p.in.slot; }
+        else { a0 = (const char*)p.in.hhi; a1 = (const char*)p.in.hlo; a2 = (const char*)p.in.agent_food; }
+        unsigned char* d0 = pic_smem + L.s[b] + (size_t)(3 * (wave - 2)) * PA_SCAP * 4;
+        uint32_t voff = (o + 4u * (uint32_t)lane) << 2;
+        for (uint32_t v0 = 0; v0 < nvec; v0 += DIE_WAVE, voff += DIE_WAVE * 16, d0 += DIE_WAVE * 16) {
+            if (v0 + (uint32_t)lane < nvec) {
+                pa_dma16(a0 + (size_t)voff, d0);
+                pa_dma16(a1 + (size_t)voff, d0 + PA_SCAP * 4);
+                pa_dma16(a2 + (size_t)voff, d0 + 2 * PA_SCAP * 4);
+            }
+        }
+        if (tail && (uint32_t)lane < tail) {
+            const uint32_t toff = (o + 4u * nvec + (uint32_t)lane) << 2;
+            unsigned char* dt = pic_smem + L.s[b] + (size_t)(3 * (wave - 2)) * PA_SCAP * 4 + (size_t)nvec * 16;
+            pa_dma4(a0 + (size_t)toff, dt);
+            pa_dma4(a1 + (size_t)toff, dt + PA_SCAP * 4);
+            pa_dma4(a2 + (size_t)toff, dt + 2 * PA_SCAP * 4);
+        }
+    };
+    // a candidate arrival's array index from its running number c: the leavers of the 8 ring tiles follow one another;
+    // pre[1..9] in scalar registers → 8 compares, no LDS search loop (that loop was 3 000 cycles per tile)
+    struct PaRanges { uint32_t own, ncand; uint32_t pre[10], adj[9]; };      // adj[r] = base[r] − pre[r]
+    auto load_ranges = [&](const uint32_t* mr_slot, PaRanges& R) {
+        uint32_t len = 0, bs = 0;
+        if (lane < 9) {
+            const uint32_t o = mr_slot[lane], st = mr_slot[9 + lane], n = mr_slot[18 + lane];
+            bs = lane == 0 ? o : o + st;
+            len = st > n ? 0u : (lane == 0 ? st : n - st);            // (s > n: broken bookkeeping — never loop over garbage)
+        }
+        uint32_t run = len;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { const uint32_t v = __shfl_up(run, o, DIE_WAVE); if (lane >= o) run += v; }
+        R.pre[0] = 0;
+#pragma unroll
+        for (int r = 0; r < 9; ++r) {
+            R.pre[r + 1] = (uint32_t)__builtin_amdgcn_readlane((int)run, r);
+            R.adj[r] = (uint32_t)__builtin_amdgcn_readlane((int)bs, r) - R.pre[r];
+        }
+        R.own = R.pre[1];
+        R.ncand = R.pre[9] - R.own;
+    };
+    auto cand_index = [&](const PaRanges& R, uint32_t c) {               // c < ncand
+        const uint32_t idx = R.own + c;
+        uint32_t adj = R.adj[1];
+#pragma unroll
+        for (int r = 2; r < 9; ++r) adj = idx >= R.pre[r] ? R.adj[r] : adj;
+        return idx + adj;
+    };
+    // (x, y) and the array index of the tile's first PA_CCAP candidate arrivals → c buffer `b` (wave 1)
+    auto issue_candidates = [&](const uint32_t* mr_slot, int b) {
+        PaRanges R;
+        load_ranges(mr_slot, R);
+        const uint32_t ncand = min(R.ncand, (uint32_t)PA_CCAP);
+        unsigned char* cb = pic_smem + L.c[b];
+        for (uint32_t c0 = 0; c0 < ncand; c0 += DIE_WAVE) {
+            const uint32_t c = c0 + lane;
+            if (c < ncand) {
+                const uint32_t j = cand_index(R, c);
+                ((uint32_t*)cb)[2 * PA_CCAP + c] = j;
+                pa_dma4((const char*)p.in.x + (size_t)(uint32_t)(j << 2), cb + (size_t)c0 * 4);
+                pa_dma4((const char*)p.in.y + (size_t)(uint32_t)(j << 2), cb + ((size_t)PA_CCAP + c0) * 4);
+            }
+        }
+    };
+    // wave 0: which of the staged candidates stand on the tile → the hits' array indices (stream 6 of a buffer `ab`) and their
+    // six streams (gather DMA); the tile's words for the compute waves
+    auto filter_tile = [&](int tile, const uint32_t* mr_slot, int cbuf, int ab, PaTileIn* ti) {
+        PaRanges R;
+        load_ranges(mr_slot, R);
+        const uint32_t own = R.own, ncand = R.ncand, nscan = min(ncand, (uint32_t)PA_CCAP);
+        const uint32_t* cx_ = (const uint32_t*)(pic_smem + L.c[cbuf]);
+        uint32_t* al = (uint32_t*)(pic_smem + L.a[ab]);
+        const int tx = tile / p.nty, ty = tile - tx * p.nty;
+        uint32_t nh = 0, cstop = nscan;
+        for (uint32_t c0 = 0; c0 < nscan; c0 += DIE_WAVE) {
+            const uint32_t c = c0 + lane;
+            bool hit = false;
+            uint32_t j = 0;
+            if (c < nscan) {
+                j = cx_[2 * PA_CCAP + c];
+                hit = (pic_row<TILED>(p.g, cx_[c]) >> XS) == tx && (pic_col<TILED>(p.g, cx_[PA_CCAP + c]) >> YS) == ty;
+            }
+            const unsigned long long m = __ballot(hit);
+            const uint32_t cm = (uint32_t)__popcll(m);
+            if (nh + cm > (uint32_t)PA_ACAP) { cstop = c0; break; }           // (wave-uniform) the rest: the compute waves' direct pass
+            if (hit) al[6 * PA_ACAP + nh + (uint32_t)__popcll(m & below)] = j;
+            nh += cm;
+        }
+        // the tile's words for the compute waves (ranges: for their direct passes over crowds)
+#pragma unroll
+        for (int r = 0; r < 9; ++r) if (lane == r) { ti->base[r] = R.adj[r] + R.pre[r]; ti->pre[r] = R.pre[r]; }
+        if (lane == 0) {
+            ti->pre[9] = R.pre[9];
+            ti->tile = (uint32_t)tile; ti->own = own; ti->ncand = ncand; ti->nh = nh; ti->cstop = cstop;
+            ti->obase = mr_slot[27]; ti->on = mr_slot[28]; ti->base0 = mr_slot[0];
+            ti->tx = tx; ti->ty = ty;
+        }
+        for (uint32_t h0 = 0; h0 < nh; h0 += DIE_WAVE) {
+            const uint32_t h = h0 + lane;
+            if (h < nh) {
+                const size_t jo = (size_t)(uint32_t)(al[6 * PA_ACAP + h] << 2);
+                pa_dma4((const char*)p.in.x + jo, al + h0);
+                pa_dma4((const char*)p.in.y + jo, al + PA_ACAP + h0);
+                pa_dma4((const char*)p.in.slot + jo, al + 2 * PA_ACAP + h0);
+                pa_dma4((const char*)p.in.hhi + jo, al + 3 * PA_ACAP + h0);
+                pa_dma4((const char*)p.in.hlo + jo, al + 4 * PA_ACAP + h0);
+                pa_dma4((const char*)p.in.agent_food + jo, al + 5 * PA_ACAP + h0);
+            }
+        }
+    };
+    // wave 0: a finished tile's counters → global memory (what k_pic_forward_move does behind its last barrier); reset
+    auto flush_tile = [&](const PaTileIn* ti, PaTileAcc* ta) {
+        const int tile = (int)pa_uni(ti->tile), tx = (int)pa_uni((uint32_t)ti->tx), ty = (int)pa_uni((uint32_t)ti->ty);
+        const uint32_t on = pa_uni(ti->on);
+        const unsigned long long cnt = ta->cnt;
+        if (lane < 9 && ta->inc[lane]) {
+            const int ddx = lane / 3 - 1, ddy = lane % 3 - 1;
+            atomicAdd(&p.out.inc[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], ta->inc[lane]);
+        }
+        const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(cnt >> 42) & 0x1FFFFFu;
+        for (uint32_t i = lane; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += DIE_WAVE)
+            ((uint32_t*)p.rim_code)[((size_t)tile * p.rim_cap) / 4 + i] = ((const uint32_t*)ta->rimc)[i];
+        if (lane == 0) {
+            p.rim_cnt[tile] = nr;
+            long long t = 0;
+            for (int i = 0; i < PA_CW; ++i) t += ta->gain[i];
+            p.part_gain[tile] = t;
+            if (TILED) {
+                long long c = 0;
+                for (int i = 0; i < PA_CW; ++i) c += ta->alv[i];
+                p.part_gain[(size_t)NT + tile] = c;
+            }
+            const uint32_t nfront = (uint32_t)cnt & 0x1FFFFFu, nback = (uint32_t)(cnt >> 21) & 0x1FFFFFu;
+            p.out.s[tile] = nfront;
+            if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
+            ta->cnt = 0ull;
+        }
+        if (lane < 9) ta->inc[lane] = 0u;
+    };
+
+#ifndef PA_LOADER_PRIO
+#define PA_LOADER_PRIO 3
+#endif
+    // the loaders are the critical path of an iteration (four waves against twelve): they win the issue arbitration
+    if (wave < PA_LOADERS && PA_LOADER_PRIO) __builtin_amdgcn_s_setprio(PA_LOADER_PRIO);
+    // ---------------------------------------------------------------- prologue: fill the pipeline
+    if (wave == 1) {
+        for (int d = 0; d < 3 && d < nk; ++d) pa_meta_issue(p, bid + d * G, mr + (d & 3) * PA_MWORDS, lane);
+        PA_WAIT_VM();
+    }
+    PA_BARRIER();
+    if (wave == 1) {
+        issue_candidates(mr, 0);
+        if (nk > 1) issue_candidates(mr + PA_MWORDS, 1);
+    }
+    if (wave == 2 || wave == 3) {
+        issue_window(bid, 0);
+        issue_stayers(mr, 0);
+    }
+    if (wave < PA_LOADERS) PA_WAIT_VM();
+    PA_BARRIER();
+    if (wave == 0) {
+        filter_tile(bid, mr, 0, 0, &tin[0]);
+        PA_WAIT_VM();
+    }
+    PA_BARRIER();
+
+    // ---------------------------------------------------------------- the tiles
+    // roles of the loaders in iteration k — wave 0: which candidates of t_{k+1} arrive, their records (a chain of LDS reads and
+    // ballots, then gathers); wave 1: (x, y) of t_{k+2}'s candidates, per-tile words of t_{k+3}; wave 2: chem window and half the
+    // stayers' streams of t_{k+1}; wave 3: counters of t_{k−1} to memory, food block and the other streams of t_{k+1}.  Waves 2
+    // and 3 run at the rate memory delivers (every CU pulls its windows at the same time), 0 and 1 at their instruction rate.
+    for (int k = 0; k < nk; ++k) {
+        const int b = k & 1;
+        [[maybe_unused]] const int stile = bid + k * G;
+        if (wave < PA_LOADERS) {
+            if (wave == 0) {
+                PA_STAMP(0, stile);
+                if (k + 1 < nk) filter_tile(bid + (k + 1) * G, mr + ((k + 1) & 3) * PA_MWORDS, (k + 1) % 3, b ^ 1, &tin[(k + 1) % 3]);
+                PA_STAMP(2, stile);
+            } else if (wave == 1) {
+                if (k + 2 < nk) issue_candidates(mr + ((k + 2) & 3) * PA_MWORDS, (k + 2) % 3);
+                if (k + 3 < nk) pa_meta_issue(p, bid + (k + 3) * G, mr + ((k + 3) & 3) * PA_MWORDS, lane);
+                PA_STAMP(4, stile);
+            } else {
+                if (wave == 3 && k >= 1) flush_tile(&tin[(k - 1) % 3], &tacc[b ^ 1]);
+                if (wave == 3) PA_STAMP(1, stile);
+                if (k + 1 < nk) {
+                    issue_window(bid + (k + 1) * G, b ^ 1);
+                    if (wave == 2) PA_STAMP(5, stile);
+                    issue_stayers(mr + ((k + 1) & 3) * PA_MWORDS, b ^ 1);
+                }
+                if (wave == 2) PA_STAMP(6, stile);
+            }
+            PA_WAIT_VM();
+            if (wave == 0) PA_STAMP(3, stile);
+            if (wave == 2) PA_STAMP(7, stile);
+        } else {
+            // ------------------------------------------------------------ compute waves: tile t_k from LDS
+            const int cw = wave - PA_LOADERS;
+            const PaTileIn* ti = &tin[k % 3];
+            PaTileAcc* ta = &tacc[b];
+            const int tile = (int)pa_uni(ti->tile), tx = (int)pa_uni((uint32_t)ti->tx), ty = (int)pa_uni((uint32_t)ti->ty);
+            const uint32_t own = pa_uni(ti->own), ncand = pa_uni(ti->ncand), nh = pa_uni(ti->nh), cstop = pa_uni(ti->cstop);
+            const uint32_t obase = pa_uni(ti->obase), on = pa_uni(ti->on), base0 = pa_uni(ti->base0);
+            const int x0 = tx << XS, y0 = ty << YS;
+            const uint32_t sown = min(own, (uint32_t)PA_SCAP), nmain_agents = sown + nh;
+            const uint32_t n_main = (nmain_agents + DIE_WAVE - 1) / DIE_WAVE;
+            const uint32_t n_ovs = (own - sown + DIE_WAVE - 1) / DIE_WAVE;
+            const uint32_t n_ovc = (ncand - cstop + DIE_WAVE - 1) / DIE_WAVE;
+            const uint32_t* sb = (const uint32_t*)(pic_smem + L.s[b]);
+            const uint32_t* ab = (const uint32_t*)(pic_smem + L.a[b]);
+            FwdTileMem<T, TILED> tm;
+            tm.g = p.g;
+            T* s_chem = (T*)(pic_smem + L.w[b]);
+            T* s_food = (T*)(pic_smem + L.w[b] + L.food_off);
+            tm.food = s_food; tm.fx0 = x0 - FR; tm.fy0 = y0 - FC; tm.fpitch = fpitch;
+            tm.chem = s_chem; tm.cx0 = x0 - P; tm.cy0 = y0 - P; tm.pitch = pitch;
+            long long gsum = 0;
+            uint32_t nowned = 0;
+            for (uint32_t item = (uint32_t)cw; item < n_main + n_ovs + n_ovc; item += PA_CW) {
+                bool act = false;
+                uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0, j = 0;
+                float af = 0.f;
+                if (item < n_main) {                                 // staged: stayers, then arrivals
+                    const uint32_t idx = item * DIE_WAVE + lane;
+                    act = idx < nmain_agents;
+                    if (act) {
+                        if (idx < sown) {
+                            X = sb[idx]; Y = sb[PA_SCAP + idx]; sid = sb[2 * PA_SCAP + idx]; hh = sb[3 * PA_SCAP + idx]; hl = sb[4 * PA_SCAP + idx];
+                            af = __uint_as_float(sb[5 * PA_SCAP + idx]);
+                            j = base0 + idx;
+                        } else {
+                            const uint32_t a = idx - sown;
+                            X = ab[a]; Y = ab[PA_ACAP + a]; sid = ab[2 * PA_ACAP + a]; hh = ab[3 * PA_ACAP + a]; hl = ab[4 * PA_ACAP + a];
+                            af = __uint_as_float(ab[5 * PA_ACAP + a]);
+                            j = ab[6 * PA_ACAP + a];
+                        }
+                    }
+                } else {                                             // crowds: beyond the staged capacities, loaded directly
+                    const uint32_t *ix_ = (const uint32_t*)ka->p.in.x, *iy_ = (const uint32_t*)ka->p.in.y, *is_ = (const uint32_t*)ka->p.in.slot;
+                    const uint32_t *ihh_ = (const uint32_t*)ka->p.in.hhi, *ihl_ = (const uint32_t*)ka->p.in.hlo;
+                    const float* ia_ = (const float*)ka->p.in.agent_food;
+                    if (item < n_main + n_ovs) {
+                        const uint32_t idx = (uint32_t)PA_SCAP + (item - n_main) * DIE_WAVE + lane;
+                        act = idx < own;
+                        j = base0 + idx;
+                        if (act) { X = PIC_AT(ix_, const uint32_t, j); Y = PIC_AT(iy_, const uint32_t, j); }
+                    } else {
+                        const uint32_t c = cstop + (item - n_main - n_ovs) * DIE_WAVE + lane;
+                        if (c < ncand) {
+                            const uint32_t idx = own + c;
+                            int r = 1;
+                            while (idx >= ti->pre[r + 1]) ++r;
+                            j = ti->base[r] + (idx - ti->pre[r]);
+                            X = PIC_AT(ix_, const uint32_t, j); Y = PIC_AT(iy_, const uint32_t, j);
+                            act = pic_tile_of<TILED>(p, X, Y) == tile;
+                        }
+                    }
+                    if (act) {
+                        sid = PIC_AT(is_, const uint32_t, j); hh = PIC_AT(ihh_, const uint32_t, j); hl = PIC_AT(ihl_, const uint32_t, j);
+                        af = PIC_AT(ia_, const float, j);
+                    }
+                }
+                bool stay = false, listed = false;
+                float dep = 0.f;
+                double hd = 0.0;
+                uint32_t code = 0;
+                if (act) {
+                    hd = __hiloint2double((int)hh, (int)hl);
+                    const FwdOut o = die_forward_agent_mem<T, DIE_AGENT_PHYSARUM, false, FwdTileMem<T, TILED>, true>(f, tm, X, Y, hd, sid, (int64_t)j);
+                    if (p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }
+                    // _agent_move (core/env.py:163-172)
+                    if (p.boundary == DIE_BOUNDARY_WRAP) {
+                        X += (uint32_t)die_q32_small(o.dx);
+                        Y += (uint32_t)die_q32_small(o.dy);
+                    } else {
+                        const int64_t qx = (int64_t)X + die_q32_small(o.dx), qy = (int64_t)Y + die_q32_small(o.dy);
+                        X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
+                        Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
+                    }
+                    const int gcx = die_cell_u(X, p.g.gW), gcy = die_cell_u(Y, p.g.gH);
+                    const int cx = TILED ? die_plane_coord(gcx, p.g.ox, p.g.W, p.g.gW) : gcx;
+                    const int cy = TILED ? die_plane_coord(gcy, p.g.oy, p.g.H, p.g.gH) : gcy;
+                    const int ntx_ = cx >> XS, nty_ = cy >> YS;
+                    stay = ntx_ == tx && nty_ == ty;
+                    // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption
+                    int rx = cx - x0, ry = cy - y0;
+                    rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
+                    ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
+                    rx = min(max(rx + FR, 0), frows - 1); ry = min(max(ry + FC, 0), fpitch - 1);
+                    const float fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry));
+                    const float consumed = p.rate_feed * fnew;
+                    const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
+                    const float gained = consumed - cost;
+                    af += gained;
+                    if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_fix(gained); ++nowned; }
+                    hd = o.heading;
+                    dep = o.dep;
+                    int ddx = 0, ddy = 0;
+                    if (!stay) {
+                        ddx = ntx_ - tx; ddy = nty_ - ty;
+                        ddx = ddx > 1 ? ddx - p.ntx : (ddx < -1 ? ddx + p.ntx : ddx);
+                        ddy = ddy > 1 ? ddy - p.nty : (ddy < -1 ? ddy + p.nty : ddy);
+                        if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) { atomicOr(p.error, 2u); ddx = ddy = 0; }
+                        else atomicAdd(&ta->inc[(ddx + 1) * 3 + ddy + 1], 1u);
+                    }
+                    const int lx = cx & (TX - 1), ly = cy & (TY - 1), Rr = p.rim_r;
+                    const int ex = lx < Rr ? 0 : (lx >= TX - Rr ? 2 : 1), ey = ly < Rr ? 0 : (ly >= TY - Rr ? 2 : 1);
+                    code = (uint32_t)(((ddx + 1) * 3 + ddy + 1) * 9 + ex * 3 + ey);
+                    listed = !stay || ex != 1 || ey != 1;
+                }
+                const unsigned long long m_stay = __ballot(act && stay), m_leave = __ballot(act && !stay), m_rim = __ballot(act && listed);
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&ta->cnt, (unsigned long long)__popcll(m_stay) | ((unsigned long long)__popcll(m_leave) << 21) |
+                                                          ((unsigned long long)__popcll(m_rim) << 42));
+                base = __shfl(base, 0, DIE_WAVE);
+                const uint32_t bf = (uint32_t)base & 0x1FFFFFu, bb = (uint32_t)(base >> 21) & 0x1FFFFFu, br = (uint32_t)(base >> 42) & 0x1FFFFFu;
+                const uint32_t kk = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
+                if (act && listed) {
+                    const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
+                    if (at < (uint32_t)p.rim_cap) {
+                        ta->rimc[at] = (uint8_t)code;
+                        ((uint4*)ka->p.rim)[(size_t)tile * p.rim_cap + at] = make_uint4(X, Y, sid, __float_as_uint(dep));
+                    }
+                }
+                if (act) {
+                    if (kk < on) {
+                        const uint32_t q = obase + kk;
+                        uint32_t *ox_ = (uint32_t*)ka->p.out.x, *oy_ = (uint32_t*)ka->p.out.y, *os_ = (uint32_t*)ka->p.out.slot;
+                        uint32_t *ohh_ = (uint32_t*)ka->p.out.hhi, *ohl_ = (uint32_t*)ka->p.out.hlo;
+                        float *oa_ = (float*)ka->p.out.agent_food, *od_ = (float*)ka->p.dep;
+                        PIC_AT(ox_, uint32_t, q) = X;
+                        PIC_AT(oy_, uint32_t, q) = Y;
+                        PIC_AT(oa_, float, q) = af;
+                        PIC_AT(os_, uint32_t, q) = sid;
+                        PIC_AT(ohh_, uint32_t, q) = (uint32_t)__double2hiint(hd);
+                        PIC_AT(ohl_, uint32_t, q) = (uint32_t)__double2loint(hd);
+                        PIC_AT(od_, float, q) = dep;
+                    } else {
+                        atomicOr((uint32_t*)ka->p.error, 1u);
+                    }
+                }
+            }
+            gsum = die_wave_sum(gsum);
+            if (lane == 0) ta->gain[cw] = gsum;
+            if (TILED) {
+                const long long c = die_wave_sum((long long)nowned);
+                if (lane == 0) ta->alv[cw] = (uint32_t)c;
+            }
+            if (cw == 0) PA_STAMP(8, stile);
+            if (cw == PA_CW - 1) PA_STAMP(9, stile);
+        }
+        PA_BARRIER();
+        if (wave == 0) PA_STAMP(10, stile);
+    }
+    if (wave == 0) flush_tile(&tin[(nk - 1) % 3], &tacc[(nk - 1) & 1]);
 }
 
 // The random turn bits of one step, one Philox block per 128 slot ids (die_rng.h die_turn_word): word w of the table for
@@ -1289,6 +1816,48 @@ static void launch_resolve_diffuse_shape(int xs, int ys, const PicArgs& k, const
     else launch_resolve_diffuse<T, 4, 5, TILED>(k, a, R, s);
 }
 
+static PaLds pa_lds_layout(int P, int FR, int FC, int esz) {
+    const int TX = 64, TY = 64;
+    PaLds L;
+    uint32_t at = 0;
+    auto take = [&](uint32_t bytes) { const uint32_t o = at; at += (bytes + 15u) & ~15u; return o; };
+    const uint32_t chem = (uint32_t)((TX + 2 * P) * (TY + 2 * P) * esz), food = (uint32_t)((TX + 2 * FR) * (TY + 2 * FC) * esz);
+    L.food_off = (chem + 15u) & ~15u;
+    for (int b = 0; b < 2; ++b) L.w[b] = take(L.food_off + food);
+    for (int b = 0; b < 2; ++b) L.s[b] = take(6 * PA_SCAP * 4);
+    for (int b = 0; b < 3; ++b) L.c[b] = take(3 * PA_CCAP * 4);
+    for (int b = 0; b < 2; ++b) L.a[b] = take(7 * PA_ACAP * 4);
+    L.mr = take(4 * PA_MWORDS * 4);
+    L.tin = take(3 * sizeof(PaTileIn));
+    L.tacc = take(2 * sizeof(PaTileAcc));
+    L.ranges = take(32 * 4);
+    L.total = at;
+    return L;
+}
+
+static int pa_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
+template <typename T, bool TILED>
+static int launch_agents(const FwdArgs& f, const PicArgs& k, const PaLds& L, int NT, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {          // (dynamic LDS beyond the default limit)
+        hipError_t e = hipFuncSetAttribute((const void*)k_pic_agents<T, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
+        if (e != hipSuccess) { (void)hipGetLastError(); die_set_error("die_pic_forward_env_step: %u bytes of LDS refused: %s", L.total, hipGetErrorString(e)); return DIE_ERR_HIP; }
+        attr_set = true;
+    }
+    const int cus = pa_cu_count();
+    k_pic_agents<T, TILED><<<NT < cus ? NT : cus, PA_WAVES * DIE_WAVE, L.total, s>>>(f, k, L);
+    return DIE_OK;
+}
+
 extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
                                         const die_action* act, const die_dynamics* d, die_step_result* result, void* stream) {
     int rc = pic_check(m, p, "die_pic_forward_env_step");
@@ -1374,7 +1943,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     }
     k.rim = (uint4*)p->rim; k.rim_code = p->rim_code; k.rim_cnt = p->rim_cnt; k.rim_cap = (int)die_pic_rim_cap(p->tile_xs, p->tile_ys); k.rim_r = R;
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
-    int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? PIC_K1_BLOCK : 256);
+    int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? 512 : 256);
     DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK, "die_pic_forward_env_step: k1_threads %d", block);
     // the random turn bits of this step (PhysarumAgent): a table over the slot ids, filled by the previous step's field kernel
     // or — the first step, a changed seed, a step counter that did not advance by one — right here
@@ -1388,7 +1957,24 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             k_turn_bits<<<(int)(blocks < 1024 ? blocks : 1024), DIE_BLOCK, 0, s>>>(p->turn_bits, turn_words, g->seed, g->step);
         }
     }
-    if (stages & 1) {
+    // the persistent agent kernel (k_pic_agents) when the caller asks for it (k1_threads = −1) and it applies: two-launch form,
+    // 64×64 tiles, staged windows, PhysarumAgent.  Not the default: at 4096² it takes 101 µs against 81 µs
+    bool persistent = false;
+    PaLds PL = {};
+    if (two && stage && physarum && p->tile_xs == 6 && p->tile_ys == 6 && p->k1_threads == -1) {
+        PL = pa_lds_layout(k.margin, k.fm_r, k.fm_c, esz);
+        const int nvc = (TX + 2 * k.margin) * vpr_c, nvf = (TX + 2 * k.fm_r) * vpr_f;
+        bool ok = PL.total <= 160u * 1024u && nvc < 4096 && nvf < 4096;
+        for (int i = 0; ok && i < nvc; ++i) ok = (int)(((uint32_t)i * k.mg_c) >> 20) == i / vpr_c;
+        for (int i = 0; ok && i < nvf; ++i) ok = (int)(((uint32_t)i * k.mg_f) >> 20) == i / vpr_f;
+        persistent = ok;
+    }
+    if ((stages & 1) && persistent) {
+        int rc2;
+        if (tiled) rc2 = m->dtype == DIE_F32 ? launch_agents<float, true>(f, k, PL, NT, s) : launch_agents<__half, true>(f, k, PL, NT, s);
+        else rc2 = m->dtype == DIE_F32 ? launch_agents<float, false>(f, k, PL, NT, s) : launch_agents<__half, false>(f, k, PL, NT, s);
+        if (rc2 != DIE_OK) return rc2;
+    } else if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s); \
                                        else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s); } while (0)
         if (tiled) {

@@ -447,7 +447,8 @@ class Env(_EnvBase):
         ag = action.agent
         if self._pic is None:
             self._pic = PicState(self, self._pic_tile)
-            self._pic.k1_threads = int(getattr(self, '_pic_k1_threads', 0))
+            if getattr(self, '_pic_k1_threads', 0):
+                self._pic.k1_threads = int(self._pic_k1_threads)
             self._pic.lazy_actions = bool(getattr(self, '_pic_lazy_actions', True))
         if not self._pic.is_current(self, ag):
             self._pic.bin(self, ag)

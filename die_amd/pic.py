@@ -3,6 +3,7 @@
 order (core/data_init.py:133-150); here the order of the arrays is free (results are keyed by slot id) and this path
 keeps it exactly tile-sorted so that `Env.step` needs no claim plane."""
 import ctypes as C
+import os
 import weakref
 from typing import Optional, Tuple
 
@@ -64,7 +65,7 @@ class PicState:
         self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
         self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
-        self.k1_threads = 0          # tuning knob of die_pic (0 = library default)
+        self.k1_threads = int(os.environ.get('DIE_PIC_THREADS', '0'))   # die_pic.k1_threads: 0 = library default, > 0: workgroup size of the agent kernel, -1: the persistent agent kernel where it applies
         self.cur = 0                 # layout index that holds the agents
         self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
         self._structs = {}           # die_pic structs by the device addresses of the two array sets (_struct)

@@ -397,7 +397,9 @@ typedef struct die_pic {
                                     die_medium.gW > 0) the owned agents per tile; also the binning scratch */
     uint32_t* error;             /* device word, 0 = fine; sticky bits after a step: 1 segment bookkeeping broken, 2 an agent moved
                                     further than a tile.  Never cleared by the library */
-    int32_t k1_threads;          /* tuning: workgroup size of the agent kernel (multiple of 64, <= 512); 0 = default */
+    int32_t k1_threads;          /* tuning: workgroup size of the agent kernel (multiple of 64, <= 512); 0 = default; -1 = the persistent
+                                    agent kernel (one 16-wave workgroup per CU, LDS-DMA loaders a tile ahead of the arithmetic) where it
+                                    applies — 64x64 tiles, two-launch form, PhysarumAgent —, else the default */
     int32_t stages;              /* 0 = the whole step; else a bit mask of the launches to run (per-kernel timing: bench.py):
                                     1 agent kernel (ONE issue per step: it adds to layout[1 - from].inc), 2 claim resolution +
                                     next offsets, 4 field sweep (two-launch form: the sweep is part of the kernel of bit 2) */
