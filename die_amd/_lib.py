@@ -74,7 +74,8 @@ class Pic(C.Structure):
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
-                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32)]
+                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32),
+                ('queue', C.c_void_p)]
 
 
 class PicSide(C.Structure):          # die_pic_side: one neighbour of the ghost refresh by tiles

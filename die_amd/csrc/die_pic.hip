@@ -32,6 +32,7 @@
 // read through the caches by K1 and streamed by the sweep.  The 'agents' channel (claim plane) is not maintained on this
 // path: die_agents_mark_owner materialises it when somebody asks (DeviceMedium.occupied / owner_slots / render).
 #include "die_forward.h"
+#include <stdlib.h>
 
 // (PIC_K2_FEED, PIC_K1_BLOCK, PIC_K2_BLOCK, PIC_STAGE_FOOD, PIC_K1_MINW: knobs of the A/B builds of scratch/build_variant.sh;
 // the values below are the measured best)
@@ -155,8 +156,21 @@ struct PicArgs {
     uint8_t* rim_code;
     uint32_t* rim_cnt;              // [tile]: entries the tile had (may exceed rim_cap: the reader then scans the segment)
     int rim_cap, rim_r;             // gaussian radius R = width of the rim
+    uint32_t* queue;                // PERSIST: [0] next tile to hand out, [1] workgroups that have finished (both 0 between launches)
 };
 
+// LDS-DMA (global_load_lds: a load that writes LDS directly — no staging registers, no ds_write pass; destination = wave-uniform
+// base + lane·size, source per lane) and the waits / barrier that go with it
+#define PA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define PA_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+typedef const void __attribute__((address_space(1)))* pa_gptr;
+typedef void __attribute__((address_space(3)))* pa_lptr;
+__device__ __forceinline__ void pa_dma16(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 16, 0, 0); }
+__device__ __forceinline__ void pa_dma4(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 4, 0, 0); }
+__device__ __forceinline__ uint32_t pa_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// (PA_BARRIER instead of __syncthreads() where only LDS is handed over: __syncthreads() is a workgroup-scope fence too and makes
+// every wave wait for its outstanding global stores and atomics — in the agent kernel that drained each tile's stores at every barrier)
 // plane row / column of the cell an agent stands on.  TILED: the planes are a tile of a decomposed world (die_medium.gW > 0) —
 // every kernel below treats that tile as periodic; what this brings in across its outer edge stays in the outermost cells
 // of the halo, which the ghost-agent decomposition discards anyway (die_amd/dist.py)
@@ -203,13 +217,13 @@ __device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* b
         base[threadIdx.x] = own ? mt.o : mt.o + mt.s;
         s_len[threadIdx.x] = mt.s > mt.n ? 0u : (own ? mt.s : mt.n - mt.s);     // (s > n: broken bookkeeping — never loop over garbage)
     }
-    __syncthreads();
+    PA_BARRIER();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int q = 0; q < 9; ++q) { pre[q] = run; run += s_len[q]; }
         pre[9] = run;
     }
-    __syncthreads();
+    PA_BARRIER();
 }
 
 // copy a rows × (vpr·V)-element block of a plane into LDS with 16-byte accesses.  A thread keeps ONE column vector
@@ -319,13 +333,20 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_K1_MINW
 #define PIC_K1_MINW 6
 #endif
+#ifndef PIC_QUEUE
+#define PIC_QUEUE 1             // two-launch form: the agent kernel as a fixed grid that draws tiles from a queue and prefetches the next tile's agents
+#endif
 #ifndef PIC_STATIC_CHUNKS
 #define PIC_STATIC_CHUNKS 0     // 1: wave w takes chunks w, w + waves, … instead of drawing them from an LDS counter
 #endif
 // element `idx` of a 4-byte-per-agent array: a 32-bit byte offset on the array's (scalar) base — the host refuses worlds of
 // 2^30 agents —, so every stream of an agent shares ONE offset register instead of a 64-bit address of its own
 #define PIC_AT(base, type, idx) (*(type*)((char*)(base) + (size_t)(uint32_t)((uint32_t)(idx) << 2)))
-template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED>
+// PERSIST: a fixed grid of workgroups (three per CU) that draw tiles from a queue (p.queue, one atomic per tile, claimed two
+// tiles ahead) and prefetch the NEXT tile's per-tile words, first stayers and candidate arrivals into registers while they work
+// on the current one — two of the four memory round trips of a tile's chain leave its critical path; LDS per workgroup is
+// unchanged (the windows are NOT double-buffered: that costs a resident workgroup, k_pic_agents below).
+template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool PERSIST = false>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
@@ -347,7 +368,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
 #define PIC_KP(field, type) (p.field)
 #endif
     extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile ± its margin
-    __shared__ uint32_t s_base[9], s_pre[10];
+    __shared__ uint32_t s_base[9], s_pre[10];                     // ranges of the current tile
+    __shared__ uint32_t s_nbase[9], s_nlen[9];                     // PERSIST: first index and length of the NEXT tile's ranges
+    __shared__ int s_claim[2];                                     // PERSIST: tiles drawn from the queue
     __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
     __shared__ uint32_t s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
@@ -355,54 +378,141 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     __shared__ uint32_t s_list[PIC_LIST_CAP];
     __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
     __shared__ uint32_t s_alv[TILED ? PIC_K1_BLOCK / DIE_WAVE : 1];   // TILED: agents this rank accounts for (die_medium.own_*)
-    const int tx = blockIdx.y, ty = blockIdx.x, tile = tx * p.nty + ty;      // (a 2-D grid: no division by a run-time value)
-    const int TX = 1 << p.xs, TY = 1 << p.ys, x0 = tx << p.xs, y0 = ty << p.ys;
+    const int NT = p.ntx * p.nty;
+    const int TX = 1 << p.xs, TY = 1 << p.ys;
     const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE, nwaves = blockDim.x / DIE_WAVE;
-    if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
-    if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
-    PIC_STAMP(0);
-    PIC_SETPRIO(PIC_PRIO_K1, 0);
-    // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
-    // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
-    const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
-    // the tiles to stage depend on nothing but the tile index: their loads go out next and overlap both round trips
+    const unsigned long long below = (1ull << lane) - 1ull;
     const T* food = (const T*)p.food;
     constexpr int SV = 16 / (int)sizeof(T);
     const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
+    // the tile(s) of this workgroup.  PERSIST: two claimed up front (one atomic), then one more per tile, two tiles ahead
+    int tile = (int)blockIdx.y * p.nty + (int)blockIdx.x, tile1 = NT;
+    // the per-tile counters (PERSIST: reset again behind every tile's epilogue — the two barriers of the next tile's ranges lie
+    // between a reset and the first wave that counts)
+    if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
+    if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
+    if (PERSIST) {
+        if (threadIdx.x == 0) { const int t = (int)atomicAdd(&p.queue[0], 2u); s_claim[0] = t; s_claim[1] = t + 1; }
+        PA_BARRIER();
+        tile = s_claim[0]; tile1 = s_claim[1];
+        PA_BARRIER();
+    }
+    // what a tile's first pass needs from memory besides its windows, in registers one tile ahead: the segment words (ranges in
+    // LDS set `cur`), this thread's first candidate arrival and the six streams of this wave's first chunk of stayers
+    [[maybe_unused]] unsigned long long stamp_prev = 0ull;
+    uint32_t cj = 0, cX = 0, cY = 0, pX = 0, pY = 0, pS = 0, pHh = 0, pHl = 0;
+    float pA = 0.f;
+    bool chas = false;
+    // (PERSIST: the words go through s_nbase / s_nlen — also for the first tile — so that the kernel holds ONE set of ranges and
+    // no more static LDS than the plain form: 48 bytes more cost the third resident workgroup per CU)
+    auto ranges_from_next = [&]() {                               // between two barriers: s_nbase / s_nlen → s_base / s_pre
+        if (threadIdx.x < 9) s_base[threadIdx.x] = s_nbase[threadIdx.x];
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int q = 0; q < 9; ++q) { s_pre[q] = run; run += s_nlen[q]; }
+            s_pre[9] = run;
+        }
+    };
+    auto words_to_next = [&](const PicMeta& m) {
+        if (threadIdx.x < 9) {
+            const bool own_ = threadIdx.x == 0;
+            s_nbase[threadIdx.x] = own_ ? m.o : m.o + m.s;
+            s_nlen[threadIdx.x] = m.s > m.n ? 0u : (own_ ? m.s : m.n - m.s);      // (s > n: broken bookkeeping — never loop over garbage)
+        }
+    };
+    auto prefetch_agents = [&]() {
+        const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
+        // this thread's first candidate arrival and the agent streams of this wave's first chunk of stayers
+        cj = 0; cX = 0; cY = 0;
+        chas = threadIdx.x < ncand;
+        if (chas) {
+            const uint32_t idx = own + threadIdx.x;
+            int r = 1;
+            while (idx >= s_pre[r + 1]) ++r;
+            cj = s_base[r] + (idx - s_pre[r]);
+            cX = PIC_AT(p.in.x, const uint32_t, cj);
+            cY = PIC_AT(p.in.y, const uint32_t, cj);
+        }
+        const uint32_t pidx = (uint32_t)(wave * DIE_WAVE + lane);
+        pX = 0; pY = 0; pS = 0; pHh = 0; pHl = 0; pA = 0.f;
+        if (pidx < own) {
+            const uint32_t j = base0 + pidx;
+            pX = PIC_AT(p.in.x, const uint32_t, j); pY = PIC_AT(p.in.y, const uint32_t, j); pS = PIC_AT(p.in.slot, const uint32_t, j);
+            pHh = PIC_AT(p.in.hhi, const uint32_t, j); pHl = PIC_AT(p.in.hlo, const uint32_t, j);
+            pA = PIC_AT(p.in.agent_food, const float, j);
+        }
+    };
+    if (PERSIST && tile < NT) {                                    // the first tile's: nothing to hide them behind
+        const int tx_ = tile / p.nty;
+        words_to_next(pic_meta_load(p.in, tx_, tile - tx_ * p.nty, p.ntx, p.nty));
+        PA_BARRIER();
+        ranges_from_next();
+        PA_BARRIER();
+        prefetch_agents();
+    }
+  for (; !PERSIST || tile < NT; ) {
+    const int tx = PERSIST ? tile / p.nty : (int)blockIdx.y, ty = PERSIST ? tile - tx * p.nty : (int)blockIdx.x;
+    const int x0 = tx << p.xs, y0 = ty << p.ys;
+    PIC_STAMP(0);
+#if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
+    if (PERSIST && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
+        ((unsigned long long*)(p.error + 2))[(size_t)tile * 16 + 6] = stamp_prev ? t_ - stamp_prev : 0ull; }
+#endif
+    PIC_SETPRIO(PIC_PRIO_K1, 0);
+    // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
+    // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
+    // (PERSIST: the NEXT tile's words — this tile's ranges are in LDS already)
+    PicMeta mt = {0u, 0u, 0u};
+    if (!PERSIST) mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
+    else if (tile1 < NT) { const int tx1 = tile1 / p.nty; mt = pic_meta_load(p.in, tx1, tile1 - tx1 * p.nty, p.ntx, p.nty); }
+    // the tiles to stage depend on nothing but the tile index: their loads go out next and overlap both round trips
     const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, (int)blockDim.x / (pitch / SV)};
     const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, (int)blockDim.x / (fpitch / SV)};
     uint4 sc[4], sf[3];                   // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
-    if (STAGE) {
+    if (STAGE && !PERSIST) {
         st_c.issue(sc);
         st_f.issue(sf);
     }
+    if (STAGE && PERSIST) {
+        // by LDS-DMA: the 28 staging registers are what the prefetched agents of the next tile need (with both in registers
+        // the kernel spilled to scratch), and the commit pass goes.  Instruction q of the block copies vectors q·64 .. q·64 + 63
+        // (row-major image, as PicStageRows leaves it); the waves take the instructions in turn.
+        unsigned char* wb = pic_smem;
+        const T* chem = (const T*)f.chem;
+        const int vpr_c = pitch / SV, vpr_f = fpitch / SV, nvc = rows * vpr_c, nvf = frows * vpr_f;
+        for (int q = wave; q * DIE_WAVE < nvc; q += nwaves) {
+            const int i = q * DIE_WAVE + lane;
+            if (i < nvc) {
+                const int row = (int)(((uint32_t)i * p.mg_c) >> 20), cv = i - row * vpr_c;
+                const int gx = min(max(x0 - P + row, 0), p.g.W - 1), gy = min(max(y0 - P + cv * SV, 0), p.g.H - SV);
+                pa_dma16(chem + (__mul24(gx, p.g.H) + gy), wb + (size_t)q * DIE_WAVE * 16);
+            }
+        }
+        wb += (size_t)rows * pitch * sizeof(T);
+        for (int q = wave; q * DIE_WAVE < nvf; q += nwaves) {
+            const int i = q * DIE_WAVE + lane;
+            if (i < nvf) {
+                const int row = (int)(((uint32_t)i * p.mg_f) >> 20), cv = i - row * vpr_f;
+                int gx = x0 - FR + row, gy = y0 - FC + cv * SV;
+                gx += gx < 0 ? p.g.W : 0; gx -= gx >= p.g.W ? p.g.W : 0;
+                gy += gy < 0 ? p.g.H : 0; gy -= gy >= p.g.H ? p.g.H : 0;
+                pa_dma16(food + (__mul24(gx, p.g.H) + gy), wb + (size_t)q * DIE_WAVE * 16);
+            }
+        }
+    }
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
-    pic_ranges_finish(mt, s_base, s_pre);
+    // the tile after the next: ONE thread of the LAST wave asks the queue.  The compiler waits for a returning atomic right where
+    // it stands (wave-aggregated add + readfirstlane) — a round trip of 2 000–4 000 cycles; in the last wave it runs beside the
+    // window loads, which every wave waits for anyway (in thread 0 it held up the whole workgroup at the top of every tile).
+    // Needed behind this tile's last barrier.
+    if (PERSIST && threadIdx.x == blockDim.x - 1) s_claim[0] = (int)atomicAdd(&p.queue[0], 1u);
+    if (!PERSIST) {
+        pic_ranges_finish(mt, s_base, s_pre);
+        prefetch_agents();
+    }
     PIC_STAMP(1);
     const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
-    const unsigned long long below = (1ull << lane) - 1ull;
-    // 2nd round trip: this thread's first candidate arrival and the agent streams of this wave's first chunk of stayers
-    uint32_t cj = 0, cX = 0, cY = 0;
-    const bool chas = threadIdx.x < ncand;
-    if (chas) {
-        const uint32_t idx = own + threadIdx.x;
-        int r = 1;
-        while (idx >= s_pre[r + 1]) ++r;
-        cj = s_base[r] + (idx - s_pre[r]);
-        cX = PIC_AT(p.in.x, const uint32_t, cj);
-        cY = PIC_AT(p.in.y, const uint32_t, cj);
-    }
-    const uint32_t pidx = (uint32_t)(wave * DIE_WAVE + lane);
-    const bool phas = pidx < own;
-    uint32_t pX = 0, pY = 0, pS = 0, pHh = 0, pHl = 0;
-    float pA = 0.f;
-    if (phas) {
-        const uint32_t j = base0 + pidx;
-        pX = PIC_AT(p.in.x, const uint32_t, j); pY = PIC_AT(p.in.y, const uint32_t, j); pS = PIC_AT(p.in.slot, const uint32_t, j);
-        pHh = PIC_AT(p.in.hhi, const uint32_t, j); pHl = PIC_AT(p.in.hlo, const uint32_t, j);
-        pA = PIC_AT(p.in.agent_food, const float, j);
-    }
     PIC_SETPRIO(PIC_PRIO_K1, 1);
     FwdTileMem<T, TILED> tm;
     tm.g = p.g;
@@ -410,8 +520,10 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     if (STAGE) {
         T* s_chem = (T*)pic_smem;
         s_food = s_chem + rows * pitch;
-        st_c.commit(s_chem, sc);
-        st_f.commit(s_food, sf);
+        if (!PERSIST) {
+            st_c.commit(s_chem, sc);
+            st_f.commit(s_food, sf);
+        }
         tm.food = s_food; tm.fx0 = x0 - FR; tm.fy0 = y0 - FC; tm.fpitch = fpitch;
         tm.chem = s_chem; tm.cx0 = x0 - P; tm.cy0 = y0 - P; tm.pitch = pitch;
     }
@@ -442,7 +554,14 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             at = __shfl(at, 0, DIE_WAVE);
             if (hit) s_list[at + (uint32_t)__popcll(m & below)] = j;
         }
-        __syncthreads();                                           // publishes the staged tiles and the list
+        if (PERSIST && STAGE && cb == 0) PA_WAIT_VM();             // this wave's window DMAs have landed
+        PA_BARRIER();                                           // publishes the staged tiles and the list
+        if (PERSIST && cb == 0) {
+            // everything requested at the top of the tile is here now: the next tile's segment words and the tile drawn from the
+            // queue go to LDS at once — a use behind the chunk loop would make the compiler drain this tile's stores first
+            // (it cannot count a wait across the loop: the tail of a tile took 9 000 cycles that way)
+            words_to_next(mt);
+        }
         PIC_STAMP(3);
         PIC_SETPRIO(PIC_PRIO_K1, 2);
         const uint32_t n_own = cb == 0 ? own : 0u, count = n_own + s_nlist;
@@ -470,7 +589,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             bool listed = false;
             if (act) {
                 const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
-                if (first && idx < n_own) {
+                if (first && idx < n_own) {                      // (this wave's prefetched chunk: idx = wave·64 + lane < own)
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
                 } else {
                     // (the pointers first — their scalar loads go out together —, then all six streams in flight together)
@@ -576,9 +695,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             first = false;
         }
         if (cb + PIC_LIST_CAP < ncand) {                           // another round (rare): reset the work counters
-            __syncthreads();
+            PA_BARRIER();
             if (threadIdx.x == 0) { s_next = 0; s_nlist = 0; }
-            __syncthreads();
+            PA_BARRIER();
         }
     }
     PIC_STAMP(4);
@@ -589,8 +708,11 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         const long long c = die_wave_sum((long long)nowned);
         if (lane == 0) s_alv[threadIdx.x / DIE_WAVE] = (uint32_t)c;
     }
-    __syncthreads();
+    PA_BARRIER();
     PIC_STAMP(5);
+#if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
+    if (PERSIST && threadIdx.x == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory"); }
+#endif
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
         const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
         atomicAdd(&PIC_KP(out.inc, uint32_t*)[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
@@ -614,6 +736,23 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
         p.out.s[tile] = nfront;
         if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
+    }
+    if (!PERSIST) break;
+    // the next tile: its ranges from the words requested at the top of this one (pic_ranges_finish, with the per-tile counters
+    // reset BETWEEN its two barriers: every wave has read this tile's counts before the first, none counts for the next tile before
+    // the second), then its first candidates and stayers — in flight while the next windows load
+    PA_BARRIER();
+    ranges_from_next();
+    if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
+    if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
+    PA_BARRIER();
+    tile = tile1;
+    tile1 = s_claim[0];
+    if (tile < NT) prefetch_agents();
+  }
+    if (PERSIST) {                                                 // the last workgroup out leaves the queue ready for the next launch
+        PA_BARRIER();
+        if (threadIdx.x == 0 && atomicAdd(&p.queue[1], 1u) == gridDim.x - 1u) { p.queue[0] = 0u; p.queue[1] = 0u; }
     }
 }
 
@@ -670,14 +809,6 @@ struct PaLds {                  // byte offsets into the dynamic LDS block (host
 #else
 #define PA_STAMP(k, tile_) do { } while (0)
 #endif
-#define PA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define PA_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-typedef const void __attribute__((address_space(1)))* pa_gptr;
-typedef void __attribute__((address_space(3)))* pa_lptr;
-__device__ __forceinline__ void pa_dma16(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 16, 0, 0); }
-__device__ __forceinline__ void pa_dma4(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 4, 0, 0); }
-__device__ __forceinline__ uint32_t pa_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
 // per-tile words of `tile`'s neighbourhood → LDS (one DMA instruction, lanes 0..28)
 __device__ __forceinline__ void pa_meta_issue(const PicArgs& p, int tile, uint32_t* mr_slot, int lane) {
     const int tx = tile / p.nty, ty = tile - tx * p.nty;
@@ -1772,6 +1903,16 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
     return DIE_OK;
 }
 
+static int pa_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 256;
+    }
+    return cus;
+}
+
 template <int XS, int YS>
 static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32, bool feed, hipStream_t s) {
     if (f32) {
@@ -1781,6 +1922,22 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
         if (feed) k_pic_resolve<__half, XS, YS, true><<<dim3(k.nty, k.ntx + 1), PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
         else k_pic_resolve<__half, XS, YS, false><<<dim3(k.nty, k.ntx + 1), PIC_K2_BLOCK, 0, s>>>(k, dep_plane);
     }
+}
+
+// PERSIST (two-launch form with staged windows): three workgroups per CU draw the tiles from k.queue
+template <typename T, bool TILED>
+static void launch_forward_move_queue(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
+    const int g3 = 3 * pa_cu_count();
+    const dim3 grid(NT < g3 ? NT : g3);
+    if (getenv("DIE_PIC_DEBUG")) {
+        int nq = -1, np_ = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nq, (const void*)k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, TILED, true>, block, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&np_, (const void*)k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, TILED, false>, block, lds);
+        fprintf(stderr, "die_pic: occupancy (workgroups per CU) queue form %d, plain form %d; block %d, dynamic LDS %zu, grid %u\n", nq, np_, block, lds, grid.x);
+    }
+    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, true, true, true, TILED, true><<<grid, block, lds, s>>>(f, k);
+    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, true, true, TILED, true><<<grid, block, lds, s>>>(f, k);
+    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, TILED, true><<<grid, block, lds, s>>>(f, k);
 }
 
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
@@ -1835,16 +1992,6 @@ static PaLds pa_lds_layout(int P, int FR, int FC, int esz) {
     return L;
 }
 
-static int pa_cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
-    return cus;
-}
-
 template <typename T, bool TILED>
 static int launch_agents(const FwdArgs& f, const PicArgs& k, const PaLds& L, int NT, hipStream_t s) {
     static bool attr_set = false;
@@ -1896,7 +2043,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.adx = act ? act->dx : nullptr; k.ady = act ? act->dy : nullptr; k.adep = act ? act->deposit : nullptr;
     k.food = m->food; k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
     k.boundary = d->boundary; k.cost = d->cost;
-    k.part_gain = (long long*)p->part_gain; k.error = p->error;
+    k.part_gain = (long long*)p->part_gain; k.error = p->error; k.queue = nullptr;
     const int NT = k.ntx * k.nty;
     hipStream_t s = (hipStream_t)stream;
     // K1 stages chem of the tile ± the probe reach in LDS when that fits: an agent's probe cell lies at most
@@ -1974,6 +2121,10 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
         if (tiled) rc2 = m->dtype == DIE_F32 ? launch_agents<float, true>(f, k, PL, NT, s) : launch_agents<__half, true>(f, k, PL, NT, s);
         else rc2 = m->dtype == DIE_F32 ? launch_agents<float, false>(f, k, PL, NT, s) : launch_agents<__half, false>(f, k, PL, NT, s);
         if (rc2 != DIE_OK) return rc2;
+    } else if ((stages & 1) && two && stage && p->queue && PIC_QUEUE) {
+        k.queue = p->queue;
+        if (tiled) { if (m->dtype == DIE_F32) launch_forward_move_queue<float, true>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, true>(g->kind, f, k, NT, block, lds, s); }
+        else { if (m->dtype == DIE_F32) launch_forward_move_queue<float, false>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, false>(g->kind, f, k, NT, block, lds, s); }
     } else if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s); \
                                        else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s); } while (0)

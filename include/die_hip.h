@@ -423,6 +423,9 @@ typedef struct die_pic {
     int64_t turn_slots;          /* slot ids are < turn_slots (>= N; a decomposed world: the world's slot count) */
     int32_t turn_ready;          /* the table already holds the bits of (g->seed, g->step) */
     int32_t reserved3;
+    uint32_t* queue;             /* 2 device words, both 0 between steps (the library leaves them so), or NULL: the tile queue of the
+                                    agent kernel's persistent form (two-launch form: a fixed grid of workgroups draws tiles from it
+                                    and prefetches the next tile's agents while it works on the current one) */
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */

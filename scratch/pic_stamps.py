@@ -21,6 +21,10 @@ for i, n in enumerate(names):
     print(f'  {n:46s} {d[:, i].mean():8.1f} {np.median(d[:, i]):8.1f} {np.percentile(d[:, i], 95):8.1f}   {100 * d[:, i].sum() / tot.sum():5.1f} %')
 print(f'  {"total":46s} {tot.mean():8.1f} {np.median(tot):8.1f} {np.percentile(tot, 95):8.1f}')
 
+tail = raw[:, 6].astype(np.float64)
+if tail.any():
+    t = tail[tail > 0]
+    print(f'  tail of the previous tile (queue form): last barrier -> next tile started   {t.mean():8.1f} {np.median(t):8.1f} {np.percentile(t, 95):8.1f}   over {len(t)} tiles')
 if raw[:, 8:15].any():
     st = raw[:, 8:15].astype(np.float64)
     d = np.diff(st, axis=1)

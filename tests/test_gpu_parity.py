@@ -532,6 +532,39 @@ def test_persistent_agent_kernel_equals_the_default(die, W, H, boundary, f16, N,
         assert np.array_equal(a, b), name
 
 
+def test_agent_kernel_tile_queue_form_equals_the_default(die):
+    """die_pic.queue: the agent kernel as a fixed grid of workgroups (three per CU) that draw tiles from a queue and prefetch the
+    next tile's segment words, first stayers and candidate arrivals while they work on the current one (k_pic_forward_move
+    <…, PERSIST>) against the default one-workgroup-per-tile launch, bit for bit — on a world of 1 600 tiles, so that a workgroup
+    takes several tiles in a row (768 workgroups on an MI355X)."""
+    W = H = 1280
+    xs = ys = 5                                               # 32x32 tiles: 40 x 40 = 1 600 of them
+    N = 250000
+    rs = np.random.RandomState(77)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.2)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    outs = []
+    for queue in (True, False):
+        env = die.Env.from_numpy(medium, agents, pic=True)
+        env._pic_tile = (5, 6)
+        env._pic_queue = queue
+        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        rewards = []
+        for i in range(6):
+            action = ag.forward(obs)
+            obs, rew, _, _, info = env.step(action)
+            rewards.append((rew, info['num_agents']))
+            assert env._pic is not None and env._pic.held[0] is env.agents.x and (env._pic.queue is not None) == queue
+        env.check()
+        assert env._pic.queue is None or int(env._pic.queue.abs().sum().item()) == 0, 'the queue words are left at zero'
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), action.to_numpy(), np.array(rewards)))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'last action', 'rewards'), outs[0], outs[1]):
+        assert np.array_equal(a, b), name
+
+
 def applied(action):
     """The action as the device applies it: displacements rounded to the Q0.32 grid of the coordinates (at most 2^-33 away
     from the float the agent computed — enough to put ≈ 1e-6 of the agents of a 4096-cell axis on the other side of a cell
