@@ -157,7 +157,16 @@ struct PicArgs {
     uint32_t* rim_cnt;              // [tile]: entries the tile had (may exceed rim_cap: the reader then scans the segment)
     int rim_cap, rim_r;             // gaussian radius R = width of the rim
     uint32_t* queue;                // PERSIST: [0] next tile to hand out, [1] workgroups that have finished (both 0 between launches)
+    // a launch over a SUBSET of the tiles (die_pic.sub_*: a decomposed rank steps the tiles that need nothing from its neighbours
+    // while the ghost refresh's messages are in flight, the others afterwards): 0 all tiles; 1 the rectangle only (the grid is the
+    // rectangle); 2 all but the rectangle (full grid, the rectangle's workgroups return at once)
+    int sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty;
 };
+__device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty) {        // false: not this launch's tile
+    if (p.sub_mode == 1) { tx += p.sub_tx0; ty += p.sub_ty0; return true; }
+    if (p.sub_mode == 2) return !(tx >= p.sub_tx0 && tx < p.sub_tx0 + p.sub_ntx && ty >= p.sub_ty0 && ty < p.sub_ty0 + p.sub_nty);
+    return true;
+}
 
 // LDS-DMA (global_load_lds: a load that writes LDS directly — no staging registers, no ds_write pass; destination = wave-uniform
 // base + lane·size, source per lane) and the waits / barrier that go with it
@@ -387,7 +396,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile(s) of this workgroup.  PERSIST: two claimed up front (one atomic), then one more per tile, two tiles ahead
-    int tile = (int)blockIdx.y * p.nty + (int)blockIdx.x, tile1 = NT;
+    int btx = (int)blockIdx.y, bty = (int)blockIdx.x;
+    if (!PERSIST && !pic_sub_tile(p, btx, bty)) return;
+    int tile = btx * p.nty + bty, tile1 = NT;
     // the per-tile counters (PERSIST: reset again behind every tile's epilogue — the two barriers of the next tile's ranges lie
     // between a reset and the first wave that counts)
     if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         prefetch_agents();
     }
   for (; !PERSIST || tile < NT; ) {
-    const int tx = PERSIST ? tile / p.nty : (int)blockIdx.y, ty = PERSIST ? tile - tx * p.nty : (int)blockIdx.x;
+    const int tx = PERSIST ? tile / p.nty : btx, ty = PERSIST ? tile - tx * p.nty : bty;
     const int x0 = tx << p.xs, y0 = ty << p.ys;
     PIC_STAMP(0);
 #if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
@@ -1519,7 +1530,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         }
         return;
     }
-    const int tx = blockIdx.y, ty = blockIdx.x, x0 = tx << XS, y0 = ty << YS;
+    int tx = blockIdx.y, ty = blockIdx.x;
+    if (!pic_sub_tile(p, tx, ty)) return;
+    const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
     [[maybe_unused]] const int tile = tx * p.nty + ty;
     PIC_STAMP(8);
@@ -1942,7 +1955,7 @@ static void launch_forward_move_queue(int kind, const FwdArgs& f, const PicArgs&
 
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
-    const dim3 grid(k.nty, k.ntx);
+    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx);
     if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, TILED><<<grid, block, lds, s>>>(f, k);
     else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true, RIM, TILED><<<grid, block, lds, s>>>(f, k);
     else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false, RIM, TILED><<<grid, block, lds, s>>>(f, k);
@@ -1955,7 +1968,8 @@ static void launch_resolve_diffuse(const PicArgs& k, const KbArgs& a, int R, hip
     constexpr int TX = 1 << XS, TY = 1 << YS, A = 16 / (int)sizeof(T), CP = TY + 2 * A;
     const int WR = TX + 2 * R, WC = TY + 2 * R;
     const size_t lds = ((size_t)WR * CP + (size_t)(WR * WC > TX * CP ? WR * WC : TX * CP)) * 4;
-    const dim3 grid(k.nty, k.ntx + 1);
+    // (a rectangle of tiles only: no extra grid row — the scan / reduction / turn bits belong to the launch that completes the step)
+    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx + 1);
     constexpr int B = KbShape<XS, YS>::BLOCK;
     switch (R) {
         case 1: k_pic_resolve_diffuse<T, XS, YS, 1, TILED><<<grid, B, lds, s>>>(k, a); break;
@@ -2044,6 +2058,14 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.food = m->food; k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
     k.boundary = d->boundary; k.cost = d->cost;
     k.part_gain = (long long*)p->part_gain; k.error = p->error; k.queue = nullptr;
+    k.sub_mode = p->sub_mode; k.sub_tx0 = p->sub_tx0; k.sub_ty0 = p->sub_ty0; k.sub_ntx = p->sub_ntx; k.sub_nty = p->sub_nty;
+    DIE_REQUIRE(p->sub_mode >= 0 && p->sub_mode <= 2, "die_pic_forward_env_step: sub_mode %d", p->sub_mode);
+    if (p->sub_mode) {
+        DIE_REQUIRE(p->stages == 1 || p->stages == 2, "die_pic_forward_env_step: a subset of the tiles is one launch (stages 1 or 2), not a whole step");
+        DIE_REQUIRE(p->sub_tx0 >= 0 && p->sub_ty0 >= 0 && p->sub_ntx >= 0 && p->sub_nty >= 0 && p->sub_tx0 + p->sub_ntx <= k.ntx && p->sub_ty0 + p->sub_nty <= k.nty,
+                    "die_pic_forward_env_step: the rectangle of tiles lies outside the planes");
+        if (p->sub_mode == 1 && (p->sub_ntx == 0 || p->sub_nty == 0)) return DIE_OK;      // an empty rectangle: nothing to launch
+    }
     const int NT = k.ntx * k.nty;
     hipStream_t s = (hipStream_t)stream;
     // K1 stages chem of the tile ± the probe reach in LDS when that fits: an agent's probe cell lies at most
@@ -2079,6 +2101,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
                      // across the world's seam, where cell W − 1 and cell 0 are the same point of the coordinate circle — labels
                      // linspace(0, 1, W), core/data_init.py:95-112 — and an agent's cell index jumps by one extra)
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
+    DIE_REQUIRE(two || !p->sub_mode, "die_pic_forward_env_step: subsets of the tiles exist in the two-launch form only");
     if (tiled && !(two && stage)) {
         die_set_error("die_pic_forward_env_step: a decomposed world's tile runs the two-launch form with staged tiles only (probe reach %d, radius %d)", P, R);
         return DIE_ERR_UNSUPPORTED;
@@ -2108,7 +2131,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // 64×64 tiles, staged windows, PhysarumAgent.  Not the default: at 4096² it takes 101 µs against 81 µs
     bool persistent = false;
     PaLds PL = {};
-    if (two && stage && physarum && p->tile_xs == 6 && p->tile_ys == 6 && p->k1_threads == -1) {
+    if (two && stage && physarum && p->tile_xs == 6 && p->tile_ys == 6 && p->k1_threads == -1 && !p->sub_mode) {
         PL = pa_lds_layout(k.margin, k.fm_r, k.fm_c, esz);
         const int nvc = (TX + 2 * k.margin) * vpr_c, nvf = (TX + 2 * k.fm_r) * vpr_f;
         bool ok = PL.total <= 160u * 1024u && nvc < 4096 && nvf < 4096;
@@ -2121,7 +2144,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
         if (tiled) rc2 = m->dtype == DIE_F32 ? launch_agents<float, true>(f, k, PL, NT, s) : launch_agents<__half, true>(f, k, PL, NT, s);
         else rc2 = m->dtype == DIE_F32 ? launch_agents<float, false>(f, k, PL, NT, s) : launch_agents<__half, false>(f, k, PL, NT, s);
         if (rc2 != DIE_OK) return rc2;
-    } else if ((stages & 1) && two && stage && p->queue && PIC_QUEUE) {
+    } else if ((stages & 1) && two && stage && p->queue && PIC_QUEUE && !p->sub_mode) {
         k.queue = p->queue;
         if (tiled) { if (m->dtype == DIE_F32) launch_forward_move_queue<float, true>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, true>(g->kind, f, k, NT, block, lds, s); }
         else { if (m->dtype == DIE_F32) launch_forward_move_queue<float, false>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, false>(g->kind, f, k, NT, block, lds, s); }

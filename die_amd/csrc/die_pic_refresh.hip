@@ -42,6 +42,7 @@ struct RfArgs {
     RfSide side[RF_SIDES];
     long long* summary;
     uint32_t capacity;
+    int phase;                  // die_pic_ghost_merge_phase: 0 the whole new layout; 1 its interior tiles (needs nothing that arrives); 2 its halo tiles
 };
 
 __device__ __forceinline__ int rf_wrap(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
@@ -155,9 +156,12 @@ __device__ __forceinline__ int rf_halo_side(const RfArgs& a, int tx, int ty, int
     return -1;
 }
 
-// one workgroup: the new segment sizes and offsets (dst's per-tile words: every agent a stayer), the totals
+// one workgroup: the new segment sizes and offsets (dst's per-tile words: every agent a stayer), the totals.  The segments of
+// the INTERIOR tiles come first (in tile order), those of the halo tiles behind them: an interior tile's offset then depends on
+// nothing that arrives from a neighbour, and the step after a refresh can run on the interior while the messages are in flight
+// (phase 1: interior tiles; phase 2: halo tiles, from the interior's total in summary[1]; phase 0: both).
 __global__ __launch_bounds__(1024) void k_pic_ghost_scan(RfArgs a) {
-    __shared__ uint32_t s[1024], s_own[1024];
+    __shared__ uint32_t s[1024];
     const int NT = a.NTX * a.NTY, per = (NT + 1023) / 1024;
     const int lo = threadIdx.x * per, hi = min(lo + per, NT);
     auto count = [&](int t, bool& interior) {
@@ -167,32 +171,47 @@ __global__ __launch_bounds__(1024) void k_pic_ghost_scan(RfArgs a) {
         int i;
         const int k = rf_halo_side(a, tx, ty, i);
         if (k < 0) return 0u;
+        if (a.phase == 1) return 0u;                            // (nothing has arrived yet)
         const uint32_t c = a.side[k].recv_counts[i];
         if (c > a.side[k].cap) { rf_flag(a, RF_FLAG_RECV); return 0u; }
         return c;
     };
-    uint32_t sum = 0, own = 0;
-    for (int t = lo; t < hi; ++t) { bool in; const uint32_t c = count(t, in); sum += c; own += in ? c : 0u; }
-    s[threadIdx.x] = sum; s_own[threadIdx.x] = own;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u, w = (int)threadIdx.x >= o ? s_own[threadIdx.x - o] : 0u;
+    uint32_t own_total = a.phase == 2 ? (uint32_t)a.summary[1] : 0u;
+    for (int pass = 0; pass < 2; ++pass) {                      // 0: interior tiles, 1: halo tiles
+        const bool active = pass == 0 ? a.phase != 2 : a.phase != 1;
+        uint32_t sum = 0;
+        if (active) for (int t = lo; t < hi; ++t) { bool in; const uint32_t c = count(t, in); sum += in == (pass == 0) ? c : 0u; }
         __syncthreads();
-        s[threadIdx.x] += v; s_own[threadIdx.x] += w;
+        s[threadIdx.x] = sum;
         __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const uint32_t total = s[1023];
+        if (active) {
+            uint32_t run = (pass == 0 ? 0u : own_total) + s[threadIdx.x] - sum;
+            for (int t = lo; t < hi; ++t) {
+                bool in;
+                const uint32_t c = count(t, in);
+                if (in != (pass == 0)) continue;
+                a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+                run += c;
+            }
+        }
+        if (pass == 0 && a.phase != 2) own_total = total;
+        if (pass == 1 && active && threadIdx.x == 0) {
+            a.summary[0] = (long long)own_total + (long long)total;
+            if (own_total + total > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
+        }
     }
-    uint32_t run = s[threadIdx.x] - sum;
-    for (int t = lo; t < hi; ++t) {
-        bool in;
-        const uint32_t c = count(t, in);
-        a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
-        run += c;
+    if (a.phase != 2 && threadIdx.x == 0) {
+        a.summary[1] = (long long)own_total;
+        if (own_total > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
     }
-    if (threadIdx.x == 1023) {
-        a.summary[0] = (long long)s[1023]; a.summary[1] = (long long)s_own[1023];
-        if (s[1023] > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
-    }
-    if ((int)threadIdx.x < a.n_sides) {
+    if (a.phase != 1 && (int)threadIdx.x < a.n_sides) {
         const RfSide& S = a.side[threadIdx.x];
         long long t = 0;
         for (int i = 0; i < S.ntx * S.nty; ++i) t += (long long)S.recv_counts[i];
@@ -205,7 +224,9 @@ __global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_merge(RfArgs a) {
     const int tx = blockIdx.y, ty = blockIdx.x, t = tx * a.NTY + ty;
     const uint32_t base = a.dst.off[t], c = a.dst.n[t], capacity = a.capacity;
     const die_pic_layout& D = a.dst;
-    if (tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1) {
+    const bool interior = tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1;
+    if (interior ? a.phase == 2 : a.phase == 1) return;
+    if (interior) {
         const uint32_t got = rf_gather(a, a.src, tx, ty, [&](uint32_t q, uint32_t X, uint32_t Y, uint32_t af, uint32_t sl, uint32_t hh, uint32_t hl) {
             const uint32_t at = base + q;
             if (q >= c || at >= capacity) return;
@@ -233,6 +254,11 @@ __global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_merge(RfArgs a) {
 __global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_words(RfArgs a) {
     const int t = blockIdx.x * RF_BLOCK + threadIdx.x;
     if (t >= a.NTX * a.NTY) return;
+    if (a.phase) {
+        const int tx = t / a.NTY, ty = t - tx * a.NTY;
+        const bool interior = tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1;
+        if (interior ? a.phase == 2 : a.phase == 1) return;
+    }
     const uint32_t c = a.dst.n[t];
     a.src.off[t] = a.dst.off[t]; a.src.n[t] = c; a.src.s[t] = c; a.src.inc[t] = 0;
 }
@@ -272,6 +298,7 @@ static int rf_fill(RfArgs& a, const die_medium* m, const die_pic* p, int32_t fro
     for (int k = n_sides; k < RF_SIDES; ++k) { a.side[k] = RfSide{}; a.first[k + 1] = a.first[n_sides]; }
     a.summary = (long long*)summary;
     a.capacity = 0;
+    a.phase = 0;
     return DIE_OK;
 }
 
@@ -290,11 +317,18 @@ extern "C" int die_pic_ghost_pack(const die_medium* m, const die_pic* p, int32_t
 
 extern "C" int die_pic_ghost_merge(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
                                    int64_t capacity, int64_t* summary, void* stream) {
+    return die_pic_ghost_merge_phase(m, p, from, n_sides, sides, capacity, summary, 0, stream);
+}
+
+extern "C" int die_pic_ghost_merge_phase(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                                         int64_t capacity, int64_t* summary, int32_t phase, void* stream) {
     RfArgs a;
     const int rc = rf_fill(a, m, p, from, n_sides, sides, summary, "die_pic_ghost_merge");
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(capacity > 0 && capacity < ((int64_t)1 << 31), "die_pic_ghost_merge: capacity %lld", (long long)capacity);
+    DIE_REQUIRE(phase >= 0 && phase <= 2, "die_pic_ghost_merge: phase %d", phase);
     a.capacity = (uint32_t)capacity;
+    a.phase = phase;
     hipStream_t s = (hipStream_t)stream;
     k_pic_ghost_scan<<<1, 1024, 0, s>>>(a);
     k_pic_ghost_merge<<<dim3(a.NTY, a.NTX), RF_BLOCK, 0, s>>>(a);

@@ -101,6 +101,33 @@ class TileGeometry:
         return sends, merges
 
 
+def peer_message_layout(dirs, neighbour, sizes):
+    """ONE message per peer for blocks that are defined per side (a side = one of the up to 8 directions with a halo).
+    `dirs`: TileGeometry.DIRS (sorted so that negation reverses the list), `neighbour(dx, dy)` -> rank, `sizes[k]`: bytes of
+    side k's block (side k of a rank and side nd - 1 - k of its neighbour there have the same shape).  Returns
+    (peers, send_off, recv_off, send_span, recv_span): byte offset of side k's block in the send / receive buffer and, per peer,
+    the (start, end) of its one message in each buffer.  The message for peer p holds the sender's sides towards p in ascending
+    side order; the block the peer packed as ITS side j is what arrives for my side nd - 1 - j, so my sides from p lie in the
+    message in DESCENDING order of my side index — also when one rank is the neighbour on several sides (2-rank axes: left and
+    right neighbour are one rank; a 2 x 2 torus has 3 peers for 8 sides) or a rank is its own neighbour."""
+    nd = len(dirs)
+    peer = [neighbour(dx, dy) for dx, dy in dirs]
+    peers = sorted(set(peer))
+    send_off, recv_off, send_span, recv_span = [0] * nd, [0] * nd, {}, {}
+    so = ro = 0
+    for p_ in peers:
+        mine = [k for k in range(nd) if peer[k] == p_]
+        s0, r0 = so, ro
+        for k in mine:
+            send_off[k] = so
+            so += sizes[k]
+        for k in reversed(mine):
+            recv_off[k] = ro
+            ro += sizes[k]
+        send_span[p_], recv_span[p_] = (s0, so), (r0, ro)
+    return peers, send_off, recv_off, send_span, recv_span
+
+
 class Comm:
     """Point-to-point transport over torch.distributed; `stage_cpu` routes device tensors through
     host memory (gloo).  Messages between one pair of ranks are matched in issue order."""
@@ -387,6 +414,7 @@ class DistEnv:
         if self.ghosts:
             self.medium.own = (g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi)
         self._ghosts_fresh = False
+        self._refresh_due, self._refresh_action = False, None     # a ghost refresh left for the next step (overlap)
         self._pic = None                 # PicState (die_amd/pic.py), built at the first step that qualifies
         self._pic_off = False            # the library refused the binned step for this configuration once
         self.pic_steps = 0               # steps taken by the tile-binned path (tests, bench)
@@ -597,19 +625,27 @@ class DistEnv:
         reward / num_agents count the agents standing on interior cells (die_medium.own_*)."""
         from .device_array import PendingAction, _ptr, stream_ptr
         lib, A, M = self._lib, self.agents, self.medium
-        if not self._ghosts_fresh:
-            self._refresh_ghosts(action)
         sp = stream_ptr(self.device)
         d = self._c_dynamics()
         result = torch.empty(2, dtype=torch.float64, device=self.device)
+        if self._refresh_due:
+            # the refresh that the previous step left for this one: the messages travel under this step's interior tiles
+            self._refresh_due = False
+            self._send_action = False
+            if self._pic_applies(action) and self._tile_refresh_applies():
+                self._check_reach(action)
+                self._check_seed(int(action.g_struct.seed))
+                self._refresh_ghosts_tiles(action, step=(d, result))
+                action.agent._forward_consumed(action)
+                M.owner_stale = self._mark_owner
+                self.pic_steps += 1
+                self.overlapped_refreshes = getattr(self, 'overlapped_refreshes', 0) + 1
+                return self._after_pic_step(action, result)
+            self._refresh_ghosts(action)
+        if not self._ghosts_fresh:
+            self._refresh_ghosts(action)
         if self._pic_applies(action) and self._pic_step(action, d, result):
-            M.swap_chem()
-            self._food_flow()
-            self._steps += 1
-            if self._steps % self.migrate_every == 0:
-                self._refresh_ghosts(action, after_step=True)
-            self.last_result = result
-            return self._get_current_obs, result
+            return self._after_pic_step(action, result)
         if self._pic is not None:
             self._pic_void()                # a classic step moves the agents in place: the tile order is gone
         M.next_epoch()
@@ -652,6 +688,31 @@ class DistEnv:
             self.sort_agents()
         self.last_result = result
         return self._get_current_obs, result
+
+    def _after_pic_step(self, action, result):
+        M = self.medium
+        M.swap_chem()
+        self._food_flow()
+        self._steps += 1
+        if self._steps % self.migrate_every == 0:
+            if self._overlap and self.geo.DIRS and self._tile_refresh_could_apply():
+                self._refresh_due, self._refresh_action = True, action      # … with the NEXT step (_step_ghost); observers flush it
+            else:
+                self._refresh_ghosts(action, after_step=True)
+        self.last_result = result
+        return self._get_current_obs, result
+
+    def _tile_refresh_could_apply(self) -> bool:
+        self._send_action = False
+        return self._tile_refresh_applies()
+
+    def flush_refresh(self):
+        """A ghost refresh that was left for the next step (to travel under its interior tiles) is done NOW: somebody wants to
+        look at the agents or the fields between two steps."""
+        if self._refresh_due:
+            self._refresh_due = False
+            self._refresh_ghosts(self._refresh_action, after_step=True)
+        self._refresh_action = None
 
     # -- tile-binned step on the padded tile (die_amd/pic.py, csrc/die_pic.hip TILED): a rank's step is the N = 1 step ------
     def _pic_applies(self, action) -> bool:
@@ -710,6 +771,7 @@ class DistEnv:
 
     def check(self):
         """Synchronise; raise if the tile-binned step reported a bookkeeping error since the last check."""
+        self.flush_refresh()
         torch.cuda.synchronize(self.device)
         if self._pic is not None and self._pic.steps_since_check:
             self._pic.check()
@@ -746,6 +808,7 @@ class DistEnv:
 
     def owned_mask(self) -> torch.Tensor:
         """Which local agents this rank accounts for (ghost mode: those standing on interior cells)."""
+        self.flush_refresh()
         if not self.ghosts:
             return torch.ones(self.agents.N, dtype=torch.bool, device=self.device)
         lx, ly = self._cells()
@@ -808,36 +871,68 @@ class DistEnv:
         P = SimpleNamespace(nd=nd, rects={})
         dens = self.world_agents / float(g.gW * g.gH)
         esz = self.medium.chem.element_size()
-        P.caps, P.off, P.cnt, geo, off = [], [], [], [], 0       # per side: (header, records, chem block, food block, end), counts
+        # per side, relative to the start of its block: (records, chem block, food block), block size; the per-tile counts come first
+        P.caps, rel, sizes, geo = [], [], [], []
         for dx, dy in g.DIRS:                         # identical on every rank: depends on the side's shape only
             (rs, cs), (hr, hc) = g._band(dx, dy), g._halo(dx, dy)
             cells = (rs.stop - rs.start) * (cs.stop - cs.start)
             cap = int(min(self.capacity, np.ceil(cells * dens * self._ghost_headroom) + 1024))
             ntx, nty = (rs.stop - rs.start) // TX, (cs.stop - cs.start) // TY
             blk = (cells * esz + 7) & ~7
-            hdr, cnt = off, off + 16
+            cnt = 16
             rec = (cnt + ntx * nty * 4 + 7) & ~7
             chem = (rec + 6 * cap * 4 + 7) & ~7
             food = chem + blk
-            off = food + blk
-            P.caps.append(cap); P.off.append((hdr, rec, chem, food, off)); P.cnt.append(cnt)
+            P.caps.append(cap); rel.append((cnt, rec, chem, food)); sizes.append(food + blk)
             geo.append((rs.start // TX, cs.start // TY, ntx, nty, hr.start // TX, hc.start // TY))
-        P.sbuf = torch.zeros(max(off, 8), dtype=torch.uint8, device=dev)
-        P.rbuf = torch.zeros(max(off, 8), dtype=torch.uint8, device=dev)
+        # ONE message per peer (a 2 x 2 torus: 3 peers, not 8 messages — a grouped exchange costs per message, whatever its size)
+        peers, soff, roff, sspan, rspan = peer_message_layout(g.DIRS, g.neighbour, sizes)
+        P.soff = [tuple(soff[k] + r for r in rel[k]) for k in range(nd)]      # (counts, records, chem, food) of side k in sbuf
+        P.roff = [tuple(roff[k] + r for r in rel[k]) for k in range(nd)]
+        total = sum(sizes)
+        P.sbuf = torch.zeros(max(total, 8), dtype=torch.uint8, device=dev)
+        P.rbuf = torch.zeros(max(total, 8), dtype=torch.uint8, device=dev)
         sb, rb = P.sbuf.data_ptr(), P.rbuf.data_ptr()
-        P.sides = (lib.PicSide * max(nd, 1))(*[lib.PicSide(*geo[k], P.caps[k], sb + P.cnt[k], sb + P.off[k][1], rb + P.cnt[k], rb + P.off[k][1])
+        P.sides = (lib.PicSide * max(nd, 1))(*[lib.PicSide(*geo[k], P.caps[k], sb + P.soff[k][0], sb + P.soff[k][1], rb + P.roff[k][0], rb + P.roff[k][1])
                                                for k in range(nd)])
-        P.recv_order = list(reversed(range(nd)))       # (see _build_ghost_plan / plan8)
-        P.smsg = [(g.neighbour(*g.DIRS[k]), P.sbuf[P.off[k][0]:P.off[k][4]]) for k in range(nd)]
-        P.rmsg = [(g.neighbour(*g.DIRS[k]), P.rbuf[P.off[k][0]:P.off[k][4]]) for k in P.recv_order]
+        P.smsg = [(p_, P.sbuf[sspan[p_][0]:sspan[p_][1]]) for p_ in peers]
+        P.rmsg = [(p_, P.rbuf[rspan[p_][0]:rspan[p_][1]]) for p_ in peers]
         P.summary = torch.zeros(lib.PIC_GHOST_SUMMARY_WORDS, dtype=torch.int64, device=dev)
         P.ops = None
         if nd and not self.comm.stage_cpu:
             P.ops = ([dist.P2POp(dist.isend, t, p_, self.comm.group) for p_, t in P.smsg] +
                      [dist.P2POp(dist.irecv, t, p_, self.comm.group) for p_, t in P.rmsg])
+        # the tiles of a step that need nothing from a neighbour (_refresh_step_tiles): the agent kernel of a tile reads its
+        # chem window +- the probe margin and the segments of the 8 tiles around it, the field kernel the agent kernel's lists of
+        # the 9 tiles around it — one ring of interior tiles for the first, two for the second stay behind (an axis without halo:
+        # nothing to stay clear of)
+        ntx_, nty_ = g.W // TX, g.H // TY
+        hx_t, hy_t = g.hx // TX, g.hy // TY
+        def inner(ring):
+            x0, x1 = (hx_t + ring, ntx_ - hx_t - ring) if g.hx else (0, ntx_)
+            y0, y1 = (hy_t + ring, nty_ - hy_t - ring) if g.hy else (0, nty_)
+            return (x0, y0, max(x1 - x0, 0), max(y1 - y0, 0))
+        P.inner_agents, P.inner_field = inner(1), inner(2)
         return P
 
-    def _refresh_ghosts_tiles(self, action):
+    def _tile_field_rects(self, P):
+        lib, g, M = self._lib, self.geo, self.medium
+        key = (M.chem.data_ptr(), M.food.data_ptr())
+        r = P.rects.get(key)
+        if r is None:
+            send, recv = [], []
+            for k, (dx, dy) in enumerate(g.DIRS):
+                send += [_slice_rect(lib, M.chem, g._band(dx, dy), P.soff[k][2]), _slice_rect(lib, M.food, g._band(dx, dy), P.soff[k][3])]
+                recv += [_slice_rect(lib, M.chem, g._halo(dx, dy), P.roff[k][2]), _slice_rect(lib, M.food, g._halo(dx, dy), P.roff[k][3])]
+            chunk = lambda rects: [((lib.Rect * len(c))(*c), len(c)) for c in (rects[i:i + 16] for i in range(0, len(rects), 16))]
+            r = (chunk(send), chunk(recv), (M.chem, M.food))
+            P.rects[key] = r
+        return r
+
+    def _refresh_ghosts_tiles(self, action, step=None):
+        """The refresh by tiles.  `step` = (d, result): the step that follows runs inside the refresh — on the tiles that need
+        nothing from a neighbour while the messages are in flight (second stream), on the others once they have arrived
+        (BASELINE north_star: "halo exchange over xGMI overlapped with interior-tile compute on a second HIP stream")."""
         from .device_array import _ptr, stream_ptr
         A, g, comm, lib, dev, pic = self.agents, self.geo, self.comm, self._lib, self.device, self._pic
         n = A.N
@@ -851,27 +946,66 @@ class DistEnv:
         pic._n_agents = int(n)
         out = pic._out_tensors(self)
         p = pic._struct(pic.held, out)
+        cur = pic.cur
         # everything below is enqueued without looking at a count; the host reads the summary once, at the end
-        lib.check(lib.lib.die_pic_ghost_pack(C.byref(m), C.byref(p), pic.cur, nd, P.sides, _ptr(P.summary), sp), 'die_pic_ghost_pack')
+        lib.check(lib.lib.die_pic_ghost_pack(C.byref(m), C.byref(p), cur, nd, P.sides, _ptr(P.summary), sp), 'die_pic_ghost_pack')
         self._tick('band tiles packed')
-        send_r, recv_r, _ = self._ghost_field_rects(P)
+        send_r, recv_r, _ = self._tile_field_rects(P)
         sb, rb = C.c_void_p(P.sbuf.data_ptr()), C.c_void_p(P.rbuf.data_ptr())
         for arr, cnt in send_r:
             lib.check(lib.lib.die_rects_pack(arr, cnt, sb, sp), 'die_rects_pack')
         self._tick('field pack')
-        if P.ops is None:
-            comm.exchange(P.smsg, P.rmsg)
+        works = None
+        main = torch.cuda.current_stream(dev)
+        if step is not None and P.ops is not None and self._comm_stream is not None:
+            # the messages go out behind the pack kernels, on the second stream; this stream carries on with the interior
+            self._comm_stream.wait_stream(main)
+            with torch.cuda.stream(self._comm_stream):
+                works = dist.batch_isend_irecv(P.ops)
+
+        def exchange_and_unpack():
+            if works is not None:
+                for req in works:
+                    req.wait()                             # (stream-ordered: this stream waits for the messages, the host does not)
+            elif P.ops is None:
+                comm.exchange(P.smsg, P.rmsg)
+            else:
+                for req in dist.batch_isend_irecv(P.ops):
+                    req.wait()
+            self._tick('exchange (records + fields, one message per peer)')
+            self._tick(stagger=True)
+            for arr, cnt in recv_r:
+                lib.check(lib.lib.die_rects_unpack(arr, cnt, rb, sp), 'die_rects_unpack')
+            self._tick('field unpack')
+
+        def adopt_new_layout():
+            pic.cur = 1 - cur
+            pic._adopt(self, pic.agent, out)
+            if step is not None and hasattr(action, 'rebind'):
+                action.rebind(A)                           # (forward() ran before the arrays were replaced)
+
+        if step is None:
+            exchange_and_unpack()
+            lib.check(lib.lib.die_pic_ghost_merge(C.byref(m), C.byref(p), cur, nd, P.sides, self.capacity, _ptr(P.summary), sp),
+                      'die_pic_ghost_merge')
+            self._tick('new layout (scan, merge, words)')
+            adopt_new_layout()
         else:
-            for req in dist.batch_isend_irecv(P.ops):
-                req.wait()
-        self._tick('exchange (records + fields, one message per side)')
-        self._tick(stagger=True)
-        for arr, cnt in recv_r:
-            lib.check(lib.lib.die_rects_unpack(arr, cnt, rb, sp), 'die_rects_unpack')
-        self._tick('field unpack')
-        lib.check(lib.lib.die_pic_ghost_merge(C.byref(m), C.byref(p), pic.cur, nd, P.sides, self.capacity, _ptr(P.summary), sp),
-                  'die_pic_ghost_merge')
-        self._tick('new layout (scan, merge, words)')
+            d, result = step
+            # the interior tiles' segments of the new layout need nothing that arrives …
+            lib.check(lib.lib.die_pic_ghost_merge_phase(C.byref(m), C.byref(p), cur, nd, P.sides, self.capacity, _ptr(P.summary), 1, sp),
+                      'die_pic_ghost_merge_phase')
+            adopt_new_layout()
+
+            def second_half():
+                # … the halo tiles' segments, and the halo cells of the planes, do
+                exchange_and_unpack()
+                lib.check(lib.lib.die_pic_ghost_merge_phase(C.byref(m), C.byref(p), cur, nd, P.sides, self.capacity, _ptr(P.summary), 2, sp),
+                          'die_pic_ghost_merge_phase')
+            ia, if_ = P.inner_agents, P.inner_field
+            rc = pic.step(self, pic.agent, action, d, result,
+                          plan=[(1, (1,) + ia), (2, (1,) + if_), second_half, (1, (2,) + ia), (2, (2,) + if_)])
+            lib.check(rc, 'die_pic_forward_env_step')
         t = P.summary.cpu().tolist()                                   # the one host read
         self._tick('counts to host')
         n_new, kept, sent, arrived, flags = t[0], t[1], t[2:2 + nd], t[10:10 + nd], int(t[18])
@@ -885,8 +1019,6 @@ class DistEnv:
             raise RuntimeError('ghost refresh by tiles: ' + '; '.join(v for b, v in lib.PIC_GHOST_FLAGS.items() if flags & b))
         if n_new != kept + sum(arrived):
             raise RuntimeError(f'ghost refresh: device count {n_new} != {kept} owned + {sum(arrived)} arrived')
-        pic.cur = 1 - pic.cur
-        pic._adopt(self, pic.agent, out)
         if n_new > n:                                      # every slot is alive on this path; readers (gather_world) look at the bytes
             A.alive[n:n_new] = 1
         self._owned = kept
@@ -1268,6 +1400,7 @@ class DistEnv:
     def sort_agents(self):
         """Bucket-sort the local agent arrays (die_agents_sort), attached Agent state included."""
         from .device_array import _ptr, stream_ptr
+        self.flush_refresh()
         self._pic_void()
         lib, A = self._lib, self.agents
         cap = self.capacity
@@ -1320,6 +1453,7 @@ class DistEnv:
     # ------------------------------------------------------------------ gathering (tests, checkpoints)
     def gather_world(self):
         """Rank 0 gets (medium (3, gW, gH), agents (4, N_world)) in slot order; others get None."""
+        self.flush_refresh()
         g, A = self.geo, self.agents
         ri, ci = g.interior()
         tile = np.stack([self.medium.sel(c)[ri, ci].to(torch.float64).cpu().numpy() for c in self.medium.channels])

@@ -101,7 +101,7 @@ class PicState:
             lay[1 - cur] = self._layout(ot, self.meta[1 - cur])
             p = self._structs[key] = _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane),
                                               _ptr(self.part), _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code),
-                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, _ptr(self.queue))
+                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, _ptr(self.queue), 0, 0, 0, 0, 0, 0)
         L = p.layout
         L[cur].slot, L[1 - cur].slot = ct[3].data_ptr(), ot[3].data_ptr()
         p.N, p.k1_threads, p.stages, p.status_out = self._n_agents, self.k1_threads, stages, status_out
@@ -176,17 +176,21 @@ class PicState:
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None, None, 0, 0, 0, None)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),
                        'die_pic_action_physarum')
         return rebuild
 
-    def step(self, env, agent, action, dyn, result, events=None, status_out=None):
+    def step(self, env, agent, action, dyn, result, events=None, status_out=None, plan=None):
         """One step.  `events`: torch.cuda.Event objects (one more than launches: 3 in the two-launch form, 4 in the
         three-launch form) — the launches are then issued one call each (die_pic.stages) with an event between them, so
         that bench.py times each kernel inside real steps.
+
+        `plan` (two-launch form; a decomposed rank's step behind a ghost refresh, die_amd/dist.py): the step as a list of
+        launches over subsets of the tiles, `(stages, (sub_mode, tx0, ty0, ntx, nty))`, with callables in between (they run on
+        the host between two launches: wait for the messages, unpack, second half of the merge).
 
         A normalised PhysarumAgent's action is a function of what the step leaves behind (heading', deposit array), so the
         step does not store it (30 MB and 7 % of the agent kernel at 4096²): the PendingAction gets a `_rebuild` hook and
@@ -202,15 +206,33 @@ class PicState:
         two = self.two_launch(env, agent)
         g = action.g_struct
         turn_key = (int(g.seed), int(g.step))
-        for i, stages in enumerate((0,) if events is None else ((1, 2) if two else (1, 2, 4))):
+        if plan is not None:
+            if not two:
+                raise ValueError('a step over subsets of the tiles exists in the two-launch form only')
+            items = list(plan)
+        elif events is None:
+            items = [(0, None)]
+        else:
+            items = [(st, None) for st in ((1, 2) if two else (1, 2, 4))]
+        i = 0
+        for item in items:
+            if callable(item):
+                item()
+                m = env.medium.c_struct(need_owner=False)
+                continue
+            stages, sub = item
             p = self._struct(self.held, out, stages, status_out if two else None)
             p.turn_ready = int(self._turn_for == turn_key)
+            p.sub_mode, p.sub_tx0, p.sub_ty0, p.sub_ntx, p.sub_nty = sub if sub is not None else (0, 0, 0, 0, 0)
             if events is not None:
                 events[i].record()
+            i += 1
             rc = _lib.lib.die_pic_forward_env_step(C.byref(m), C.byref(p), self.cur, C.byref(action.g_struct), u, C.byref(dyn),
                                                    _ptr(result), stream_ptr(env.device))
             if rc != 0:
                 return rc
+            if (stages & 1 or stages == 0) and lazy_ok(agent):
+                self._turn_for = turn_key                      # (the agent kernel's launch has filled the table if it was not ready)
         if events is not None:
             events[2 if two else 3].record()
         # (the field kernel of the two-launch form has filled the table for the next step of this seed)

@@ -426,6 +426,12 @@ typedef struct die_pic {
     uint32_t* queue;             /* 2 device words, both 0 between steps (the library leaves them so), or NULL: the tile queue of the
                                     agent kernel's persistent form (two-launch form: a fixed grid of workgroups draws tiles from it
                                     and prefetches the next tile's agents while it works on the current one) */
+    /* ONE launch (stages = 1 or 2) over a subset of the tiles: sub_mode 0 all tiles; 1 only the rectangle [sub_tx0, sub_tx0 +
+     * sub_ntx) x [sub_ty0, sub_ty0 + sub_nty) of tiles; 2 all tiles but that rectangle — and, for stages = 2, the workgroups that
+     * complete a step (next offsets, reward, turn bits).  A decomposed rank steps the tiles that need nothing from its neighbours
+     * while its ghost refresh's messages are in flight, the others once they have arrived (die_amd/dist.py).  The caller issues
+     * every tile exactly once per stage; two-launch form only. */
+    int32_t sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty, reserved4;
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */
@@ -492,6 +498,12 @@ int die_pic_ghost_pack(const die_medium* m, const die_pic* p, int32_t from, int3
                        int64_t* summary, void* stream);
 int die_pic_ghost_merge(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
                         int64_t capacity, int64_t* summary, void* stream);
+/* The same in two halves, for a refresh whose messages travel while the next step runs on the tiles that need nothing from a
+ * neighbour: phase 1 = the interior tiles' segments (they come first in the new layout: their offsets depend on nothing that
+ * arrives; summary[1] = their total), phase 2 = the halo tiles' segments behind them, from the received counts; phase 0 = both
+ * (die_pic_ghost_merge).  Phase 1 before phase 2, die_pic_ghost_pack before both. */
+int die_pic_ghost_merge_phase(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                              int64_t capacity, int64_t* summary, int32_t phase, void* stream);
 /* Rebuild the 'agents' channel from the agent arrays: atomicMax of (m->epoch, slot) claims (deposit bits 0) for every
  * alive agent.  The caller advances m->epoch (or zeroes the plane) first. */
 int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream);

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from die_amd.dist import Comm, TileGeometry, fill_holes, halo_exchange, halo_merge_max, route_records
+from die_amd.dist import Comm, TileGeometry, fill_holes, halo_exchange, halo_merge_max, peer_message_layout, route_records
 
 
 def _free_port():
@@ -75,6 +75,41 @@ def _halo_case(rank, size, world, grid, h):
                                                 (2, (12, 16), (1, 2), (0, 4)), (4, (32, 8), (4, 1), (3, 0))])
 def test_halo_exchange_is_periodic_including_corners(size, world, grid, h):
     _run(size, _halo_case, world, grid, h)
+
+
+def _peer_message_case(rank, size, world, grid, h):
+    """ONE message per peer (die_amd/dist.py peer_message_layout, the ghost refresh by tiles): every side's block — here the
+    band cells of a plane of world cell ids plus a (sender, side) tag — must arrive as the halo block of the opposite side."""
+    g = TileGeometry(world, grid, rank, h)
+    comm = Comm()
+    gid = np.arange(world[0] * world[1], dtype=np.float32).reshape(world)
+    plane = torch.full((g.W, g.H), -1.0)
+    ri, ci = g.interior()
+    plane[ri, ci] = torch.from_numpy(gid[g.x0:g.x0 + g.Wi, g.y0:g.y0 + g.Hi])
+    nd = len(g.DIRS)
+    shapes = [tuple(sl.stop - sl.start for sl in g._band(dx, dy)) for dx, dy in g.DIRS]
+    sizes = [(2 + a * b) * 4 for a, b in shapes]                          # tag (sender, side) + the cells, float32
+    peers, soff, roff, sspan, rspan = peer_message_layout(g.DIRS, g.neighbour, sizes)
+    assert len(peers) == len({g.neighbour(dx, dy) for dx, dy in g.DIRS}) and sum(b - a for a, b in sspan.values()) == sum(sizes)
+    sbuf, rbuf = torch.zeros(sum(sizes) // 4), torch.full((sum(sizes) // 4,), -7.0)
+    for k, (dx, dy) in enumerate(g.DIRS):
+        blk = plane[g._band(dx, dy)].reshape(-1)
+        sbuf[soff[k] // 4:soff[k] // 4 + 2] = torch.tensor([float(rank), float(k)])
+        sbuf[soff[k] // 4 + 2:(soff[k] + sizes[k]) // 4] = blk
+    comm.exchange([(p, sbuf[sspan[p][0] // 4:sspan[p][1] // 4]) for p in peers], [(p, rbuf[rspan[p][0] // 4:rspan[p][1] // 4]) for p in peers])
+    for k, (dx, dy) in enumerate(g.DIRS):
+        tag = rbuf[roff[k] // 4:roff[k] // 4 + 2].tolist()
+        assert tag == [float(g.neighbour(dx, dy)), float(nd - 1 - k)], f'rank {rank} side {k}: block of {tag}'
+        plane[g._halo(dx, dy)] = rbuf[roff[k] // 4 + 2:(roff[k] + sizes[k]) // 4].reshape(shapes[k])
+    ix = (np.arange(g.W) + g.ox) % world[0]
+    iy = (np.arange(g.H) + g.oy) % world[1]
+    assert np.array_equal(plane.numpy(), gid[ix][:, iy]), f'rank {rank}: halo mismatch'
+
+
+@pytest.mark.parametrize('size,world,grid,h', [(2, (12, 16), (1, 2), (0, 4)), (2, (16, 12), (2, 1), 4), (4, (16, 24), (2, 2), 5),
+                                                (4, (32, 8), (4, 1), (3, 0)), (1, (8, 8), (1, 1), 3)])
+def test_one_message_per_peer_carries_every_side_to_its_opposite(size, world, grid, h):
+    _run(size, _peer_message_case, world, grid, h)
 
 
 def _value(q, gx, gy):

@@ -83,7 +83,8 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
             env.check()
         if rank == 0:
             np.savez(out_path, medium=world[0], agents=world[1], rewards=np.array(rewards), pic_steps=getattr(env, 'pic_steps', 0),
-                     plane=np.array([env.geo.W, env.geo.H]), tile_refreshes=getattr(env, 'tile_refreshes', 0))
+                     plane=np.array([env.geo.W, env.geo.H]), tile_refreshes=getattr(env, 'tile_refreshes', 0),
+                     overlapped=getattr(env, 'overlapped_refreshes', 0))
     finally:
         dist.destroy_process_group()
 
@@ -167,15 +168,19 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
     assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
 
 
+@pytest.mark.parametrize('overlap', [False, True])
 @pytest.mark.parametrize('grid,refresh_every,backend,wave,plane', [
     ((2, 2), 2, 'gloo', False, (320, 256)), ((1, 2), 3, 'gloo', True, (384, 256)), ((2, 1), 2, 'gloo-f16', False, (320, 256)),
     ((1, 1), 4, 'nccl', False, (384, 256)), ((1, 2), 2, 'gloo', 'limit', (384, 256))])
-def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_every, backend, wave, plane):
+def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_every, backend, wave, plane, overlap):
     """A rank of the ghost-agent decomposition takes the step the single GPU takes: the tile-binned two-launch step on its
     padded tile (die_pic.hip TILED: agents binned by the plane cell that holds their world cell, ownership-masked reward,
     probes clamped at the WORLD's edge; the halo is rounded up until the planes split into whole tiles); the refresh goes
     by tiles and leaves the tile order intact.  Every slot alive (the binned step's precondition).  Gathered world and rewards equal the single-device
-    run bit for bit; the worker reports how many of its steps took the binned path: all of them."""
+    run bit for bit; the worker reports how many of its steps took the binned path: all of them.
+    `overlap`: a refresh is left for the step that follows it and its messages (one per peer) travel under that step's interior
+    tiles — agent kernel and field kernel on the tiles that need nothing from a neighbour, then the halo tiles' segments, then
+    both kernels on the rest (DistEnv._refresh_ghosts_tiles(step=...)): the same bits."""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import torch.multiprocessing as mp
@@ -184,13 +189,15 @@ def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_ever
     size = grid[0] * grid[1]
     f16 = backend.endswith('-f16')
     backend = backend.replace('-f16', '')
-    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, False, refresh_every, out, backend, True, wave, f16),
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, overlap, refresh_every, out, backend, True, wave, f16),
              nprocs=size, join=True)
     got = np.load(out)
     assert int(got['pic_steps']) == steps, 'the ranks did not take the tile-binned step'
     assert tuple(got['plane']) == plane                     # (halo rounded up so that the planes are whole tiles)
     # every refresh after a step went by tiles (csrc/die_pic_refresh.hip: no per-agent classification, no re-bin afterwards)
     assert int(got['tile_refreshes']) == (steps // refresh_every if size > 1 else 0)
+    # … and, with overlap, inside the step that followed (the last one, if the run ends on a refresh, is flushed by the reader)
+    assert int(got['overlapped']) == ((steps - 1) // refresh_every if size > 1 and overlap else 0)
     m, a, r = _single_device_run(W, H, N, N, steps, wave, f16)
     assert np.array_equal(got['agents'], a)
     for c in range(3):
@@ -308,7 +315,7 @@ def _full_worker(rank, size, port, grid, W, H, steps, sort_every, refresh_every,
         agents = np.load(os.path.join(tmp, 'agents.npy'), mmap_mode='r')
         dir0 = np.load(os.path.join(tmp, 'dir0.npy'))
         env = DistEnv.from_global_numpy(medium, agents, grid, None, probe_reach=11, device='cuda:0', sort_every=sort_every,
-                                        overlap=False, migrate_every=refresh_every, max_step_cells=1.6, ghosts=True,
+                                        overlap=True, migrate_every=refresh_every, max_step_cells=1.6, ghosts=True,
                                         ghost_headroom=1.3)
         del medium, agents
         agent = die_amd.PhysarumAgent(max_agents=env.capacity, seed=3, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
@@ -320,9 +327,10 @@ def _full_worker(rank, size, port, grid, W, H, steps, sort_every, refresh_every,
         for _ in range(steps):
             obs, res = env.step(agent.forward(obs))
             rewards.append(env.read_result(res))
+        assert env.overlapped_refreshes == (steps - 1) // refresh_every       # (the refresh travelled under the step that followed it)
+        own = env.owned_mask()
         g, A, n = env.geo, env.agents, env.agents.N
         ri, ci = g.interior()
-        own = env.owned_mask()
         np.savez(os.path.join(tmp, f'rank{rank}.npz'), x0=g.x0, y0=g.y0,
                  occ=env.medium.occupied()[ri, ci].cpu().numpy(), food=env.medium.food[ri, ci].cpu().numpy(),
                  chem=env.medium.chem[ri, ci].cpu().numpy(), slots=A.slot[:n][own].cpu().numpy(),
