@@ -77,6 +77,7 @@ def parse():
     p.add_argument('--dist-mode', choices=['ghost', 'guard'], default='ghost',
                    help='decomposed runs: ghost = communication-avoiding (ghost agents, nothing crosses ranks for M steps); '
                         'guard = claims merged and halos exchanged every step, strays handed over every M steps')
+    p.add_argument('--no-refresh-overlap', action='store_true', help='decomposed ghost-agent runs: refresh right behind its step (default: the refresh waits for the next step and its messages travel under that step\'s interior tiles)')
     p.add_argument('--no-pic', action='store_true', help='classic step (claim plane + bucket sort) instead of the tile-binned one')
     p.add_argument('--pic-tile', default='', help='tuning: log2 tile shape of the tile-binned step, e.g. 6,6')
     p.add_argument('--pic-threads', type=int, default=0, help='tuning: workgroup size of the tile-binned agent kernel')
@@ -402,7 +403,8 @@ def main():
         denv = DistEnv((gW, gH), grid, die_amd.Dynamics(init_agent_ratio=args.ratio), probe_reach=11,
                        device=device, seed=args.seed, sort_every=8 if args.sort_every is None else args.sort_every,
                        migrate_every=args.migrate_every, max_step_cells=1.6, ghosts=args.dist_mode == 'ghost',
-                       ghost_headroom=1.3)     # the synthetic world stays uniform (measured fill 0.5 of 2x over 1200 steps)
+                       ghost_headroom=1.3,     # the synthetic world stays uniform (measured fill 0.5 of 2x over 1200 steps)
+                       overlap=not args.no_refresh_overlap)
         how = (f'ghost agents, halo ({denv.geo.hx}, {denv.geo.hy}) re-seated every {denv.migrate_every} steps' if denv.ghosts else
                f'halo {denv.geo.h}, claims merged every step, strays handed over every {denv.migrate_every} steps')
         mode = (f'{grid[0]}x{grid[1]} domain decomposition of a {gW}x{gH} torus, {how}, '
@@ -456,6 +458,7 @@ def main():
 
     dt, res, per_step, n_pre = timed_run(env, agent)
     last_reward, last_alive = env.read_result(res)
+    env.check()                # (the tile-binned step's sticky error word: a loop that reads nothing back has to ask)
     K = env.agents.N
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -487,7 +490,8 @@ def main():
             line['config']['ghost_message_fill_max_rank0'] = round(denv.ghost_fill, 3)
         # which step and which refresh the ranks took (rank 0's counts over the whole run: pre-warm, warm-up, timed steps)
         line['config'].update(steps_total_rank0=int(denv._steps), tile_binned_steps_rank0=int(getattr(denv, 'pic_steps', 0)),
-                              refreshes_by_tiles_rank0=int(getattr(denv, 'tile_refreshes', 0)))
+                              refreshes_by_tiles_rank0=int(getattr(denv, 'tile_refreshes', 0)),
+                              refreshes_under_the_next_steps_interior_rank0=int(getattr(denv, 'overlapped_refreshes', 0)))
         line['roofline'] = {'bound': 'hbm', 'kernel': 'whole step (all ranks)', 'achieved': round(Bw / (dt / args.steps) / 1e9, 1),
                             'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': round(Bw / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
                             'traffic': None, 'algorithmic_bytes_per_launch': Bw}

@@ -707,8 +707,8 @@ class DistEnv:
         return self._tile_refresh_applies()
 
     def flush_refresh(self):
-        """A ghost refresh that was left for the next step (to travel under its interior tiles) is done NOW: somebody wants to
-        look at the agents or the fields between two steps."""
+        """A ghost refresh that was left for the next step (to travel under its interior tiles) is done NOW.  COLLECTIVE: every rank
+        must call it (gather_world does; the rank-local observers — owned_mask, check, read_result — need no refresh)."""
         if self._refresh_due:
             self._refresh_due = False
             self._refresh_ghosts(self._refresh_action, after_step=True)
@@ -771,7 +771,6 @@ class DistEnv:
 
     def check(self):
         """Synchronise; raise if the tile-binned step reported a bookkeeping error since the last check."""
-        self.flush_refresh()
         torch.cuda.synchronize(self.device)
         if self._pic is not None and self._pic.steps_since_check:
             self._pic.check()
@@ -807,8 +806,8 @@ class DistEnv:
         return (cx - g.x0) % g.gW, (cy - g.y0) % g.gH
 
     def owned_mask(self) -> torch.Tensor:
-        """Which local agents this rank accounts for (ghost mode: those standing on interior cells)."""
-        self.flush_refresh()
+        """Which local agents this rank accounts for (ghost mode: those standing on interior cells — also true while a refresh is
+        waiting for the next step: every agent on an interior cell is a valid copy)."""
         if not self.ghosts:
             return torch.ones(self.agents.N, dtype=torch.bool, device=self.device)
         lx, ly = self._cells()
@@ -1400,8 +1399,7 @@ class DistEnv:
     def sort_agents(self):
         """Bucket-sort the local agent arrays (die_agents_sort), attached Agent state included."""
         from .device_array import _ptr, stream_ptr
-        self.flush_refresh()
-        self._pic_void()
+        self._pic_void()                   # (a refresh that waits for the next step then goes agent by agent: the tile order is gone)
         lib, A = self._lib, self.agents
         cap = self.capacity
         if self._shadow is None:

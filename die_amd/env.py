@@ -456,7 +456,8 @@ class Env(_EnvBase):
         status = getattr(self, '_status_word', None)
         two = self._pic.two_launch(self, ag)
         _lib.check(self._pic.step(self, ag, action, self._c_dynamics(), result, getattr(self, '_pic_events', None),
-                                  status_out=status.data_ptr() + 16 if status is not None and two else None),
+                                  status_out=status.data_ptr() + 16 if status is not None and two else None,
+                                  plan=getattr(self, '_pic_plan', None)),       # (scratch/split_step_cost.py: the step as launches over subsets of the tiles)
                    'die_pic_forward_env_step')
         self._pic_status_written = status is not None and two
         ag._forward_consumed(action)
