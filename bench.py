@@ -233,6 +233,29 @@ def copy_ceiling_gbs(device, mb=512, reps=10):
     return 2.0 * (mb << 20) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
 
 
+def stream_ceiling_gbs(device, mb=512, reps=20):
+    """The in-tree streaming copy (die_stream_copy: one 16-byte vector per thread) through the C ABI: read + written bytes per
+    second — what this box's GPU moves when nothing but a stream is asked of it (MI355X_MICROARCH.md measures
+    6.29 TB/s for a float4 copy; the shapes that do worse: scratch/kbench_dma/copy_sweep.hip)."""
+    import ctypes as C
+    import torch
+    from die_amd import _lib
+    from die_amd.device_array import _ptr, stream_ptr
+    src = torch.zeros(mb << 20, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    call = lambda: _lib.check(_lib.lib.die_stream_copy(_ptr(src), _ptr(dst), mb << 20, stream_ptr(torch.device(device))), 'die_stream_copy')
+    for _ in range(3):
+        call()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        call()
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * (mb << 20) * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def side_measurements(args, device, agent_kw, torch, die_amd):
     """What the headline does not show: the same workload (a) through the Gym API's synchronous form —
     `Env(sync=True)`: float reward + info dict, i.e. one host read per step — and (b) with the reference's default slot
@@ -241,11 +264,15 @@ def side_measurements(args, device, agent_kw, torch, die_amd):
     W = H = args.size
     dt_f = torch.float16 if args.fields == 'f16' else torch.float32
     out = {}
-    for name, kw, n in (('sync_true_steps_per_s', dict(max_agents='alive', sync=True), 100),
-                        ('reference_default_slots_steps_per_s', dict(max_agents=None, sync=False), 30)):
+    # (c) SURVEY §8(d)'s stress case: the LITERAL normalised parameters of examples/minimal_run.py:42 (sense_offset .04, scale
+    #     .006 — a 164-cell probe and a 25-cell step at 4096²) instead of the cell-unit-constant ones; with the path it took
+    literal = dict(agent_kw, sense_offset=0.04, scale=0.006)
+    for name, kw, n, akw in (('sync_true_steps_per_s', dict(max_agents='alive', sync=True), 100, agent_kw),
+                             ('reference_default_slots_steps_per_s', dict(max_agents=None, sync=False), 30, agent_kw),
+                             ('literal_normalised_parameters_steps_per_s', dict(max_agents='alive', sync=False), 60, literal)):
         try:
             env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed, device=device, field_dtype=dt_f, **kw)
-            agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **agent_kw)
+            agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **akw)
             obs = env._get_current_obs
             for _ in range(max(20, n // 2)):
                 obs, *_ = env.step(agent.forward(obs))
@@ -257,6 +284,11 @@ def side_measurements(args, device, agent_kw, torch, die_amd):
             out[name] = round(n / (time.perf_counter() - t0), 1)
             if kw['max_agents'] is None:
                 out['reference_default_slots'] = int(env.agents.N)
+            if akw is literal:
+                binned = getattr(env, '_pic', None) is not None and env._pic.held is not None
+                out['literal_normalised_parameters'] = {'sense_offset': 0.04, 'scale': 0.006, 'probe_cells': round(0.04 * (W - 1), 1), 'step_cells': round(0.006 * (W - 1), 1),
+                                                        'path': ('tile-binned, ' + ('two' if env._pic.two_launch(env, agent) else 'three') + ' launches') if binned
+                                                        else 'classic step (claim plane, re-sort every 8 steps): the probe reaches further than the 24 cells the tile-binned agent kernel stages'}
             del env, agent, obs
             torch.cuda.empty_cache()
         except Exception as e:               # a side measurement never takes the headline down
@@ -535,7 +567,9 @@ def main():
             'avg_launch_us': round(kt[dom], 2), 'algorithmic_bytes_per_launch': B[dom],
             'kernels_us': {k: round(v, 2) for k, v in kt.items()},
             'kernels_gbs': {k: round(B[k] / (v * 1e-6) / 1e9, 1) for k, v in kt.items()},
-            'copy_ceiling_gbs': round(copy_ceiling_gbs(device), 1),
+            'copy_ceiling_gbs': round(copy_ceiling_gbs(device), 1),               # torch's uint8 copy_ (rounds 1-3 quoted this)
+            'stream_ceiling_gbs': round(stream_ceiling_gbs(device), 1),           # die_stream_copy, 16 bytes per lane, through the C ABI
+            'kernels_frac_of_peak': {k: round(B[k] / (v * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) for k, v in kt.items()},
             'empty_event_interval_us': None if empty_interval is None else round(empty_interval, 2),
             'kernel_event_intervals_us': {k: round(v, 2) for k, v in intervals.items()},
             # the whole step on BOTH byte bases: the contract's B = 12·C + 104·K (action W + R included) and
@@ -548,6 +582,8 @@ def main():
                      'frac': round(B['step'] / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                      'frac_median_step': round(B['step'] / (med * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        sc = line['roofline']['stream_ceiling_gbs']
+        line['roofline']['kernels_frac_of_stream_ceiling'] = {k: round(v / sc, 4) for k, v in line['roofline']['kernels_gbs'].items()}
         line['config']['chem_max_after_timed_steps'] = round(float(env.medium.chem.float().max().item()), 4)
         if not args.no_extras:
             line['config']['side_measurements'] = side_measurements(args, device, agent_kw, torch, die_amd)

@@ -114,3 +114,40 @@ extern "C" int die_records_scatter(void* const* arrays, const int32_t* elem_byte
                                    const int32_t* records_in, void* stream) {
     return records(arrays, elem_bytes, n, idx, count, (int32_t*)records_in, false, stream, "die_records_scatter");
 }
+
+
+// ---- a plain streaming copy, for the bench's ceiling ------------------------------------------------------------------
+// What this GPU moves when nothing but a stream is asked of it: ONE 16-byte vector per thread, bytes / 4096 workgroups of 256
+// threads.  The shape matters (scratch/kbench_dma/copy_sweep.hip, 512 MB, one MI355X): this one 6.21 TB/s (MI355X_MICROARCH.md:
+// 6.29 for a float4 copy); a workgroup per contiguous slice with four vectors in flight 5.35–5.69; grid-stride loops of 1 024 –
+// 16 384 workgroups 4.3–5.4; hipMemcpyAsync / torch's copy_ 4.8–4.9 (the "copy ceiling" rounds 1–3 quoted).  Short-lived
+// workgroups dispatched in address order sweep the memory sequentially; a grid-stride loop makes every workgroup hop through the
+// whole buffer.  bench.py times it through the C ABI and quotes both step kernels against it (roofline.stream_ceiling_gbs).
+__global__ __launch_bounds__(256) void k_stream_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+extern "C" int die_stream_copy(const void* src, void* dst, int64_t bytes, void* stream) {
+    DIE_REQUIRE(src && dst && bytes > 0 && bytes % 16 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0,
+                "die_stream_copy: 16-byte aligned buffers of a multiple of 16 bytes");
+    const int64_t n = bytes / 16, g = (n + 255) / 256;
+    DIE_REQUIRE(g < ((int64_t)1 << 31), "die_stream_copy: at most 2^31 workgroups (8 TiB)");
+    k_stream_copy<<<(unsigned)g, 256, 0, (hipStream_t)stream>>>((const uint4*)src, (uint4*)dst, n);
+    DIE_CHECK_LAUNCH("die_stream_copy");
+    return DIE_OK;
+}
+
+// The device address of pinned host memory (hipHostGetDevicePointer) through the runtime instance this library is linked
+// against — the one that launches the kernels.  die_amd/env.py uses it for the synchronous step's result buffer (round 3 opened
+// libamdhip64 by its SONAME with ctypes: on another ROCm that can load a second runtime into the process — ADVICE r3).
+extern "C" int die_host_device_pointer(void* host, int32_t device, void** dev_out) {
+    DIE_REQUIRE(host && dev_out, "die_host_device_pointer: null argument");
+    int cur = -1;
+    hipError_t e = hipGetDevice(&cur);
+    if (e == hipSuccess && device >= 0 && device != cur) e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(dev_out, host, 0);
+    if (cur >= 0 && device >= 0 && device != cur) (void)hipSetDevice(cur);
+    if (e != hipSuccess) { (void)hipGetLastError(); die_set_error("die_host_device_pointer: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
+    return DIE_OK;
+}

@@ -368,19 +368,16 @@ class Env(_EnvBase):
             try:
                 if os.environ.get('DIE_HOST_RESULT', '1') != '0':
                     buf = torch.zeros(3, dtype=torch.float64).pin_memory()
-                    # (the runtime instance torch and libdie_hip.so already share: asked for by its SONAME first)
-                    hip = None
-                    for name in ('libamdhip64.so.7', 'libamdhip64.so'):
-                        try:
-                            hip = C.CDLL(name)
-                            break
-                        except OSError:
-                            continue
+                    # (through libdie_hip.so: the HIP runtime instance that launches the kernels; queried on THIS env's device)
                     dev = C.c_void_p()
-                    if hip is not None and hip.hipHostGetDevicePointer(C.byref(dev), C.c_void_p(buf.data_ptr()), 0) == 0 \
-                            and dev.value == buf.data_ptr():
+                    rc = _lib.lib.die_host_device_pointer(C.c_void_p(buf.data_ptr()), self.device.index if self.device.index is not None else -1, C.byref(dev))
+                    if rc == 0 and dev.value == buf.data_ptr():
                         self._host_res, self._host_i64 = buf, buf.numpy().view(np.int64)
-            except Exception:
+                    else:
+                        logging.getLogger('die_amd').info('Env(sync=True): no device-visible host buffer (%s): the step result is read by copy',
+                                                          _lib.lib.die_last_error().decode() if rc else 'address differs on the device')
+            except Exception as e:
+                logging.getLogger('die_amd').info('Env(sync=True): the step result is read by copy (%s: %s)', type(e).__name__, e)
                 self._host_res = self._host_i64 = None
         return self._host_res
 

@@ -585,6 +585,14 @@ int die_ghost_apply(void* const* arrays, const int32_t* elem_bytes, int32_t n_ar
                     const int64_t* caps, const int64_t* hdr_off, const int64_t* rec_off, const void* recv_buf,
                     const int32_t* holes, const void* plan_ws, int64_t n_local, int64_t capacity, int64_t* n_new_out, void* stream);
 
+/* A plain streaming copy of `bytes` (a multiple of 16; both buffers 16-byte aligned) device bytes, 16 bytes per lane: what bench.py
+ * measures as this GPU's streaming ceiling (roofline.stream_ceiling_gbs), beside the 8 TB/s peak.  No reference counterpart. */
+int die_stream_copy(const void* src, void* dst, int64_t bytes, void* stream);
+
+/* Device-visible address of pinned host memory on `device` (-1: the current one), through the HIP runtime this library is linked
+ * against (hipHostGetDevicePointer).  Env(sync=True) lets the step's last kernel write its three result words there. */
+int die_host_device_pointer(void* host, int32_t device, void** dev_out);
+
 #ifdef __cplusplus
 }
 #endif
