@@ -164,6 +164,7 @@ _SIGNATURES = {
     'die_render_frames': (C.c_int, [_P(Medium), C.c_void_p, C.c_float, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     'die_rects_pack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
+    'die_pic_two_launch': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]),
     'die_stream_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_host_device_pointer': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     'die_rects_unpack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),

@@ -19,30 +19,37 @@ from ..device_array import DeviceAction, _ptr, stream_ptr
 from .base import Agent, save_args
 
 
+_CHECKPOINT_KEYS = ('params_dict', 'model_state')      # the layout of a saved agent (core/agent/evo.py:24-42): kept, so that files interchange
+
+
 class TorchAgent(Agent, nn.Module):
-    """core/agent/evo.py:18-42."""
+    """An agent whose behaviour is a torch model (core/agent/evo.py:18-42): `save` writes the constructor arguments and the
+    model's state_dict under the reference's two keys, `load` rebuilds the agent from them."""
 
     @property
     @abstractmethod
     def model(self) -> nn.Module:
-        pass
+        """The module whose parameters the evolution loop edits."""
 
     def save(self, file: Union[str, os.PathLike, io.IOBase]):
-        th.save(dict(params_dict=self.init_params, model_state=self.model.state_dict()), file)
+        th.save(dict(zip(_CHECKPOINT_KEYS, (self.init_params, self.model.state_dict()))), file)
 
     @classmethod
     def load(cls, file: Union[str, os.PathLike, io.IOBase]):
-        loaded = th.load(file)
-        params_dict = dict(loaded['params_dict'])
-        kwargs = params_dict.pop('model_kwargs', {})
-        agent = cls(**params_dict, **kwargs)
-        agent.model.load_state_dict(loaded['model_state'])
-        return agent
+        ctor_args, weights = (th.load(file)[k] for k in _CHECKPOINT_KEYS)
+        ctor_args = dict(ctor_args)
+        ctor_args.update(ctor_args.pop('model_kwargs', {}))            # **model_kwargs of NeuralAutomataAgent are stored nested
+        restored = cls(**ctor_args)
+        restored.model.load_state_dict(weights)
+        return restored
 
 
 class ConvolutionModel(nn.Module):
-    """core/agent/evo.py:45-118: bias-free Conv2d kernels of the given sizes with 'same' padding (circular by default),
-    all but the last mapping obs channels to obs channels, then Tanh; an (inverted-)dropout mask over cells."""
+    """The perception model of core/agent/evo.py:45-118: a stack of bias-free 'same'-padded Conv2d layers (one per entry of
+    `kernel_sizes`; every layer keeps the observation channels except the last, which maps them to the action channels), a Tanh
+    that brings the outputs into [-1, 1], and an (inverted-)dropout mask over cells.  The submodule names `kernels.<i>` and
+    `agent_dropout` are the reference's, so state_dicts interchange; the device path (NeuralAutomataAgent.sense) reads the
+    layers' weights and never calls this module's forward."""
 
     def __init__(self,
                  num_obs_channels: int = 3,
@@ -54,30 +61,29 @@ class ConvolutionModel(nn.Module):
                  ):
         self._init_params = save_args(self.__init__, locals())
         super().__init__()
-        num_kernels = len(kernel_sizes)
-        input_channels = [num_obs_channels] * num_kernels
-        kernel_channels = [num_obs_channels] * (num_kernels - 1) + [num_act_channels]
-        kernels = [nn.Conv2d(in_channels=i, out_channels=o, kernel_size=k, padding='same', padding_mode=boundary, bias=False)
-                   for i, k, o in zip(input_channels, kernel_sizes, kernel_channels)]
-        kernels.append(nn.Tanh())           # outputs normalised into [-1, 1]
-        self.agent_dropout = nn.Dropout(p=p_agent_dropout)
-        self.kernels = nn.Sequential(*kernels)
+        depth = len(kernel_sizes)
+        stack = nn.Sequential()
+        for level, size in enumerate(kernel_sizes):
+            widens_to_actions = level == depth - 1
+            stack.append(nn.Conv2d(num_obs_channels, num_act_channels if widens_to_actions else num_obs_channels, size,
+                                   padding='same', padding_mode=boundary, bias=False))
+        stack.append(nn.Tanh())
+        self.agent_dropout = nn.Dropout(p_agent_dropout)
+        self.kernels = stack
         self.requires_grad_(requires_grad)
 
+    def conv_layers(self):
+        return [layer for layer in self.kernels if isinstance(layer, nn.Conv2d)]
+
     def init_weights(self):
-        for kernel in self.kernels:
-            if hasattr(kernel, 'weight'):
-                nn.init.xavier_uniform_(kernel.weight)
+        for layer in self.conv_layers():
+            nn.init.xavier_uniform_(layer.weight)
 
     def forward(self, input: th.Tensor) -> th.Tensor:
-        """The torch evaluation of the model (what the reference runs; used here by tests as the fp32 reference of the
-        device path and by callers that hold plain tensors)."""
-        sense_transform = self.kernels(input)
-        dropout_mask = self.agent_dropout(th.ones(input.shape[2:], device=input.device))
-        return sense_transform * dropout_mask
-
-    def conv_layers(self):
-        return [k for k in self.kernels if isinstance(k, nn.Conv2d)]
+        """The torch evaluation (what the reference runs; here the fp32 reference of the device path in tests, and for callers
+        that hold plain tensors): the cells' dropout mask is drawn on the field's own device."""
+        keep = self.agent_dropout(th.ones(input.shape[-2:], device=input.device, dtype=input.dtype))
+        return self.kernels(input) * keep
 
 
 class NeuralAutomataAgent(TorchAgent):

@@ -90,6 +90,14 @@ class BatchedEnv:
         b = _lib.Batch(self.R, 0, self.W * self.H, self.Nmax, 1, (C.c_int64 * 64)(*self.n))
         return m, a, dyn, b
 
+    def check(self):
+        """Synchronise; raise if a replica's tile-binned step reported a bookkeeping error since the last check (per-replica
+        regime: every replica is an `Env` of its own; the one-launch-pair regime runs the classic kernels, which have no such word)."""
+        torch.cuda.synchronize(self.device)
+        if self.per_replica:
+            for e in self.envs:
+                e.check()
+
     def step(self, agent: 'BatchedPhysarumAgent', results: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One step of every replica: `agent.forward` + `Env.step` fused, two launches for the whole batch.  Returns the
         (R, 2) float64 tensor of die_step_result words (device; `read_results` decodes)."""

@@ -1885,6 +1885,22 @@ extern "C" int64_t die_pic_rim_cap(int32_t tile_xs, int32_t tile_ys) {
     return (1 << tile_xs) * (1 << tile_ys) >= 4096 ? KbShape<6, 6>::RIM_CAP : KbShape<4, 5>::RIM_CAP;
 }
 
+// Does a step with these parameters take the two-launch form (given rim lists)?  ONE place for the rule: the step below and the
+// host side (die_amd/pic.py: whether the deposit plane of the three-launch form has to exist, whether status_out is written).
+static bool pic_two_launch_rule(int worldmax, int tile_xs, int tile_ys, float scale, float diffuse_sigma, int diffuse_mode) {
+    const int TX = 1 << tile_xs, TY = 1 << tile_ys;
+    const float reach = fabsf(scale) * (float)(worldmax - 1);
+    const int R = (int)(4.0 * (double)diffuse_sigma + 0.5);
+    // an agent changes cell by at most floor(reach) + 1 per axis (+ 1 across the world's seam, where cell W − 1 and cell 0 are the
+    // same point of the coordinate circle — labels linspace(0, 1, W), core/data_init.py:95-112) and must not come within R cells
+    // of the FAR border of the tile it walks onto
+    return diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 && (int)floorf(reach) + 2 + R <= (TX < TY ? TX : TY);
+}
+extern "C" int32_t die_pic_two_launch(int32_t world_max, int32_t tile_xs, int32_t tile_ys, float scale, float diffuse_sigma, int32_t diffuse_mode) {
+    if (!pic_shape_ok(tile_xs, tile_ys) || world_max < 2) return -1;
+    return pic_two_launch_rule(world_max, tile_xs, tile_ys, scale, diffuse_sigma, diffuse_mode) ? 1 : 0;
+}
+
 extern "C" int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys) {
     if (W < 1 || H < 1 || !pic_shape_ok(tile_xs, tile_ys)) return -1;
     return (int64_t)(W >> tile_xs) * (H >> tile_ys);
@@ -2096,10 +2112,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
     // FAR border of the tile it walks onto
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
-    const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr && d->diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 &&
-                     (int)floorf(reach) + 2 + R <= (TX < TY ? TX : TY);     // (+ 2: floor(reach) + 1 cells by the move itself, one more
-                     // across the world's seam, where cell W − 1 and cell 0 are the same point of the coordinate circle — labels
-                     // linspace(0, 1, W), core/data_init.py:95-112 — and an agent's cell index jumps by one extra)
+    const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr &&
+                     pic_two_launch_rule(worldmax, p->tile_xs, p->tile_ys, g->scale, d->diffuse_sigma, d->diffuse_mode);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
     DIE_REQUIRE(two || !p->sub_mode, "die_pic_forward_env_step: subsets of the tiles exist in the two-launch form only");
     if (tiled && !(two && stage)) {

@@ -1437,6 +1437,8 @@ class DistEnv:
         """World-wide (reward, num_agents): scalar all-reduce of the local results.  Ghost mode also sums the owned
         agents counted at the last refresh: every world agent must have exactly one owner."""
         host = result.cpu()
+        if self._pic is not None and self._pic.steps_since_check:      # the tile-binned step's sticky error word: the stream is idle now,
+            self._pic.check()                                          # one more 4-byte read (ADVICE r3: a loop that only reads results never saw it)
         owned = float(self._owned) if (self.ghosts and self._owned is not None) else -1.0
         trip = torch.tensor([float(host[0]), float(int(host.view(torch.int64)[1])), owned], dtype=torch.float64)
         if not self.comm.stage_cpu:

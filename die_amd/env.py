@@ -49,6 +49,34 @@ class BoundaryCondition(Enum):
     limit = 'limit'
 
 
+class ActionView(np.ndarray):
+    """The (3, N) host action as a numpy array that answers the label-based calls of the reference's xarray action
+    (core/base_types.py: channels dx, dy, deposit1): `.sel(channel='dx')`, `.sel(channel=['dx', 'dy'])`, `.coords['channel']`,
+    `.values`, `.to_numpy()` — enough for a CostOperator written against the reference (core/env.py:29-39)."""
+    CHANNELS = ('dx', 'dy', 'deposit1')
+
+    def __new__(cls, data):
+        return np.asarray(data, dtype=np.float64).view(cls)
+
+    def sel(self, channel=None, **kw):
+        if kw or channel is None:
+            raise NotImplementedError('ActionView.sel selects by channel only')
+        if isinstance(channel, str):
+            return np.asarray(self)[self.CHANNELS.index(channel)].view(np.ndarray)
+        return np.asarray(self)[[self.CHANNELS.index(c) for c in channel]].view(np.ndarray)
+
+    @property
+    def coords(self):
+        return {'channel': np.array(self.CHANNELS), 'index': np.arange(self.shape[1])}
+
+    @property
+    def values(self):
+        return np.asarray(self)
+
+    def to_numpy(self):
+        return np.asarray(self)
+
+
 def linear_action_cost(action, weights=(0.02, 0.01)):
     """core/env.py:29-35 — marker for the device cost operator (evaluated in k_move_claim);
     callable on a (3, N) numpy array for host-side use."""
@@ -153,6 +181,7 @@ class Env(_EnvBase):
             self._alloc_sort_buffers()      # no step of a timed loop pays for allocations
         self._fuse_forward = True           # False once die_forward_env_step reports the shape unsupported
         self._pic = None                    # PicState, built at the first eligible step
+        self._host_read_pending = False     # Env(sync=True): a step's result words were requested and not read yet
         self._pic_status_written = False    # the last step copied the binned step's error word behind its result
         self._status_word = None
         self._frozen = None                 # compat='reference' with agents_die: (x, y, alive, K) the stale indexer sees
@@ -258,9 +287,11 @@ class Env(_EnvBase):
 
     def _custom_cost(self, action):
         """`Dynamics.op_action_cost` as an arbitrary callable (core/env.py:43,209: any CostOperator): evaluated on the host on
-        the (3, N) action in slot order, like `op_food_flow` — a round trip per step.  Returns the (N,) device tensor of costs."""
+        the (3, N) action in slot order, like `op_food_flow` — a round trip per step.  The operator receives a numpy array that
+        also answers the xarray calls the reference's own operators make (`action.sel(channel=[...])`, core/env.py:29-35), so a
+        CostOperator written against the reference runs unchanged.  Returns the (N,) device tensor of costs."""
         a = action.to_numpy() if hasattr(action, 'to_numpy') else np.asarray(action, dtype=np.float64)
-        burned = np.asarray(self.dynamics.op_action_cost(a), dtype=np.float64).reshape(-1)
+        burned = np.asarray(self.dynamics.op_action_cost(ActionView(a)), dtype=np.float64).reshape(-1)
         if burned.shape[0] != self.agents.N:
             raise ValueError(f'op_action_cost returned {burned.shape[0]} values for {self.agents.N} slots')
         return torch.from_numpy(burned.astype(np.float32)).to(self.device)
@@ -286,7 +317,12 @@ class Env(_EnvBase):
         host = self._sync and burned is None and self._host_result_buffer() is not None
         if host:
             res3 = self._host_res
+            if self._host_read_pending:
+                # the previous step's words were never waited for (it raised between its launch and its read): its last kernel
+                # may still be on its way and would satisfy THIS step's wait with the old values — let it finish first
+                torch.cuda.synchronize(self.device)
             self._host_i64[0], self._host_i64[1], self._host_i64[2] = _HOST_SENTINEL_NAN, -1, -1
+            self._host_read_pending = True
         else:
             res3 = torch.empty(3, dtype=torch.float64, device=self.device) if self._sync else None
         result = res3[:2] if res3 is not None else torch.empty(2, dtype=torch.float64, device=self.device)
@@ -341,6 +377,7 @@ class Env(_EnvBase):
             return self._get_current_obs, result, False, False, {}
         if host:
             reward, num_agents = self._read_host_result()
+            self._host_read_pending = False
             self.last_result = res3[:2].clone()
         else:
             reward, num_agents = self.read_result(res3)

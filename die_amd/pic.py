@@ -119,10 +119,10 @@ class PicState:
         return self._two
 
     def _two_launch(self, env, agent) -> bool:
+        """The library's rule (die_pic_two_launch): nothing is restated here."""
         W, H = self._world_shape
-        reach = float(np.float32(abs(agent._scale)) * np.float32(max(W, H) - 1))      # (float32, as the library computes it)
-        R = int(4.0 * float(np.float32(env.dynamics.diffuse_sigma)) + 0.5)
-        return 1 <= R <= 4 and int(reach) + 2 + R <= min(1 << self.xs, 1 << self.ys)
+        mode = _lib.DIFFUSE_MODES[env.dynamics.diffuse_mode]
+        return _lib.lib.die_pic_two_launch(max(W, H), self.xs, self.ys, float(agent._scale), float(env.dynamics.diffuse_sigma), mode) == 1
 
     def is_current(self, env, agent) -> bool:
         A, h = env.agents, self.held

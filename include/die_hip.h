@@ -436,6 +436,10 @@ typedef struct die_pic {
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */
 int64_t die_pic_rim_cap(int32_t tile_xs, int32_t tile_ys);
+/* 1 if die_pic_forward_env_step takes the two-launch form for these parameters when rim lists are given (world_max = the longer
+ * axis of the WORLD in cells), 0 if it takes three launches (then dep_plane must exist and status_out is not written), -1 for a
+ * tile shape that is not compiled in.  The library's own rule: callers need not restate it. */
+int32_t die_pic_two_launch(int32_t world_max, int32_t tile_xs, int32_t tile_ys, float scale, float diffuse_sigma, int32_t diffuse_mode);
 /* number of tiles (words per per-tile array), or -1 if the shape is not compiled in */
 int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 /* Bin agents held in any order (die_agents; `heading` in the same order) into layout[into]; both layouts' per-tile words

@@ -780,6 +780,13 @@ def test_custom_action_cost_operator(die):
     def quadratic_cost(action):
         a = np.asarray(action)
         return 0.5 * a[2] ** 2 + 3.0 * (np.abs(a[0]) + np.abs(a[1]))
+
+    def reference_style_cost(action):            # the reference's own operators index the action by label (core/env.py:29-35)
+        dist = np.linalg.norm(action.sel(channel=['dx', 'dy']), axis=0)
+        return 0.02 * np.abs(action.sel(channel='deposit1')) + 0.01 * dist
+    a = np.arange(12.0).reshape(3, 4)
+    assert np.array_equal(reference_style_cost(die.env.ActionView(a)), 0.02 * np.abs(a[2]) + 0.01 * np.hypot(a[0], a[1]))
+    assert list(die.env.ActionView(a).coords['channel']) == ['dx', 'dy', 'deposit1']
     for W, H, N, K, tile in ((64, 48, 900, 600, None), (192, 192, 5000, 5000, (6, 6))):
         rs = np.random.RandomState(W + N)
         medium, agents = random_state(W, H, N, K, rs)
@@ -857,6 +864,41 @@ def test_sync_result_in_pinned_host_memory_equals_the_copied_result(die, binned,
         assert float(kept[0]) == out[3][0]                     # the 4th step's result, not the 9th
         runs.append(out)
     assert runs[0] == runs[1]
+
+
+def test_sync_step_that_failed_before_its_read_does_not_feed_the_next_one(die, monkeypatch):
+    """the pinned three-word result buffer is reused every step.  A step that raises after its kernels were
+    enqueued and before its words were waited for (here: the wait itself is made to fail once) leaves a kernel on its way that
+    would satisfy the NEXT step's wait with the old words — the next step synchronises first.  The results after the failure
+    equal those of an undisturbed run."""
+    W, H, N = 192, 192, 5000
+    rs = np.random.RandomState(33)
+    medium, agents = random_state(W, H, N, N, rs)
+
+    def run(fail_at):
+        env = die.Env.from_numpy(medium, agents, sync=True)
+        env._pic_tile = (6, 6)
+        ag = die.PhysarumAgent(max_agents=N, seed=4, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
+        obs, out = env._get_current_obs, []
+        real = env._read_host_result
+        for t in range(6):
+            if t == fail_at:
+                def boom():
+                    raise KeyboardInterrupt
+                env._read_host_result = boom
+                with pytest.raises(KeyboardInterrupt):
+                    env.step(ag.forward(obs))
+                env._read_host_result = real
+                assert env._host_res is None or env._host_read_pending
+                obs = env._get_current_obs
+                out.append(None)
+                continue
+            obs, reward, _, _, info = env.step(ag.forward(obs))
+            out.append((reward, info['num_agents']))
+        return out, env.medium.to_numpy()
+    (a, ma), (b, mb) = run(2), run(-1)
+    assert a[3:] == b[3:] and a[:2] == b[:2]                       # (the failed step itself ran on the device: the worlds are the same)
+    assert np.array_equal(ma, mb)
 
 
 def test_tile_binned_step_with_a_gradient_agent(die):

@@ -139,3 +139,20 @@ def test_agent_save_load_roundtrip(tmp_path):
     assert b.init_params == a.init_params and b.init_params['sense_offset'] == 0.04
     c = die_amd.BrownianAgent(move_scale=0.02)
     assert c.init_params == {'move_scale': 0.02, 'deposit_scale': 0.5, 'seed': None}
+
+
+def test_two_launch_rule_is_the_librarys(built_lib):
+    """die_pic_two_launch: the ONE statement of which form the tile-binned step takes (ADVICE r3: die_amd/pic.py restated it);
+    pinned here against the rule in words — an agent changes cell by at most floor(reach) + 1 per axis, + 1 across the world's
+    seam, and must stay R cells clear of the far border of the tile it walks onto."""
+    import numpy as np
+    from die_amd import _lib
+    L = _lib.lib
+    for worldmax, (xs, ys), scale, sigma, mode in ((4096, (6, 6), 1.53 / 4095, 0.5, 0), (4096, (6, 6), 0.006, 0.5, 0), (128, (4, 5), 1.53 / 127, 0.5, 0),
+                                                    (128, (4, 5), 11.5 / 127, 0.5, 0), (4096, (6, 6), 1.53 / 4095, 0.5, 1), (4096, (6, 6), 1.53 / 4095, 1.2, 0),
+                                                    (4096, (6, 6), 59.5 / 4095, 0.5, 0), (256, (5, 6), -9.9 / 255, 0.8, 0)):
+        reach = float(np.float32(abs(scale)) * np.float32(worldmax - 1))
+        R = int(4.0 * float(np.float32(sigma)) + 0.5)
+        want = mode == 0 and 1 <= R <= 4 and int(reach) + 2 + R <= min(1 << xs, 1 << ys)
+        assert L.die_pic_two_launch(worldmax, xs, ys, scale, sigma, mode) == int(want), (worldmax, xs, ys, scale, sigma, mode)
+    assert L.die_pic_two_launch(4096, 3, 3, 0.001, 0.5, 0) == -1
