@@ -76,7 +76,7 @@ class Pic(C.Structure):
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
                 ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32),
                 ('queue', C.c_void_p), ('sub_mode', C.c_int32), ('sub_tx0', C.c_int32), ('sub_ty0', C.c_int32), ('sub_ntx', C.c_int32),
-                ('sub_nty', C.c_int32), ('reserved4', C.c_int32)]
+                ('sub_nty', C.c_int32), ('reserved4', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p)]
 
 
 class PicSide(C.Structure):          # die_pic_side: one neighbour of the ghost refresh by tiles

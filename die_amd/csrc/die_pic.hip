@@ -1286,6 +1286,70 @@ __global__ __launch_bounds__(PA_WAVES * DIE_WAVE, 4) void k_pic_agents(FwdArgs f
     if (wave == 0) flush_tile(&tin[(nk - 1) % 3], &tacc[(nk - 1) & 1]);
 }
 
+// ---- dead slots on the tile-binned path (the reference's default layout: max_agents = W·H slots, core/data_init.py:143-144) ----------
+// A slot that never lived still acts, moves, burns and "consumes" (core/agent/gradient.py:96-124 has no alive masking;
+// core/env.py:163-172 moves every slot; :224-243 feeds every slot from rate·food·(agents > 0) and sums `gained` over all of them) —
+// it only never claims, deposits or marks a cell.  The binned layouts hold the alive agents in their tiles' segments, entries
+// [0, n_alive), and the dead slots behind them, entries [n_alive, N), in any fixed order; per step, between the agent kernel and the
+// field kernel:  k_pic_mark — the cells the alive agents stand on NOW, one bit per cell (the 'agents' channel of this step, which the
+// binned path never materialises: 2 MB at 4096², L2-resident) — and k_pic_dead — forward from global memory, move, feeding from the
+// food plane as it still is BEFORE the field kernel's consumption, reward partial per workgroup.
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_mark(PicArgs p, uint32_t n_alive, uint32_t* occ) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_alive; j += stride) {
+        const int cx = die_cell_u(p.out.x[j], p.g.gW), cy = die_cell_u(p.out.y[j], p.g.gH);
+        const uint32_t c = (uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy;
+        atomicOr(&occ[c >> 5], 1u << (c & 31u));
+    }
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, uint32_t first, uint32_t count, const uint32_t* occ, long long* part) {
+    f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
+    f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
+    f.g = p.g;
+    const FwdGlobalMem<T, false> mem(f);
+    const T* food = (const T*)p.food;
+    long long gsum = 0;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) {
+        const uint32_t j = first + i;
+        uint32_t X = p.in.x[j], Y = p.in.y[j];
+        const uint32_t sid = p.in.slot[j];
+        const double hd = __hiloint2double((int)p.in.hhi[j], (int)p.in.hlo[j]);
+        const FwdOut o = die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, true>(f, mem, X, Y, hd, sid, (int64_t)j);
+        if (p.adx) { p.adx[j] = o.dx; p.ady[j] = o.dy; p.adep[j] = o.dep; }
+        if (p.boundary == DIE_BOUNDARY_WRAP) {
+            X += (uint32_t)die_q32_small(o.dx);
+            Y += (uint32_t)die_q32_small(o.dy);
+        } else {
+            const int64_t qx = (int64_t)X + die_q32_small(o.dx), qy = (int64_t)Y + die_q32_small(o.dy);
+            X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
+            Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
+        }
+        const int cx = die_cell_u(X, p.g.gW), cy = die_cell_u(Y, p.g.gH);
+        const uint32_t c = (uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy;
+        // _agent_feed (core/env.py:224-233): a dead slot "consumes" iff somebody alive stands on its cell
+        const bool occupied = (occ[c >> 5] >> (c & 31u)) & 1u;
+        const float consumed = occupied ? p.rate_feed * die_ld(food, (int64_t)c) : 0.f;
+        const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
+        const float gained = consumed - cost;
+        gsum += die_fix(gained);
+        p.out.x[j] = X; p.out.y[j] = Y; p.out.agent_food[j] = p.in.agent_food[j] + gained; p.out.slot[j] = sid;
+        p.out.hhi[j] = (uint32_t)__double2hiint(o.heading); p.out.hlo[j] = (uint32_t)__double2loint(o.heading);
+        p.dep[j] = o.dep;
+    }
+    __shared__ long long s_g[DIE_BLOCK / DIE_WAVE];
+    gsum = die_wave_sum(gsum);
+    if ((threadIdx.x & (DIE_WAVE - 1)) == 0) s_g[threadIdx.x / DIE_WAVE] = gsum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int w = 0; w < DIE_BLOCK / DIE_WAVE; ++w) t += s_g[w];
+        part[blockIdx.x] = t;
+    }
+}
+
 // The random turn bits of one step, one Philox block per 128 slot ids (die_rng.h die_turn_word): word w of the table for
 // w < words.  Launched by die_pic_forward_env_step when the table does not hold this step's bits yet; in steady state the
 // field kernel's spare workgroups fill it for the NEXT step.
@@ -1431,6 +1495,7 @@ struct KbArgs {
     long long alive_const;
     long long* status_out;                                  // where the reduction workgroup copies the error word (die_pic.status_out), or NULL
     const uint32_t* error;
+    int n_part;                                             // reward partials in part_gain: one per tile, + (dead slots) one per workgroup of k_pic_dead
     uint32_t* turn_bits;                                    // the NEXT step's random turn bits (pic_turn_bits_fill), or NULL
     int64_t turn_words;
     uint64_t turn_seed;
@@ -1490,10 +1555,10 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         } else if (blockIdx.x == 1 && a.result) {           // reward: the agent kernel's per-tile partials (integers: any order)
             long long* s_g = (long long*)kb_smem;           // BLOCK 64-bit words
             long long t = 0;
-            for (int base = threadIdx.x; base < NT; base += BLOCK * 8) {
+            for (int base = threadIdx.x; base < a.n_part; base += BLOCK * 8) {
                 long long v[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int i = base + q * BLOCK; v[q] = i < NT ? p.part_gain[i] : 0; }
+                for (int q = 0; q < 8; ++q) { const int i = base + q * BLOCK; v[q] = i < a.n_part ? p.part_gain[i] : 0; }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) t += v[q];
             }
@@ -1776,13 +1841,16 @@ struct PicBinArgs {
     const uint32_t *hhi, *hlo;
     PicLayout out;
     uint32_t* cursor;
+    const uint8_t* alive;           // NULL: every entry is alive.  Dead slots (the reference's default layout: N = W·H slots of which
+    uint32_t n_alive;               // 85 % never lived, core/data_init.py:143-144) go behind the tiles' segments, entries [n_alive, N)
+    uint32_t* dead_cursor;
 };
 
 __global__ __launch_bounds__(DIE_BLOCK) void k_pic_hist(PicBinArgs a, uint32_t* hist) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < a.N; b += stride) {
         const int64_t n = b + threadIdx.x;
-        const bool active = n < a.N;
+        const bool active = n < a.N && (!a.alive || a.alive[n]);
         uint32_t key = 0;
         if (active) key = a.tiled ? (uint32_t)((pic_row<true>(a.g, a.x[n]) >> a.xs) * a.nty + (pic_col<true>(a.g, a.y[n]) >> a.ys))
                                   : (uint32_t)((pic_row<false>(a.g, a.x[n]) >> a.xs) * a.nty + (pic_col<false>(a.g, a.y[n]) >> a.ys));
@@ -1820,13 +1888,16 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t b = (int64_t)blockIdx.x * blockDim.x; b < a.N; b += stride) {
         const int64_t n = b + threadIdx.x;
-        const bool active = n < a.N;
-        const uint32_t X = active ? a.x[n] : 0u, Y = active ? a.y[n] : 0u;
+        const bool inside = n < a.N, active = inside && (!a.alive || a.alive[n]);
+        const uint32_t X = inside ? a.x[n] : 0u, Y = inside ? a.y[n] : 0u;
         uint32_t key = 0;
         if (active) key = a.tiled ? (uint32_t)((pic_row<true>(a.g, X) >> a.xs) * a.nty + (pic_col<true>(a.g, Y) >> a.ys))
                                   : (uint32_t)((pic_row<false>(a.g, X) >> a.xs) * a.nty + (pic_col<false>(a.g, Y) >> a.ys));
-        const uint32_t j = wave_grouped_add<true>(a.cursor, key, active);
-        if (!active) continue;
+        uint32_t j = wave_grouped_add<true>(a.cursor, key, active);
+        // a dead slot: any free entry behind the segments (results are keyed by the slot id, not by the array order)
+        const uint32_t jd = wave_grouped_add<true>(a.dead_cursor, 0u, inside && !active);
+        if (!inside) continue;
+        if (!active) j = a.n_alive + jd;
         a.out.x[j] = X;
         a.out.y[j] = Y;
         a.out.agent_food[j] = a.agent_food[n];
@@ -1913,16 +1984,19 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
     DIE_REQUIRE(a && a->N == p->N && a->x && a->y && a->agent_food && heading_hi && heading_lo, "die_pic_bin: bad agent arrays");
     DIE_REQUIRE(into == 0 || into == 1, "die_pic_bin: layout index %d", into);
     DIE_REQUIRE(a->x != p->layout[into].x, "die_pic_bin: the agents are already held in layout %d: bin into the other one", into);
+    const bool dead = p->n_alive > 0 && p->n_alive < p->N;
+    DIE_REQUIRE(p->n_alive >= 0 && p->n_alive <= p->N && (!dead || a->alive), "die_pic_bin: n_alive %lld of %lld slots needs the alive flags", (long long)p->n_alive, (long long)p->N);
     const int NT = (int)die_pic_tiles(m->W, m->H, p->tile_xs, p->tile_ys);
     hipStream_t s = (hipStream_t)stream;
-    uint32_t* hist = (uint32_t*)p->part_gain;                 // NT 64-bit words of scratch: histogram + cursors
+    uint32_t* hist = (uint32_t*)p->part_gain;                 // 2·NT 64-bit words of scratch: histogram, cursors, the dead slots' cursor
     uint32_t* cursor = hist + NT;
-    hipError_t e = hipMemsetAsync(hist, 0, (size_t)NT * 4, s);
+    hipError_t e = hipMemsetAsync(hist, 0, (size_t)(2 * NT + 1) * 4, s);
     if (e != hipSuccess) { die_set_error("die_pic_bin: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
     PicBinArgs b;
     b.g = die_geo_of(m); b.tiled = m->gW > 0; b.N = a->N; b.nty = m->H >> p->tile_ys; b.xs = p->tile_xs; b.ys = p->tile_ys;
     b.x = a->x; b.y = a->y; b.slot = a->slot; b.agent_food = a->agent_food; b.hhi = heading_hi; b.hlo = heading_lo;
     b.out = pic_layout(p->layout[into]); b.cursor = cursor;
+    b.alive = dead ? a->alive : nullptr; b.n_alive = dead ? (uint32_t)p->n_alive : (uint32_t)p->N; b.dead_cursor = hist + 2 * NT;
     int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
     const int grid = (int)(g < 4096 ? g : 4096);
     k_pic_hist<<<grid, DIE_BLOCK, 0, s>>>(b, hist);
@@ -2041,8 +2115,10 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(g && d && result && (from == 0 || from == 1), "die_pic_forward_env_step: null argument");
     DIE_REQUIRE(m->chem_next && m->chem_next != m->chem, "die_pic_forward_env_step: chem_next must be a second plane");
-    DIE_REQUIRE(!d->has_dead_slots && !d->agents_die && !m->sense_mask && !d->staged,
-                "die_pic_forward_env_step: every slot must be alive (no agents_die), no sense mask");
+    const bool dead = p->n_alive > 0 && p->n_alive < p->N;          // dead slots behind the segments (die_pic.n_alive)
+    DIE_REQUIRE((!d->has_dead_slots || dead) && !d->agents_die && !m->sense_mask && !d->staged,
+                "die_pic_forward_env_step: every slot alive, or the dead slots behind the segments (die_pic.n_alive); no agents_die, no sense mask");
+    DIE_REQUIRE(!dead || (p->occ && m->gW <= 0), "die_pic_forward_env_step: dead slots need the occupancy bitmap (die_pic.occ) and a single-tile world");
     DIE_REQUIRE(g->inertia == 0.f && g->noise_scale == 0.f && g->normalized_grad && !g->prev_gx && !g->prev_gy && !g->step_base,
                 "die_pic_forward_env_step: the step length must be bounded by `scale` (normalised gradient, no inertia, no noise), no graph replay");
     if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
@@ -2116,6 +2192,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
                      pic_two_launch_rule(worldmax, p->tile_xs, p->tile_ys, g->scale, d->diffuse_sigma, d->diffuse_mode);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
     DIE_REQUIRE(two || !p->sub_mode, "die_pic_forward_env_step: subsets of the tiles exist in the two-launch form only");
+    DIE_REQUIRE(!(dead && p->sub_mode), "die_pic_forward_env_step: subsets of the tiles and dead slots do not combine");
     if (tiled && !(two && stage)) {
         die_set_error("die_pic_forward_env_step: a decomposed world's tile runs the two-launch form with staged tiles only (probe reach %d, radius %d)", P, R);
         return DIE_ERR_UNSUPPORTED;
@@ -2177,6 +2254,26 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
         }
 #undef DIE_PIC_K1
     }
+    // dead slots (two-launch form): the cells the alive agents stand on now, then the slots that never lived
+    const int dead_blocks = dead ? (int)((p->N - p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK < NT ? (p->N - p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK : NT) : 0;
+    if (dead) {
+        DIE_REQUIRE(two, "die_pic_forward_env_step: dead slots exist in the two-launch form only");
+        if (stages & 1) {
+            hipError_t e = hipMemsetAsync(p->occ, 0, ((size_t)m->W * m->H + 31) / 32 * 4, s);
+            if (e != hipSuccess) { die_set_error("die_pic_forward_env_step: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
+            const int64_t gm = (p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK;
+            k_pic_mark<<<(int)(gm < 4096 ? gm : 4096), DIE_BLOCK, 0, s>>>(k, (uint32_t)p->n_alive, p->occ);
+            long long* part = (long long*)p->part_gain + NT;
+            const uint32_t first = (uint32_t)p->n_alive, count = (uint32_t)(p->N - p->n_alive);
+            if (m->dtype == DIE_F32) {
+                if (physarum) k_pic_dead<float, DIE_AGENT_PHYSARUM><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
+                else k_pic_dead<float, DIE_AGENT_GRADIENT><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
+            } else {
+                if (physarum) k_pic_dead<__half, DIE_AGENT_PHYSARUM><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
+                else k_pic_dead<__half, DIE_AGENT_GRADIENT><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
+            }
+        }
+    }
     if (two) {
         if (stages & 2) {                                   // (bit 2 alone: nothing — the sweep is part of this kernel)
             if (!tiled && !fused_step_shape_ok(m, d)) {
@@ -2189,7 +2286,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             a.chem = m->chem; a.chem_next = m->chem_next; a.rim = (const uint4*)p->rim; a.rim_code = p->rim_code; a.rim_cnt = p->rim_cnt;
             a.food_infinite = d->food_infinite; a.keep = (float)(1.0 - (double)d->rate_decay_chem);
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
-            a.result = result; a.alive_const = p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
+            a.result = result; a.alive_const = dead ? p->n_alive : p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
+            a.n_part = NT + (dead ? dead_blocks : 0);
             a.turn_bits = physarum && !g->turn_sign && k.nty > 2 ? p->turn_bits : nullptr;
             a.turn_words = turn_words; a.turn_seed = g->seed; a.turn_step = g->step + 1u;
             if (tiled) {

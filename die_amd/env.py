@@ -449,7 +449,8 @@ class Env(_EnvBase):
     # ------------------------------------------------------------------ tile-binned step (die_amd/pic.py)
     def _pic_applies(self, action) -> bool:
         d, ag = self.dynamics, action.agent
-        if not (self._pic_enabled and self._all_alive and not d.agents_die and not d.apply_sense_mask and not self._staged
+        # (dead slots — the reference's default max_agents = W·H — ride behind the tiles' segments: without agents_die they stay dead)
+        if not (self._pic_enabled and not d.agents_die and not d.apply_sense_mask and not self._staged
                 and self.medium.world is None and isinstance(d.boundary, BoundaryCondition) and d.diffuse_mode == 'wrap'
                 and 1 <= int(4.0 * float(d.diffuse_sigma) + 0.5) <= 4):
             return False
@@ -470,7 +471,12 @@ class Env(_EnvBase):
                 self._pic_tile = pick_tile(W, H, reach, shapes=((6, 6),)) or False
             else:
                 self._pic_tile = False
-        return bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1
+        if not (bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1):
+            return False
+        if not self._all_alive:                  # dead slots ride along in the two-launch form only
+            return _lib.lib.die_pic_two_launch(max(W, H), self._pic_tile[0], self._pic_tile[1], float(ag._scale), float(d.diffuse_sigma), 0) == 1 \
+                and getattr(self, '_pic_fused', True)
+        return True
 
     def _pic_step(self, action, result) -> bool:
         """`env.step(agent.forward(obs))` on tile-binned agents: die_pic_forward_env_step.  False: not applicable, the
@@ -480,6 +486,9 @@ class Env(_EnvBase):
         from .pic import PicState
         ag = action.agent
         if self._pic is None:
+            self._pic_n_alive = 0 if self._all_alive else int(self.agents.alive.sum().item())
+            if not self._all_alive and self._pic_n_alive == 0:
+                return False                        # (nobody alive: nothing to bin)
             self._pic = PicState(self, self._pic_tile)
             if getattr(self, '_pic_k1_threads', 0):
                 self._pic.k1_threads = int(self._pic_k1_threads)

@@ -61,6 +61,10 @@ class PicState:
         self.turn_slots = max(N, int(getattr(env, 'world_agents', 0) or 0))
         self.turn_bits = torch.zeros(4 * ((self.turn_slots + 127) // 128), dtype=torch.int32, device=dev)
         self._turn_for = None
+        # the reference's default slot layout (max_agents = W·H: most slots never lived): the alive agents in the tiles' segments,
+        # the dead slots behind them (include/die_hip.h `die_pic.n_alive`); `occ`: this step's occupancy bitmap for their feeding
+        self.n_alive = int(getattr(env, '_pic_n_alive', 0) or 0)
+        self.occ = torch.zeros((W * H + 31) // 32, dtype=torch.int32, device=dev) if 0 < self.n_alive < N else None
         # die_pic.queue: the agent kernel as a fixed grid that draws tiles from a queue (opt-in: slower at every size measured)
         self.queue = torch.zeros(2, dtype=torch.int32, device=dev) if (getattr(env, '_pic_queue', False) or os.environ.get('DIE_PIC_QUEUE', '0') == '1') else None
         self.part = torch.zeros(2 * self.NT, dtype=torch.int64, device=dev)       # reward partials | owned agents (decomposed tiles)
@@ -101,7 +105,8 @@ class PicState:
             lay[1 - cur] = self._layout(ot, self.meta[1 - cur])
             p = self._structs[key] = _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane),
                                               _ptr(self.part), _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code),
-                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, _ptr(self.queue), 0, 0, 0, 0, 0, 0)
+                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, _ptr(self.queue), 0, 0, 0, 0, 0, 0,
+                                              self.n_alive if self.occ is not None else 0, _ptr(self.occ))
         L = p.layout
         L[cur].slot, L[1 - cur].slot = ct[3].data_ptr(), ot[3].data_ptr()
         p.N, p.k1_threads, p.stages, p.status_out = self._n_agents, self.k1_threads, stages, status_out
@@ -159,6 +164,9 @@ class PicState:
                                         stream_ptr(env.device)), 'die_pic_bin')
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)
+        if self.occ is not None:                 # the array order is now: alive agents (tile by tile), then the dead slots
+            A.alive = torch.cat([torch.ones(self.n_alive, dtype=A.alive.dtype, device=env.device),
+                                 torch.zeros(self._n_agents - self.n_alive, dtype=A.alive.dtype, device=env.device)])
 
     def flush_lazy(self):
         """The action of the previous step, if somebody still holds it without having read it: fill it in now (the next
@@ -176,7 +184,7 @@ class PicState:
         def rebuild(act):
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
-            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0)
+            p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, None)
             act.slot = slot                                    # the values come out in the order of the layout the step wrote
             u = act.raw_struct()
             _lib.check(_lib.lib.die_pic_action_physarum(C.byref(p), lay, C.byref(act.g_struct), C.byref(u), stream_ptr(dev)),

@@ -432,6 +432,14 @@ typedef struct die_pic {
      * while its ghost refresh's messages are in flight, the others once they have arrived (die_amd/dist.py).  The caller issues
      * every tile exactly once per stage; two-launch form only. */
     int32_t sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty, reserved4;
+    /* The reference's default slot layout on this path (core/data_init.py:143-144: max_agents = W*H slots, most of which never
+     * lived): the tiles' segments hold the n_alive alive agents, entries [0, n_alive) of the arrays, the dead slots lie behind them,
+     * entries [n_alive, N), where die_pic_bin puts them.  A dead slot acts, moves, burns and "consumes" like the reference's
+     * (core/env.py:163-172, 224-243) — from the occupancy bitmap `occ` (one bit per cell: the cells alive agents stand on in this
+     * step; scratch, (W*H + 31) / 32 words) — and never claims, deposits or marks a cell.  0 (or N): every slot is alive.
+     * Two-launch form, single-tile worlds. */
+    int64_t n_alive;
+    uint32_t* occ;
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */

@@ -619,12 +619,13 @@ def _binned_steps_against_the_oracle(die, medium, agents, dyn, tile, agent_kind,
         assert np.array_equal(gm[0], renv.medium[0]), f'step {step}: agents channel'
         ix, iy = R.cell(renv.agents[0], W), R.cell(renv.agents[1], H)
         want_owner = np.full((W, H), -1, dtype=np.int64)
-        want_owner[ix, iy] = np.arange(N)                   # ascending order: the last (highest) write stays
+        live = np.nonzero(renv.agents[2] > 0)[0]            # (dead slots never claim a cell: core/env.py:204-215 works on the alive ones)
+        want_owner[ix[live], iy[live]] = live               # ascending order: the last (highest) write stays
         assert np.array_equal(env.medium.owner_slots().cpu().numpy(), want_owner), f'step {step}: ownership'
         assert np.allclose(ga[3], renv.agents[3], rtol=frtol, atol=fatol), f'step {step}: agent_food'
         assert np.allclose(gm[1], renv.medium[1], rtol=frtol, atol=fatol), f'step {step}: food'
         assert np.allclose(gm[2], renv.medium[2], rtol=frtol, atol=fatol), f'step {step}: chem'
-        assert info['num_agents'] == want_info['num_agents'] == N and term == want_term
+        assert info['num_agents'] == want_info['num_agents'] == len(live) and term == want_term
         assert abs(reward - want_reward) <= max(RTOL, frtol) * np.abs(renv.last_gained).sum() + 1e-9, f'step {step}: reward'
     return env
 
@@ -640,6 +641,11 @@ BINNED_ORACLE_CASES = [
     dict(W=192, H=192, tile=(6, 6), dense=True),                             # several agents per cell
     dict(W=64, H=96, tile=(4, 5), form='three launches'),
     dict(W=192, H=192, tile=(6, 6), collide=0.6, form='three launches'),
+    # dead slots (the reference's default layout: max_agents = W·H slots, core/data_init.py:143-144) behind the tiles' segments:
+    # they act, move, burn and consume like the reference's, and never claim a cell
+    dict(W=192, H=192, tile=(6, 6), dead=0.6, collide=0.5),
+    dict(W=128, H=192, tile=(5, 6), dead=0.85, boundary='limit'),
+    dict(W=64, H=96, tile=(4, 5), dead=0.3, f16=True),
 ]
 
 
@@ -653,7 +659,9 @@ def test_tile_binned_step_vs_oracle(die, case):
     W, H = case['W'], case['H']
     rs = np.random.RandomState(W * 3 + H)
     N = 3 * W * H if case.get('dense') else int(0.15 * W * H)
-    medium, agents = random_state(W, H, N, N, rs, collide=case.get('collide', 0.3))
+    if case.get('dead'):
+        N = int(0.5 * W * H)
+    medium, agents = random_state(W, H, N, N - int(case.get('dead', 0) * N), rs, collide=case.get('collide', 0.3))
     dyn = die.Dynamics(boundary=die.BoundaryCondition(case.get('boundary', 'wrap')), food_infinite=case.get('food_infinite', False),
                        op_action_cost=die.zero_cost if case.get('zero_cost') else die.linear_action_cost,
                        diffuse_sigma=case.get('sigma', 0.5), rate_feed=case.get('rate_feed', 0.1), rate_decay_chem=case.get('decay', 0.1))
