@@ -267,12 +267,19 @@ def side_measurements(args, device, agent_kw, torch, die_amd):
     # (c) SURVEY §8(d)'s stress case: the LITERAL normalised parameters of examples/minimal_run.py:42 (sense_offset .04, scale
     #     .006 — a 164-cell probe and a 25-cell step at 4096²) instead of the cell-unit-constant ones; with the path it took
     literal = dict(agent_kw, sense_offset=0.04, scale=0.006)
+    # (d) the reference's default GradientAgent momentum (inertia .9, noise .025, sense_offset 0: core/agent/gradient.py:19-30) at the
+    #     benchmark's step length: _prev_grad travels through the tile-binned layouts (die_pic.prev_grad)
+    momentum = dict(scale=agent_kw['scale'], sense_offset=0.0, inertia=0.9, noise_scale=0.025)
     for name, kw, n, akw in (('sync_true_steps_per_s', dict(max_agents='alive', sync=True), 100, agent_kw),
                              ('reference_default_slots_steps_per_s', dict(max_agents=None, sync=False), 30, agent_kw),
-                             ('literal_normalised_parameters_steps_per_s', dict(max_agents='alive', sync=False), 60, literal)):
+                             ('literal_normalised_parameters_steps_per_s', dict(max_agents='alive', sync=False), 60, literal),
+                             ('gradient_agent_default_momentum_steps_per_s', dict(max_agents='alive', sync=False), 60, momentum)):
         try:
             env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed, device=device, field_dtype=dt_f, **kw)
-            agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **akw)
+            if akw is momentum:
+                agent = die_amd.GradientAgent(max_agents=env.agents.N, seed=args.seed, **akw)
+            else:
+                agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **akw)
             obs = env._get_current_obs
             for _ in range(max(20, n // 2)):
                 obs, *_ = env.step(agent.forward(obs))
@@ -284,6 +291,10 @@ def side_measurements(args, device, agent_kw, torch, die_amd):
             out[name] = round(n / (time.perf_counter() - t0), 1)
             if kw['max_agents'] is None:
                 out['reference_default_slots'] = int(env.agents.N)
+            if akw is momentum:
+                binned = getattr(env, '_pic', None) is not None and env._pic.held is not None
+                out['gradient_agent_default_momentum'] = {'inertia': 0.9, 'noise_scale': 0.025, 'step_cells': round(akw['scale'] * (W - 1), 2),
+                                                          'path': 'tile-binned, two launches (action stored every step)' if binned else 'classic step'}
             if akw is literal:
                 binned = getattr(env, '_pic', None) is not None and env._pic.held is not None
                 out['literal_normalised_parameters'] = {'sense_offset': 0.04, 'scale': 0.006, 'probe_cells': round(0.04 * (W - 1), 1), 'step_cells': round(0.006 * (W - 1), 1),

@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 
 class Medium(C.Structure):
@@ -76,7 +76,8 @@ class Pic(C.Structure):
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
                 ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32),
                 ('queue', C.c_void_p), ('sub_mode', C.c_int32), ('sub_tx0', C.c_int32), ('sub_ty0', C.c_int32), ('sub_ntx', C.c_int32),
-                ('sub_nty', C.c_int32), ('reserved4', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p)]
+                ('sub_nty', C.c_int32), ('reserved4', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p),
+                ('prev_grad', (C.c_void_p * 2) * 2)]
 
 
 class PicSide(C.Structure):          # die_pic_side: one neighbour of the ghost refresh by tiles
@@ -165,6 +166,7 @@ _SIGNATURES = {
                                     C.c_void_p]),
     'die_rects_pack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_pic_two_launch': (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32]),
+    'die_pic_step_bound': (C.c_float, [C.c_float, C.c_float]),
     'die_stream_copy': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'die_host_device_pointer': (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]),
     'die_rects_unpack': (C.c_int, [_P(Rect), C.c_int32, C.c_void_p, C.c_void_p]),
@@ -185,6 +187,7 @@ _SIGNATURES = {
     'die_pic_tiles': (C.c_int64, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'die_pic_rim_cap': (C.c_int64, [C.c_int32, C.c_int32]),
     'die_pic_bin': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
+    'die_pic_bin_momentum': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),

@@ -119,6 +119,7 @@ __device__ __forceinline__ void die_polar2xy_heading(double heading, float r, fl
 struct FwdOut {
     float dx, dy, dep;
     double heading;
+    float ux, uy;              // the vector the action is `scale` times: with momentum, the new _prev_grad (gradient.py:89)
 };
 
 // The 4 chem taps of np.gradient at the probe cell (px, py) — central inside the world, one-sided at its four edges
@@ -201,7 +202,9 @@ __device__ __forceinline__ void die_normalize2(float gx, float gy, float* ux, fl
 
 // TB: the random turn bits come from the step's table (FwdArgs.turn_bits, filled by die_turn_bits_fill) instead of a Philox
 // evaluation per agent — the same bits (die_rng.h).
-template <typename T, int KIND, bool EXT, class MEM, bool TB = false>
+// PGSTORE = false: _prev_grad is read at index n but NOT updated in place — the caller stores FwdOut.ux / uy where the agent
+// goes (the tile-binned step: the agent's index changes with the step).
+template <typename T, int KIND, bool EXT, class MEM, bool TB = false, bool PGSTORE = true>
 __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const MEM& mem, const uint32_t X, const uint32_t Y, const double d64,
                                                        const uint32_t sid, const int64_t n) {
     const float d = (float)d64;             // trigonometry in fp32 (1e-7 of a cell on the probe), decisions in float64
@@ -300,13 +303,14 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
         ux += 0.f;
         uy += 0.f;
     }
-    if (a.pgx) { a.pgx[n] = ux; a.pgy[n] = uy; }
+    if (PGSTORE && a.pgx) { a.pgx[n] = ux; a.pgy[n] = uy; }
     if (heading_from_vector) d_new = (double)die_np_angle(ux, uy);    // get_radians (gradient.py:110)
     FwdOut o;
     o.heading = d_new;
     o.dx = ux * a.scale;
     o.dy = uy * a.scale;
     o.dep = a.deposit * t.f_own * dep_mask;
+    o.ux = ux; o.uy = uy;
     return o;
 }
 

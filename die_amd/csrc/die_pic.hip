@@ -161,6 +161,9 @@ struct PicArgs {
     // while the ghost refresh's messages are in flight, the others afterwards): 0 all tiles; 1 the rectangle only (the grid is the
     // rectangle); 2 all but the rectangle (full grid, the rectangle's workgroups return at once)
     int sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty;
+    // GradientAgent with momentum (inertia ≠ 0: die_pic.prev_grad): _prev_grad in `in` order / where the step leaves it, `out` order
+    const float *ipgx, *ipgy;
+    float *opgx, *opgy;
 };
 __device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty) {        // false: not this launch's tile
     if (p.sub_mode == 1) { tx += p.sub_tx0; ty += p.sub_ty0; return true; }
@@ -355,13 +358,16 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 // tiles ahead) and prefetch the NEXT tile's per-tile words, first stayers and candidate arrivals into registers while they work
 // on the current one — two of the four memory round trips of a tile's chain leave its critical path; LDS per workgroup is
 // unchanged (the windows are NOT double-buffered: that costs a resident workgroup, k_pic_agents below).
-template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool PERSIST = false>
+template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool PERSIST = false, bool MOM = false>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
     // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)
-    f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
-    f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
+    // MOM (GradientAgent with inertia / noise, gradient.py:82-91): the momentum path stays; _prev_grad is read from the `in`
+    // arrays at the agent's index and written to the `out` arrays where the agent goes
+    f.pgx = MOM ? (float*)p.ipgx : nullptr; f.pgy = MOM ? (float*)p.ipgy : nullptr; f.step_base = nullptr; f.mask = nullptr;
+    if (!MOM) { f.inertia = 0.f; f.noise_scale = 0.f; }
+    f.normalized = 1;
     f.g = p.g;                            // one copy of the geometry
 #if PIC_KARG
     // The array pointers are needed at a few places each — the streams once per chunk, the epilogue's once per tile.  Kept in
@@ -595,6 +601,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             bool stay = false;
             uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0;
             float af = 0.f, dep = 0.f;
+            [[maybe_unused]] float pux = 0.f, puy = 0.f;
             double hd = 0.0;
             uint32_t code = 0;
             bool listed = false;
@@ -612,8 +619,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     af = PIC_AT(ia_, const float, j);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
-                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, true>(f, tm, X, Y, hd, sid, (int64_t)j)
-                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, true>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
+                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, true, false>(f, tm, X, Y, hd, sid, (int64_t)j)
+                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, true, false>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
+                if (MOM) { pux = o.ux; puy = o.uy; }
                 if (ACT && p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
                 // (a step is shorter than a tile — checked on the host — so the fixed-point increment needs no float64 path)
@@ -699,6 +707,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     PIC_AT(ohh_, uint32_t, q) = (uint32_t)__double2hiint(hd);
                     PIC_AT(ohl_, uint32_t, q) = (uint32_t)__double2loint(hd);
                     PIC_AT(od_, float, q) = dep;
+                    if (MOM && p.opgx) { PIC_AT(p.opgx, float, q) = pux; PIC_AT(p.opgy, float, q) = puy; }
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
@@ -1844,6 +1853,8 @@ struct PicBinArgs {
     const uint8_t* alive;           // NULL: every entry is alive.  Dead slots (the reference's default layout: N = W·H slots of which
     uint32_t n_alive;               // 85 % never lived, core/data_init.py:143-144) go behind the tiles' segments, entries [n_alive, N)
     uint32_t* dead_cursor;
+    const float *pgx, *pgy;         // GradientAgent with inertia: _prev_grad travels along (NULL: none)
+    float *opgx, *opgy;
 };
 
 __global__ __launch_bounds__(DIE_BLOCK) void k_pic_hist(PicBinArgs a, uint32_t* hist) {
@@ -1904,6 +1915,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
         a.out.slot[j] = a.slot ? a.slot[n] : (uint32_t)n;
         a.out.hhi[j] = a.hhi[n];
         a.out.hlo[j] = a.hlo[n];
+        if (a.pgx) { a.opgx[j] = a.pgx[n]; a.opgy[j] = a.pgy[n]; }
     }
 }
 
@@ -1967,6 +1979,16 @@ static bool pic_two_launch_rule(int worldmax, int tile_xs, int tile_ys, float sc
     // of the FAR border of the tile it walks onto
     return diffuse_mode == DIE_DIFFUSE_WRAP && R >= 1 && R <= 4 && (int)floorf(reach) + 2 + R <= (TX < TY ? TX : TY);
 }
+// Per-axis bound of the vector a GradientAgent's action is `scale` times (include/die_hip.h die_pic_step_bound)
+#define PIC_NOISE_MAX 2.67f          // 0.4·sqrt(−2·ln 2^-32) = 2.6642: the largest 0.4-sigma Box–Muller normal of die_forward.h / die_init_heading
+extern "C" float die_pic_step_bound(float inertia, float noise_scale) {
+    if (inertia == 0.f && noise_scale == 0.f) return 1.f;
+    if (!(inertia >= 0.f && inertia < 1.f)) return INFINITY;
+    const float ns = fabsf(noise_scale) * PIC_NOISE_MAX;
+    if (inertia == 0.f) return 1.f + ns;
+    const float fix = 1.f + ns / (1.f - inertia);
+    return fix > PIC_NOISE_MAX ? fix : PIC_NOISE_MAX;
+}
 extern "C" int32_t die_pic_two_launch(int32_t world_max, int32_t tile_xs, int32_t tile_ys, float scale, float diffuse_sigma, int32_t diffuse_mode) {
     if (!pic_shape_ok(tile_xs, tile_ys) || world_max < 2) return -1;
     return pic_two_launch_rule(world_max, tile_xs, tile_ys, scale, diffuse_sigma, diffuse_mode) ? 1 : 0;
@@ -1977,8 +1999,8 @@ extern "C" int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t 
     return (int64_t)(W >> tile_xs) * (H >> tile_ys);
 }
 
-extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
-                           const die_pic* p, int32_t into, void* stream) {
+static int pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
+                   const float* prev_gx, const float* prev_gy, const die_pic* p, int32_t into, void* stream) {
     int rc = pic_check(m, p, "die_pic_bin");
     if (rc != DIE_OK) return rc;
     DIE_REQUIRE(a && a->N == p->N && a->x && a->y && a->agent_food && heading_hi && heading_lo, "die_pic_bin: bad agent arrays");
@@ -1997,6 +2019,9 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
     b.x = a->x; b.y = a->y; b.slot = a->slot; b.agent_food = a->agent_food; b.hhi = heading_hi; b.hlo = heading_lo;
     b.out = pic_layout(p->layout[into]); b.cursor = cursor;
     b.alive = dead ? a->alive : nullptr; b.n_alive = dead ? (uint32_t)p->n_alive : (uint32_t)p->N; b.dead_cursor = hist + 2 * NT;
+    b.pgx = prev_gx; b.pgy = prev_gy; b.opgx = p->prev_grad[into][0]; b.opgy = p->prev_grad[into][1];
+    DIE_REQUIRE((prev_gx != nullptr) == (prev_gy != nullptr) && (!prev_gx || (b.opgx && b.opgy && b.opgx != prev_gx)),
+                "die_pic_bin: _prev_grad given without die_pic.prev_grad[%d] to carry it into", into);
     int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
     const int grid = (int)(g < 4096 ? g : 4096);
     k_pic_hist<<<grid, DIE_BLOCK, 0, s>>>(b, hist);
@@ -2004,6 +2029,14 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
     k_pic_scatter<<<grid, DIE_BLOCK, 0, s>>>(b);
     DIE_CHECK_LAUNCH("die_pic_bin");
     return DIE_OK;
+}
+extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
+                           const die_pic* p, int32_t into, void* stream) {
+    return pic_bin(m, a, heading_hi, heading_lo, nullptr, nullptr, p, into, stream);
+}
+extern "C" int die_pic_bin_momentum(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
+                                    const float* prev_gx, const float* prev_gy, const die_pic* p, int32_t into, void* stream) {
+    return pic_bin(m, a, heading_hi, heading_lo, prev_gx, prev_gy, p, into, stream);
 }
 
 static int pa_cu_count() {
@@ -2044,8 +2077,14 @@ static void launch_forward_move_queue(int kind, const FwdArgs& f, const PicArgs&
 }
 
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
-static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
+static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s, bool mom = false) {
     const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx);
+    if constexpr (!TILED) {
+        if (kind != DIE_AGENT_PHYSARUM && mom) {
+            k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, false, false, true><<<grid, block, lds, s>>>(f, k);
+            return;
+        }
+    }
     if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, TILED><<<grid, block, lds, s>>>(f, k);
     else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, true, RIM, TILED><<<grid, block, lds, s>>>(f, k);
     else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, STAGE, false, RIM, TILED><<<grid, block, lds, s>>>(f, k);
@@ -2119,8 +2158,17 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     DIE_REQUIRE((!d->has_dead_slots || dead) && !d->agents_die && !m->sense_mask && !d->staged,
                 "die_pic_forward_env_step: every slot alive, or the dead slots behind the segments (die_pic.n_alive); no agents_die, no sense mask");
     DIE_REQUIRE(!dead || (p->occ && m->gW <= 0), "die_pic_forward_env_step: dead slots need the occupancy bitmap (die_pic.occ) and a single-tile world");
-    DIE_REQUIRE(g->inertia == 0.f && g->noise_scale == 0.f && g->normalized_grad && !g->prev_gx && !g->prev_gy && !g->step_base,
-                "die_pic_forward_env_step: the step length must be bounded by `scale` (normalised gradient, no inertia, no noise), no graph replay");
+    // momentum (GradientAgent's inertia / noise, gradient.py:82-91): _prev_grad rides in die_pic.prev_grad, the step is bounded by
+    // |scale|·die_pic_step_bound.  (g->prev_gx / prev_gy are ignored here: the state is the layouts'.)
+    const bool mom = g->inertia != 0.f || g->noise_scale != 0.f;
+    const float ubound = die_pic_step_bound(g->inertia, g->noise_scale);
+    DIE_REQUIRE(g->normalized_grad && !g->step_base && (!mom || (g->kind == DIE_AGENT_GRADIENT && ubound < 1e6f)),
+                "die_pic_forward_env_step: the step length must be bounded (normalised gradient; momentum for a GradientAgent with inertia < 1 only), no graph replay");
+    DIE_REQUIRE(!mom || (!dead && m->gW <= 0 && !p->sub_mode), "die_pic_forward_env_step: momentum combines with neither dead slots nor a decomposed world's tile");
+    const float* const* pg_in = (const float* const*)p->prev_grad[from];
+    float* const* pg_out = (float* const*)p->prev_grad[1 - from];
+    DIE_REQUIRE(g->inertia == 0.f || (pg_in[0] && pg_in[1] && pg_out[0] && pg_out[1] && pg_in[0] != pg_out[0]),
+                "die_pic_forward_env_step: inertia needs die_pic.prev_grad of both layouts");
     if (d->boundary != DIE_BOUNDARY_WRAP && d->boundary != DIE_BOUNDARY_LIMIT) {
         die_set_error("die_pic_forward_env_step: boundary %d is not representable in Q0.32", d->boundary);
         return DIE_ERR_UNSUPPORTED;
@@ -2129,7 +2177,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const int TX = 1 << p->tile_xs, TY = 1 << p->tile_ys;
     const bool tiled = m->gW > 0;                           // a decomposed world's tile: lengths are fractions of the WORLD
     const int worldmax = tiled ? (m->gW > m->gH ? m->gW : m->gH) : (m->W > m->H ? m->W : m->H);
-    const float reach = fabsf(g->scale) * (float)(worldmax - 1);     // cells per step, at most
+    const float step_scale = g->scale * ubound;
+    const float reach = fabsf(step_scale) * (float)(worldmax - 1);     // cells per step, at most
     if (!(reach <= (float)((TX < TY ? TX : TY) - 1))) {
         die_set_error("die_pic_forward_env_step: a step of %.1f cells does not stay within the neighbouring %dx%d tiles", (double)reach, TX, TY);
         return DIE_ERR_UNSUPPORTED;
@@ -2139,6 +2188,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     a.N = p->N; a.x = Lin.x; a.y = Lin.y; a.alive = nullptr; a.agent_food = Lin.agent_food; a.slot = Lin.slot;
     die_gradient_agent gg = *g;
     gg.heading_hi = Lin.heading_hi; gg.heading_lo = Lin.heading_lo;
+    gg.prev_gx = g->inertia != 0.f ? (float*)pg_in[0] : nullptr; gg.prev_gy = g->inertia != 0.f ? (float*)pg_in[1] : nullptr;
     FwdArgs f;
     rc = die_fill_fwd_args(f, m, &a, &gg, act, "die_pic_forward_env_step");
     if (rc != DIE_OK) return rc;
@@ -2151,6 +2201,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.boundary = d->boundary; k.cost = d->cost;
     k.part_gain = (long long*)p->part_gain; k.error = p->error; k.queue = nullptr;
     k.sub_mode = p->sub_mode; k.sub_tx0 = p->sub_tx0; k.sub_ty0 = p->sub_ty0; k.sub_ntx = p->sub_ntx; k.sub_nty = p->sub_nty;
+    const bool keep_pg = mom && g->inertia != 0.f;
+    k.ipgx = keep_pg ? pg_in[0] : nullptr; k.ipgy = keep_pg ? pg_in[1] : nullptr; k.opgx = keep_pg ? pg_out[0] : nullptr; k.opgy = keep_pg ? pg_out[1] : nullptr;
     DIE_REQUIRE(p->sub_mode >= 0 && p->sub_mode <= 2, "die_pic_forward_env_step: sub_mode %d", p->sub_mode);
     if (p->sub_mode) {
         DIE_REQUIRE(p->stages == 1 || p->stages == 2, "die_pic_forward_env_step: a subset of the tiles is one launch (stages 1 or 2), not a whole step");
@@ -2189,7 +2241,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // FAR border of the tile it walks onto
     const int R = (int)(4.0 * (double)d->diffuse_sigma + 0.5);
     const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr &&
-                     pic_two_launch_rule(worldmax, p->tile_xs, p->tile_ys, g->scale, d->diffuse_sigma, d->diffuse_mode);
+                     pic_two_launch_rule(worldmax, p->tile_xs, p->tile_ys, step_scale, d->diffuse_sigma, d->diffuse_mode);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
     DIE_REQUIRE(two || !p->sub_mode, "die_pic_forward_env_step: subsets of the tiles exist in the two-launch form only");
     DIE_REQUIRE(!(dead && p->sub_mode), "die_pic_forward_env_step: subsets of the tiles and dead slots do not combine");
@@ -2235,13 +2287,13 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
         if (tiled) rc2 = m->dtype == DIE_F32 ? launch_agents<float, true>(f, k, PL, NT, s) : launch_agents<__half, true>(f, k, PL, NT, s);
         else rc2 = m->dtype == DIE_F32 ? launch_agents<float, false>(f, k, PL, NT, s) : launch_agents<__half, false>(f, k, PL, NT, s);
         if (rc2 != DIE_OK) return rc2;
-    } else if ((stages & 1) && two && stage && p->queue && PIC_QUEUE && !p->sub_mode) {
+    } else if ((stages & 1) && two && stage && p->queue && PIC_QUEUE && !p->sub_mode && !mom) {
         k.queue = p->queue;
         if (tiled) { if (m->dtype == DIE_F32) launch_forward_move_queue<float, true>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, true>(g->kind, f, k, NT, block, lds, s); }
         else { if (m->dtype == DIE_F32) launch_forward_move_queue<float, false>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, false>(g->kind, f, k, NT, block, lds, s); }
     } else if (stages & 1) {
-#define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s); \
-                                       else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s); } while (0)
+#define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s, mom); \
+                                       else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s, mom); } while (0)
         if (tiled) {
             if (m->dtype == DIE_F32) launch_forward_move<float, true, true, true>(g->kind, f, k, NT, block, lds, s);
             else launch_forward_move<__half, true, true, true>(g->kind, f, k, NT, block, lds, s);

@@ -454,10 +454,17 @@ class Env(_EnvBase):
                 and self.medium.world is None and isinstance(d.boundary, BoundaryCondition) and d.diffuse_mode == 'wrap'
                 and 1 <= int(4.0 * float(d.diffuse_sigma) + 0.5) <= 4):
             return False
-        if not (ag._normalized and ag._inertia == 0 and ag._noise_scale == 0 and ag._step_base is None and ag._prev_grad is None):
+        if not (ag._normalized and ag._step_base is None):
             return False
+        momentum = ag._inertia != 0 or ag._noise_scale != 0
+        if momentum and (ag._kind != _lib.DIE_AGENT_GRADIENT or not self._all_alive):
+            return False                                         # (a PhysarumAgent with momentum, momentum with dead slots: the classic step)
+        if not momentum and ag._prev_grad is not None:
+            return False
+        from .pic import step_scale
         W, H = self._field_size
-        reach = abs(ag._scale) * (max(W, H) - 1)                 # cells per step, at most
+        eff_scale = step_scale(ag)                               # |scale| · the bound of the vector it multiplies (momentum: die_pic_step_bound)
+        reach = abs(eff_scale) * (max(W, H) - 1)                 # cells per step, at most
         if self._pic_tile is None:
             from .pic import pick_tile
             # small worlds are bound by launches and their gaps, not by what the binned step saves.  Measured (r3, µs per step,
@@ -474,7 +481,7 @@ class Env(_EnvBase):
         if not (bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1):
             return False
         if not self._all_alive:                  # dead slots ride along in the two-launch form only
-            return _lib.lib.die_pic_two_launch(max(W, H), self._pic_tile[0], self._pic_tile[1], float(ag._scale), float(d.diffuse_sigma), 0) == 1 \
+            return _lib.lib.die_pic_two_launch(max(W, H), self._pic_tile[0], self._pic_tile[1], eff_scale, float(d.diffuse_sigma), 0) == 1 \
                 and getattr(self, '_pic_fused', True)
         return True
 

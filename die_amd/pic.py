@@ -25,6 +25,14 @@ def pick_tile(W: int, H: int, reach_cells: float, shapes=TILE_SHAPES) -> Optiona
     return None
 
 
+def step_scale(agent) -> float:
+    """`scale` times the per-axis bound of the vector the action is `scale` times (die_pic_step_bound: 1 without momentum), as the
+    library computes it in float32: what the tile rules take for `scale`."""
+    import numpy as np
+    bound = _lib.lib.die_pic_step_bound(float(agent._inertia), float(agent._noise_scale))
+    return float(np.float32(agent._scale) * np.float32(bound))
+
+
 def lazy_ok(agent) -> bool:
     """Does the field kernel leave the next step's turn bits behind for this agent?  (A PhysarumAgent drawing from Philox.)"""
     return agent._kind == _lib.DIE_AGENT_PHYSARUM and agent._turn_sign is None
@@ -71,19 +79,21 @@ class PicState:
         self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
         self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
+        self.spare_pg = None         # GradientAgent with inertia: the (2, N) _prev_grad array of the layout that is not current (die_pic.prev_grad)
         self.k1_threads = int(os.environ.get('DIE_PIC_THREADS', '0'))   # die_pic.k1_threads: 0 = library default, > 0: workgroup size of the agent kernel, -1: the persistent agent kernel where it applies
         self.cur = 0                 # layout index that holds the agents
         self.held = None             # (x, y, agent_food, slot, heading hi, lo) tensors of layout[cur] — identity = validity
         self._structs = {}           # die_pic structs by the device addresses of the two array sets (_struct)
         self._two_key = self._two = None
         self.agent = None
+        self.agent_for_out = None    # the agent whose state the next output tensors carry (bin / step set it)
         self.steps_since_check = 0   # binned steps whose error word nobody has read yet
         self.lazy_actions = True     # PhysarumAgent: the step keeps the action in registers, PendingAction re-derives it on demand
         self._lazy_ref = None        # weak reference to the last such action (it must be filled in before its inputs change)
 
     # ------------------------------------------------------------------
     def _layout(self, tensors, meta) -> _lib.PicLayout:
-        x, y, af, slot, hh, hl = tensors
+        x, y, af, slot, hh, hl = tensors[:6]
         return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hh), _ptr(hl), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
 
     def _struct(self, cur_tensors, other_tensors, stages: int = 0, status_out=None) -> _lib.Pic:
@@ -95,7 +105,8 @@ class PicState:
         ct, ot, cur = cur_tensors, other_tensors, self.cur
         key = (cur, ct[0].data_ptr(), ct[1].data_ptr(), ct[2].data_ptr(), ct[4].data_ptr(), ct[5].data_ptr(),
                ot[0].data_ptr(), ot[1].data_ptr(), ot[2].data_ptr(), ot[4].data_ptr(), ot[5].data_ptr(),
-               0 if self._dep_plane is None else self._dep_plane.data_ptr())
+               0 if self._dep_plane is None else self._dep_plane.data_ptr(),
+               0 if ct[6] is None else ct[6].data_ptr(), 0 if ot[6] is None else ot[6].data_ptr())
         p = self._structs.get(key)
         if p is None:
             if len(self._structs) >= 8:
@@ -107,6 +118,9 @@ class PicState:
                                               _ptr(self.part), _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code),
                                               _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, _ptr(self.queue), 0, 0, 0, 0, 0, 0,
                                               self.n_alive if self.occ is not None else 0, _ptr(self.occ))
+            for lay_i, t in ((cur, ct[6]), (1 - cur, ot[6])):
+                for axis in (0, 1):
+                    p.prev_grad[lay_i][axis] = None if t is None else t[axis].data_ptr()
         L = p.layout
         L[cur].slot, L[1 - cur].slot = ct[3].data_ptr(), ot[3].data_ptr()
         p.N, p.k1_threads, p.stages, p.status_out = self._n_agents, self.k1_threads, stages, status_out
@@ -117,7 +131,7 @@ class PicState:
         here it only settles whether the deposit plane of the three-launch form has to exist.)"""
         if not self.fused:
             return False
-        key = (agent._scale, env.dynamics.diffuse_sigma)
+        key = (agent._scale, env.dynamics.diffuse_sigma, agent._inertia, agent._noise_scale)
         if key == self._two_key:
             return self._two
         self._two_key, self._two = key, self._two_launch(env, agent)
@@ -127,12 +141,12 @@ class PicState:
         """The library's rule (die_pic_two_launch): nothing is restated here."""
         W, H = self._world_shape
         mode = _lib.DIFFUSE_MODES[env.dynamics.diffuse_mode]
-        return _lib.lib.die_pic_two_launch(max(W, H), self.xs, self.ys, float(agent._scale), float(env.dynamics.diffuse_sigma), mode) == 1
+        return _lib.lib.die_pic_two_launch(max(W, H), self.xs, self.ys, step_scale(agent), float(env.dynamics.diffuse_sigma), mode) == 1
 
     def is_current(self, env, agent) -> bool:
         A, h = env.agents, self.held
         return h is not None and self.agent is agent and A.x is h[0] and A.y is h[1] and A.agent_food is h[2] and A.slot is h[3] and \
-            agent._hd_hi is h[4] and agent._hd_lo is h[5] and agent._order is A.slot
+            agent._hd_hi is h[4] and agent._hd_lo is h[5] and agent._order is A.slot and getattr(agent, '_prev_grad', None) is h[6]
 
     def _adopt(self, env, agent, new):
         """The agents now live in `new` = (x, y, agent_food, slot, heading hi, lo): hand the arrays to their owners and keep the
@@ -141,12 +155,19 @@ class PicState:
         self.spare = [A.x, A.y, A.agent_food, agent._hd_hi, agent._hd_lo]
         A.x, A.y, A.agent_food, A.slot = new[0], new[1], new[2], new[3]
         agent._hd_hi, agent._hd_lo = new[4], new[5]
+        if new[6] is not None:
+            self.spare_pg, agent._prev_grad = agent._prev_grad, new[6]
         agent._order = A.slot
         self.held, self.agent = tuple(new), agent
 
     def _out_tensors(self, env):
         slot = torch.empty(self.cap, dtype=torch.int32, device=env.device)
-        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4])
+        pg = None
+        if getattr(self.agent_for_out, '_prev_grad', None) is not None:
+            if self.spare_pg is None or self.spare_pg.shape != (2, self.cap):
+                self.spare_pg = torch.empty((2, self.cap), dtype=torch.float32, device=env.device)
+            pg = self.spare_pg
+        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4], pg)
 
     def bin(self, env, agent):
         """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset.  (The sticky error word is read first
@@ -156,12 +177,22 @@ class PicState:
             self.check()
         A = env.agents
         self._n_agents = int(A.N)
+        self.agent_for_out = agent
+        pg = getattr(agent, '_prev_grad', None)
+        if pg is not None and (pg.dtype != torch.float32 or not pg.is_contiguous() or pg.shape != (2, self.cap)):
+            pg = agent._prev_grad = pg.to(torch.float32).contiguous()
+        if pg is not None and self.spare_pg is pg:
+            self.spare_pg = None                 # (never bin an array into itself)
         out = self._out_tensors(env)
-        cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo)
+        cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo, pg)
         p = self._struct(cur_t, out)
         m, a = env.medium.c_struct(need_owner=False), A.c_struct()
-        _lib.check(_lib.lib.die_pic_bin(C.byref(m), C.byref(a), _ptr(agent._hd_hi), _ptr(agent._hd_lo), C.byref(p), 1 - self.cur,
-                                        stream_ptr(env.device)), 'die_pic_bin')
+        if pg is None:
+            _lib.check(_lib.lib.die_pic_bin(C.byref(m), C.byref(a), _ptr(agent._hd_hi), _ptr(agent._hd_lo), C.byref(p), 1 - self.cur,
+                                            stream_ptr(env.device)), 'die_pic_bin')
+        else:
+            _lib.check(_lib.lib.die_pic_bin_momentum(C.byref(m), C.byref(a), _ptr(agent._hd_hi), _ptr(agent._hd_lo), _ptr(pg[0]), _ptr(pg[1]),
+                                                     C.byref(p), 1 - self.cur, stream_ptr(env.device)), 'die_pic_bin_momentum')
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)
         if self.occ is not None:                 # the array order is now: alive agents (tile by tile), then the dead slots
@@ -205,6 +236,7 @@ class PicState:
         is filled in when somebody reads it — or, if it is still referenced then, before the next step."""
         self.flush_lazy()
         self._n_agents = int(env.agents.N)
+        self.agent_for_out = agent
         if self._dep_plane is None and not self.two_launch(env, agent):
             self._dep_plane = torch.empty(self._plane_shape, dtype=torch.float32, device=env.device)
         out = self._out_tensors(env)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 19
+#define DIE_ABI_VERSION 20
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -440,6 +440,11 @@ typedef struct die_pic {
      * Two-launch form, single-tile worlds. */
     int64_t n_alive;
     uint32_t* occ;
+    /* GradientAgent with momentum on this path (core/agent/gradient.py:82-91: inertia and / or noise; normalised gradient).
+     * prev_grad[l][0 / 1]: _prev_grad's x / y component in the order of layout[l] (N floats each) — the step reads layout[from]'s
+     * and writes layout[1 - from]'s, die_pic_bin carries them from g's arrays into layout[into]'s; all NULL when inertia = 0
+     * (noise alone keeps no state).  The step length the tiles must hold is |scale| * die_pic_step_bound(inertia, noise_scale). */
+    float* prev_grad[2][2];
 } die_pic;
 
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */
@@ -447,6 +452,12 @@ int64_t die_pic_rim_cap(int32_t tile_xs, int32_t tile_ys);
 /* 1 if die_pic_forward_env_step takes the two-launch form for these parameters when rim lists are given (world_max = the longer
  * axis of the WORLD in cells), 0 if it takes three launches (then dep_plane must exist and status_out is not written), -1 for a
  * tile shape that is not compiled in.  The library's own rule: callers need not restate it. */
+/* Largest |component| of the vector a GradientAgent's action is `scale` times, per axis, for a normalised gradient: 1 without
+ * momentum; with it the fixed point of |u'| <= (1 - inertia) + inertia |u| + noise_scale * 2.67 (2.67 = the largest value of the
+ * library's 0.4-sigma Box-Muller normals, which also bounds the initial _prev_grad), i.e.
+ * max(2.67, 1 + 2.67 noise_scale / (1 - inertia)); inertia = 0: 1 + 2.67 noise_scale.  +inf for inertia >= 1.  Callers pass
+ * scale * bound where the rules below ask for `scale`. */
+float die_pic_step_bound(float inertia, float noise_scale);
 int32_t die_pic_two_launch(int32_t world_max, int32_t tile_xs, int32_t tile_ys, float scale, float diffuse_sigma, int32_t diffuse_mode);
 /* number of tiles (words per per-tile array), or -1 if the shape is not compiled in */
 int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
@@ -454,6 +465,9 @@ int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
  * are initialised.  DIE_ERR_UNSUPPORTED unless the world splits into at least 3×3 whole tiles. */
 int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo, const die_pic* p,
                 int32_t into, void* stream);
+/* … and a GradientAgent's _prev_grad (core/agent/gradient.py:42,89), same order, into p->prev_grad[into] (both NULL: die_pic_bin) */
+int die_pic_bin_momentum(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
+                         const float* prev_gx, const float* prev_gy, const die_pic* p, int32_t into, void* stream);
 /* GradientAgent/PhysarumAgent.forward (core/agent/gradient.py:96-124) + Env.step (core/env.py:101-131) on binned agents:
  * two launches when p->rim is given and floor(|scale| * (max(W, H) - 1)) + 2 + gaussian radius <= tile (forward + move + feeding +
  * re-binning + rim lists; per-tile claim resolution + deposit + diffusion + feeding + next offsets + reward), else three

@@ -593,16 +593,22 @@ def _binned_steps_against_the_oracle(die, medium, agents, dyn, tile, agent_kind,
     else:
         dev, ref = die.GradientAgent(max_agents=N, seed=seed, **kw), R.RefGradientAgent(N, seed=seed, **kw)
     dir0 = f32(ref._direction_rads)
-    dev.set_state(dir0)
+    momentum = kw.get('inertia', 0) != 0
+    dev.set_state(dir0, prev_grad=f32(ref._prev_grad) if momentum else None)
     frtol, fatol = (1e-3, 1e-4) if f16 else (RTOL, 1e-7)
     obs = env._get_current_obs
     for step in range(n_steps):
         m0, a0, d0 = env.medium.to_numpy(), env.agents.to_numpy(), dev.direction_rads_numpy()
         ref._direction_rads = d0.copy()
+        if momentum:
+            ref._prev_grad = dev.prev_grad_numpy()
         renv = R.RefEnv(m0, a0, rd)
         want_action = ref.forward(renv.obs)
         action = dev.forward(obs)
         obs, reward, term, _, info = env.step(action)
+        if momentum:                                         # _prev_grad travels with the agents through the tiles (gradient.py:89)
+            bad_pg = ~np.isclose(dev.prev_grad_numpy(), ref._prev_grad, rtol=max(RTOL, frtol), atol=1e-6 + (1e-3 if f16 else 0)).all(axis=0)
+            assert bad_pg.mean() < 2e-3, f'step {step}: _prev_grad differs for {bad_pg.sum()} of {N} slots'
         assert env._pic is not None and env._pic.held is not None and env._pic.held[0] is env.agents.x, 'the tile-binned step did not run'
         assert env._pic.two_launch(env, dev) == (form != 'three launches')
         got_action = action.to_numpy()
@@ -638,6 +644,10 @@ BINNED_ORACLE_CASES = [
     dict(W=192, H=256, tile=(6, 6), zero_cost=True, sigma=0.8, rate_feed=0.3, decay=0.05),    # gaussian radius 3
     dict(W=128, H=192, tile=(5, 6), f16=True),
     dict(W=128, H=192, tile=(5, 6), agent='gradient'),
+    # GradientAgent with momentum (the reference's defaults: inertia .9, noise .025 — gradient.py:19-30): _prev_grad in the layouts
+    dict(W=128, H=192, tile=(5, 6), agent='gradient', inertia=0.9, noise=0.025),
+    dict(W=192, H=192, tile=(6, 6), agent='gradient', inertia=0.5, noise=0.0, collide=0.5),
+    dict(W=64, H=96, tile=(4, 5), agent='gradient', inertia=0.0, noise=0.05, form='three launches'),
     dict(W=192, H=192, tile=(6, 6), dense=True),                             # several agents per cell
     dict(W=64, H=96, tile=(4, 5), form='three launches'),
     dict(W=192, H=192, tile=(6, 6), collide=0.6, form='three launches'),
@@ -666,7 +676,7 @@ def test_tile_binned_step_vs_oracle(die, case):
                        op_action_cost=die.zero_cost if case.get('zero_cost') else die.linear_action_cost,
                        diffuse_sigma=case.get('sigma', 0.5), rate_feed=case.get('rate_feed', 0.1), rate_decay_chem=case.get('decay', 0.1))
     if case.get('agent') == 'gradient':
-        kw = dict(scale=0.01, sense_offset=0.03, inertia=0.0, noise_scale=0.0, normalized_grad=True)
+        kw = dict(scale=0.01, sense_offset=0.03, inertia=case.get('inertia', 0.0), noise_scale=case.get('noise', 0.0), normalized_grad=True)
     else:
         kw = dict(scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
     if case.get('f16'):                                     # fields the device holds exactly
@@ -909,9 +919,11 @@ def test_sync_step_that_failed_before_its_read_does_not_feed_the_next_one(die, m
     assert np.array_equal(ma, mb)
 
 
-def test_tile_binned_step_with_a_gradient_agent(die):
-    """GradientAgent without inertia / noise (normalised gradient: bounded step) takes the binned path too
-    (k_pic_forward_move<T, GRADIENT>): same bits as the classic step."""
+@pytest.mark.parametrize('inertia,noise', [(0.0, 0.0), (0.9, 0.025), (0.0, 0.05), (0.6, 0.0)])
+def test_tile_binned_step_with_a_gradient_agent(die, inertia, noise):
+    """GradientAgent (normalised gradient: bounded step) takes the binned path too (k_pic_forward_move<T, GRADIENT>), with the
+    reference's default momentum (inertia .9, noise .025: core/agent/gradient.py:19-30,82-91) as well — _prev_grad travels through
+    the layouts with the agents: same bits as the classic step, re-sorts of the classic run and a re-bin in between included."""
     W, H, N = 128, 192, 7000
     rs = np.random.RandomState(11)
     medium, agents = random_state(W, H, N, N, rs, collide=0.3)
@@ -919,17 +931,20 @@ def test_tile_binned_step_with_a_gradient_agent(die):
     for pic in (True, False):
         env = die.Env.from_numpy(medium, agents, sort_every=2, pic=pic)
         env._pic_tile = (5, 6) if pic else None
-        ag = die.GradientAgent(max_agents=N, seed=2, scale=0.01, sense_offset=0.03, inertia=0.0, noise_scale=0.0, normalized_grad=True)
+        ag = die.GradientAgent(max_agents=N, seed=2, scale=0.01, sense_offset=0.03, inertia=inertia, noise_scale=noise, normalized_grad=True)
         obs = env._get_current_obs
         acts = []
         for i in range(6):
             action = ag.forward(obs)
             obs, rew, _, _, info = env.step(action)
             acts.append(action.to_numpy())
+            if i == 3 and pic:
+                env._agents_changed()                       # the tile order is void: the next step bins again (prev_grad along)
         if pic:
             assert env._pic is not None and env._pic.held[0] is env.agents.x, 'the tile-binned path did not run'
-        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.stack(acts), np.array([rew, info['num_agents']])))
-    for name, a, b in zip(('medium', 'agents', 'heading', 'actions', 'reward'), outs[0], outs[1]):
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.stack(acts), np.array([rew, info['num_agents']]),
+                     ag.prev_grad_numpy() if inertia else np.zeros(1)))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'actions', 'reward', 'prev_grad'), outs[0], outs[1]):
         assert np.array_equal(a, b), name
 
 

@@ -49,8 +49,9 @@ def test_struct_layouts_match_header(built_lib):
     assert C.sizeof(_lib.PicLayout) == 10 * 8
     assert C.sizeof(_lib.PicSide) == 6 * 4 + 8 + 4 * 8
     # die_pic: tile shape 2 x i32, N i64, two layouts, dep / dep_plane / part_gain / error, k1_threads + stages, rim / rim_code /
-    # rim_cnt / status_out, turn_bits / turn_slots / turn_ready + reserved / queue / sub_mode + rectangle + reserved / n_alive / occ
-    assert C.sizeof(_lib.Pic) == 8 + 8 + 2 * 10 * 8 + 4 * 8 + 8 + 4 * 8 + 8 + 8 + 8 + 8 + 6 * 4 + 8 + 8
+    # rim_cnt / status_out, turn_bits / turn_slots / turn_ready + reserved / queue / sub_mode + rectangle + reserved / n_alive / occ /
+    # prev_grad[2][2]
+    assert C.sizeof(_lib.Pic) == 8 + 8 + 2 * 10 * 8 + 4 * 8 + 8 + 4 * 8 + 8 + 8 + 8 + 8 + 6 * 4 + 8 + 8 + 4 * 8
     assert C.sizeof(_lib.Batch) == 8 + 8 + 8 + 8 + 64 * 8
 
 
@@ -156,3 +157,22 @@ def test_two_launch_rule_is_the_librarys(built_lib):
         want = mode == 0 and 1 <= R <= 4 and int(reach) + 2 + R <= min(1 << xs, 1 << ys)
         assert L.die_pic_two_launch(worldmax, xs, ys, scale, sigma, mode) == int(want), (worldmax, xs, ys, scale, sigma, mode)
     assert L.die_pic_two_launch(4096, 3, 3, 0.001, 0.5, 0) == -1
+
+
+def test_step_bound_of_a_gradient_agent_with_momentum(built_lib):
+    """die_pic_step_bound: per axis, |u'| <= (1 - i)·1 + i·|u| + ns·n_max for a normalised gradient (core/agent/gradient.py:82-91),
+    n_max = the largest 0.4-sigma Box-Muller normal the library draws from a 32-bit uniform: a bound that holds for the initial
+    _prev_grad (the same normals) and is a fixed point of the recurrence."""
+    import math
+    from die_amd import _lib
+    B = _lib.lib.die_pic_step_bound
+    n_max = 0.4 * math.sqrt(-2.0 * math.log(2.0 ** -32))
+    assert 2.66 < n_max < 2.67
+    assert B(0.0, 0.0) == 1.0
+    assert abs(B(0.0, 0.05) - (1 + 0.05 * 2.67)) < 1e-6
+    assert abs(B(0.9, 0.025) - 2.67) < 1e-6                        # the reference's defaults: the initial noise dominates
+    assert abs(B(0.9, 0.5) - (1 + 0.5 * 2.67 / 0.1)) < 1e-4
+    for i, ns in ((0.9, 0.025), (0.5, 0.2), (0.99, 0.01), (0.3, 0.0)):
+        b = B(i, ns)
+        assert b >= n_max and (1 - i) + i * b + ns * n_max <= b * (1 + 1e-6)
+    assert math.isinf(B(1.0, 0.0)) and math.isinf(B(1.5, 0.1))
