@@ -116,7 +116,7 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'current_pmc_traffic_per_kernel_avg.js
 PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_claim': 'void k_move_claim<float>',
              'k_forward_move_claim': 'void k_forward_move_claim<float, 1, false, true>',
              'k_diffuse_rows_fused': 'void k_diffuse_rows<float, 2, 1, true>',
-             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false, true, false>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
+             'k_pic_forward_move': 'void k_pic_forward_move<float, 1, true, false, true, false, false, false>', 'k_pic_resolve': 'void k_pic_resolve<float, 6, 6, true>',
              'k_pic_resolve_diffuse': 'void k_pic_resolve_diffuse<float, 6, 6, 2, false>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
 WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve', 'k_pic_resolve_diffuse')
@@ -136,7 +136,8 @@ def pmc_traffic(kernel, K=0):
         doc = json.load(open(PMC_FILE))
         if doc.get('kernel_source_sha') != kernel_source_sha():
             return None, f'{os.path.relpath(PMC_FILE, ROOT)} was taken from another build of the kernels (sha {doc.get("kernel_source_sha")}): not reported'
-        c = doc[PMC_NAMES[kernel]]
+        name = PMC_NAMES[kernel]
+        c = doc[name] if name in doc else doc[[k for k in doc if k.startswith(name.rstrip('>'))][0]]       # (trailing template arguments may have been added)
         fetch = c['FETCH_SIZE'] * 1024
         if kernel in WIDE_STREAM_KERNELS:
             narrow = NARROW_STREAM_BYTES_PER_AGENT.get(kernel, 0) * K

@@ -210,8 +210,11 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     const float d = (float)d64;             // trigonometry in fp32 (1e-7 of a cell on the probe), decisions in float64
     const die_geo g = a.g;
     const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
+#ifndef DIE_TB_LAZY
+#define DIE_TB_LAZY 0      // 1: the table word is loaded only by the lanes whose turn IS random (A/B: scratch/variants.log)
+#endif
     uint32_t tbits = 0;
-    if (TB && KIND == DIE_AGENT_PHYSARUM) tbits = a.turn_bits[sid >> 5];      // (requested first: needed last)
+    if (TB && KIND == DIE_AGENT_PHYSARUM && !DIE_TB_LAZY) tbits = a.turn_bits[sid >> 5];      // (requested first: needed last)
     float sd, cd;
     die_sincos(d, &sd, &cd);
     // probe cell: agents + sense_offset·(cos d, sin d), nearest label, clamped (gradient.py:73-76,105)
@@ -269,7 +272,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
         double sgn;
         if (und) {
             if (a.turn_sign) sgn = (double)a.turn_sign[sid];
-            else if (TB) sgn = ((tbits >> (sid & 31u)) & 1u) ? 1.0 : -1.0;
+            else if (TB) { if (DIE_TB_LAZY) tbits = a.turn_bits[sid >> 5]; sgn = ((tbits >> (sid & 31u)) & 1u) ? 1.0 : -1.0; }
             else sgn = die_turn_bit(a.seed, a.step + (a.step_base ? *a.step_base : 0u), sid) ? 1.0 : -1.0;
         } else {
             sgn = right ? -1.0 : 1.0;         // right (clockwise) / left

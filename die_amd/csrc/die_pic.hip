@@ -165,6 +165,34 @@ struct PicArgs {
     const float *ipgx, *ipgy;
     float *opgx, *opgy;
 };
+// Workgroups are handed to the 8 XCDs round robin (linear workgroup id modulo 8), and every XCD has its own L2.  With the plain
+// (blockIdx.y, blockIdx.x) = (tx, ty) mapping the tiles that share cache lines — the margins of their staged windows: a row of a
+// window starts 16–48 bytes before a 256-byte boundary and so touches a 128-byte line of each neighbour along y, the margin rows are
+// the neighbours' along x — always sit in DIFFERENT L2s, and every shared line is fetched from memory twice.  PIC_XCD_MAP:
+//   2 (default): a band of columns per XCD — XCD j takes the tiles with ty in [j·nty/8, (j + 1)·nty/8), walked row of tiles by row of
+//      tiles: neighbours along y meet in one L2 at the same time, neighbours along x nty/8 workgroups later, and at any time the 8 XCDs
+//      read the same rows of the planes at different columns (4096² fp32: agent kernel FETCH_SIZE −26 %, 79.8 → 77.6 µs)
+//   1: one contiguous eighth of the tiles per XCD, in memory order — fewer fetches too (−21 %) but SLOWER (82.1 vs 77.4 µs): the 8 XCDs
+//      then walk addresses that differ by exact multiples of an eighth of every array, i.e. the same memory channels at the same time
+//   0: plain
+#ifndef PIC_XCD_MAP
+#define PIC_XCD_MAP 2
+#endif
+__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty) {
+#if PIC_XCD_MAP == 1
+    if (((gridDim.x * gridDim.y) & 7u) == 0) {
+        const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x, G8 = (gridDim.x * gridDim.y) >> 3;
+        const uint32_t nl = (L & 7u) * G8 + (L >> 3);
+        tx = (int)(nl / gridDim.x); ty = (int)(nl - (uint32_t)tx * gridDim.x);
+    }
+#elif PIC_XCD_MAP == 2
+    if ((gridDim.x & 7u) == 0) {                            // (gridDim.x = tiles per row; the field kernel's extra grid row comes last)
+        const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x, wb = gridDim.x >> 3, k = L >> 3;
+        tx = (int)(k / wb); ty = (int)((L & 7u) * wb + (k - (uint32_t)tx * wb));
+    }
+#endif
+}
+
 __device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty) {        // false: not this launch's tile
     if (p.sub_mode == 1) { tx += p.sub_tx0; ty += p.sub_ty0; return true; }
     if (p.sub_mode == 2) return !(tx >= p.sub_tx0 && tx < p.sub_tx0 + p.sub_ntx && ty >= p.sub_ty0 && ty < p.sub_ty0 + p.sub_nty);
@@ -353,6 +381,12 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #endif
 // element `idx` of a 4-byte-per-agent array: a 32-bit byte offset on the array's (scalar) base — the host refuses worlds of
 // 2^30 agents —, so every stream of an agent shares ONE offset register instead of a 64-bit address of its own
+#ifndef PIC_FOOD_COLS
+#define PIC_FOOD_COLS 0         // 1: the agent kernel's food block has a margin of columns too (the round-4 first cut: every new cell from LDS)
+#endif
+#ifndef PIC_TB
+#define PIC_TB true             // the agent kernel reads a PhysarumAgent's random turn bit from the step's table (false: one Philox block per agent whose turn is random)
+#endif
 #define PIC_AT(base, type, idx) (*(type*)((char*)(base) + (size_t)(uint32_t)((uint32_t)(idx) << 2)))
 // PERSIST: a fixed grid of workgroups (three per CU) that draw tiles from a queue (p.queue, one atomic per tile, claimed two
 // tiles ahead) and prefetch the NEXT tile's per-tile words, first stayers and candidate arrivals into registers while they work
@@ -403,6 +437,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile(s) of this workgroup.  PERSIST: two claimed up front (one atomic), then one more per tile, two tiles ahead
     int btx = (int)blockIdx.y, bty = (int)blockIdx.x;
+    if (!PERSIST && p.sub_mode == 0) pic_xcd_tile(btx, bty);
     if (!PERSIST && !pic_sub_tile(p, btx, bty)) return;
     int tile = btx * p.nty + bty, tile1 = NT;
     // the per-tile counters (PERSIST: reset again behind every tile's epilogue — the two barriers of the next tile's ranges lie
@@ -619,8 +654,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     af = PIC_AT(ia_, const float, j);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
-                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, true, false>(f, tm, X, Y, hd, sid, (int64_t)j)
-                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, true, false>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
+                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, PIC_TB, false>(f, tm, X, Y, hd, sid, (int64_t)j)
+                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, PIC_TB, false>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
                 if (MOM) { pux = o.ux; puy = o.uy; }
                 if (ACT && p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
@@ -646,8 +681,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     int rx = cx - x0, ry = cy - y0;                                    // relative to the tile, periodic
                     rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
                     ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
-                    rx = min(max(rx + FR, 0), frows - 1); ry = min(max(ry + FC, 0), fpitch - 1);   // (a longer jump is an error, flagged below: never out of the block)
-                    fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry));
+                    rx = min(max(rx + FR, 0), frows - 1);                              // (a longer jump is an error, flagged below: never out of the block)
+                    // the block has a margin of ROWS only by default (fm_c = 0): a row of the plane starts on a 256-byte boundary of
+                    // the tile, so whole rows cost no partial cache lines, while ± 4 columns made every row touch two more 128-byte
+                    // lines (70 rows × 4 lines instead of 64 × 2: + 65 MB of fetches per step at 4096²).  The few agents that leave
+                    // the tile's columns (≈ 1 % per step at the benchmark's step length) read their cell from global memory
+                    if (ry >= -FC && ry < TY + FC) fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry + FC));
+                    else fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
                 } else {
                     fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
                 }
@@ -1605,6 +1645,10 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         return;
     }
     int tx = blockIdx.y, ty = blockIdx.x;
+#ifndef PIC_XCD_MAP_KB
+#define PIC_XCD_MAP_KB 1
+#endif
+    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile(tx, ty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
@@ -2222,7 +2266,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // the food block: the tile ± the cells an agent can walk onto in one step (floor(reach) + 1 by the move, one more across the
     // world's seam), columns in whole vectors
     k.fm_r = stage ? (int)floorf(reach) + 2 : 0;
-    k.fm_c = (k.fm_r + V - 1) / V * V;
+    // (columns: only for the persistent agent kernel, which has no path to global memory in its compute waves; PIC_FOOD_COLS = 1: always)
+    k.fm_c = (PIC_FOOD_COLS || p->k1_threads == -1) ? (k.fm_r + V - 1) / V * V : 0;
     const int vpr_c = (TY + 2 * k.margin) / V, vpr_f = (TY + 2 * k.fm_c) / V;     // 16-byte vectors per staged row
     k.mg_c = ((1u << 20) + (uint32_t)vpr_c - 1u) / (uint32_t)vpr_c;
     k.mg_f = ((1u << 20) + (uint32_t)vpr_f - 1u) / (uint32_t)vpr_f;

@@ -638,6 +638,9 @@ def _binned_steps_against_the_oracle(die, medium, agents, dyn, tile, agent_kind,
 
 BINNED_ORACLE_CASES = [
     dict(W=64, H=96, tile=(4, 5)),
+    # 8 and 16 tiles per row: the workgroup → tile mapping by XCD bands (die_pic.hip pic_xcd_tile) is on the path
+    dict(W=48, H=256, tile=(4, 5), collide=0.5),
+    dict(W=64, H=512, tile=(4, 5), boundary='limit'),
     dict(W=192, H=192, tile=(6, 6), collide=0.6),                            # forced collisions: last writer wins
     dict(W=96, H=192, tile=(5, 6), boundary='limit'),
     dict(W=96, H=384, tile=(5, 7), food_infinite=True),
