@@ -178,17 +178,26 @@ struct PicArgs {
 #ifndef PIC_XCD_MAP
 #define PIC_XCD_MAP 2
 #endif
-__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty) {
+template <bool REVERSE = false>
+__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx) {      // ntx: rows of tiles (the grid may have one row more)
 #if PIC_XCD_MAP == 1
-    if (((gridDim.x * gridDim.y) & 7u) == 0) {
-        const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x, G8 = (gridDim.x * gridDim.y) >> 3;
+    if (((gridDim.x * (uint32_t)ntx) & 7u) == 0) {
+        const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x, G8 = (gridDim.x * (uint32_t)ntx) >> 3;
         const uint32_t nl = (L & 7u) * G8 + (L >> 3);
         tx = (int)(nl / gridDim.x); ty = (int)(nl - (uint32_t)tx * gridDim.x);
     }
 #elif PIC_XCD_MAP == 2
-    if ((gridDim.x & 7u) == 0) {                            // (gridDim.x = tiles per row; the field kernel's extra grid row comes last)
-        const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x, wb = gridDim.x >> 3, k = L >> 3;
+    // (gridDim.x = tiles per row.  Bands of wb = floor(nty / 8) columns; the nty mod 8 columns left over — a decomposed rank's planes:
+    // 68 tiles per row — come last, in the plain order)
+    const uint32_t nty = gridDim.x, wb = nty >> 3, banded = (wb << 3) * (uint32_t)ntx;
+    const uint32_t L = blockIdx.y * nty + blockIdx.x;
+    if (wb == 0) return;
+    if (L < banded) {
+        const uint32_t k = REVERSE ? wb * (uint32_t)ntx - 1u - (L >> 3) : L >> 3;      // (REVERSE: the band walked from its far end — A/B only)
         tx = (int)(k / wb); ty = (int)((L & 7u) * wb + (k - (uint32_t)tx * wb));
+    } else {
+        const uint32_t r = L - banded, rem = nty - (wb << 3);
+        tx = (int)(r / rem); ty = (int)((wb << 3) + (r - (uint32_t)tx * rem));
     }
 #endif
 }
@@ -437,7 +446,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile(s) of this workgroup.  PERSIST: two claimed up front (one atomic), then one more per tile, two tiles ahead
     int btx = (int)blockIdx.y, bty = (int)blockIdx.x;
-    if (!PERSIST && p.sub_mode == 0) pic_xcd_tile(btx, bty);
+    if (!PERSIST && p.sub_mode == 0) pic_xcd_tile(btx, bty, p.ntx);
     if (!PERSIST && !pic_sub_tile(p, btx, bty)) return;
     int tile = btx * p.nty + bty, tile1 = NT;
     // the per-tile counters (PERSIST: reset again behind every tile's epilogue — the two barriers of the next tile's ranges lie
@@ -1646,9 +1655,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     }
     int tx = blockIdx.y, ty = blockIdx.x;
 #ifndef PIC_XCD_MAP_KB
-#define PIC_XCD_MAP_KB 1
+#define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile(tx, ty);
+    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
