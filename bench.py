@@ -120,16 +120,14 @@ PMC_NAMES = {'k_gradient_forward': 'void k_gradient_forward<float, 1>', 'k_move_
              'k_pic_resolve_diffuse': 'void k_pic_resolve_diffuse<float, 6, 6, 2, false>',
              'k_diffuse_rows_dep': 'void k_diffuse_rows<float, 2, 2, true>'}
 WIDE_STREAM_KERNELS = ('k_diffuse_rows_fused', 'k_diffuse_rows_dep', 'k_pic_forward_move', 'k_pic_resolve', 'k_pic_resolve_diffuse')
-# bytes per agent that the tile-binned kernels read as 4-byte-per-lane streams (counted in full by FETCH_SIZE; only the
-# 16-byte-per-lane tile loads are under-counted): K1 x, y, slot, heading hi/lo, agent_food; K2 x, y, slot, deposit
-NARROW_STREAM_BYTES_PER_AGENT = {'k_pic_forward_move': 24, 'k_pic_resolve': 16, 'k_pic_resolve_diffuse': 16}
-
-
 def pmc_traffic(kernel, K=0):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this same command
-    (profiles/README.md): (FETCH_SIZE + WRITE_SIZE) KiB.  FETCH_SIZE under-counts wide coalesced streams by 2x on gfx950
-    (MI355X_MICROARCH.md): the 16-byte-per-lane loads of the sweep and of the tile staging are doubled, the 4-byte-per-lane
-    agent streams of the tile-binned kernels (NARROW_STREAM_BYTES_PER_AGENT x K) are counted in full and left as they are.
+    (profiles/README.md): (2 x FETCH_SIZE + WRITE_SIZE) KiB.  On gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B while the L2 fetches
+    128-byte lines (MI355X_MICROARCH.md: exactly half of a wide coalesced stream): doubled for the kernels whose reads are
+    coalesced streams.  Calibrated on this path (round 4, profiles/r04_final_ea_requests.txt): TCC_EA0_RDREQ of the agent kernel
+    x 128 B = 208 MB against the 194 MB + lists it must read at least (both planes once, the agent streams once) — the
+    4-byte-per-lane agent streams are requests of whole lines too, so nothing is exempt from the factor (rounds 2-3 exempted them
+    and reported 628 MB per step where this rule gives 729).
     The file carries the sha of the kernel sources it was taken from: when the sources have changed since, the figure
     would be stale and is reported as null."""
     try:
@@ -140,10 +138,9 @@ def pmc_traffic(kernel, K=0):
         c = doc[name] if name in doc else doc[[k for k in doc if k.startswith(name.rstrip('>'))][0]]       # (trailing template arguments may have been added)
         fetch = c['FETCH_SIZE'] * 1024
         if kernel in WIDE_STREAM_KERNELS:
-            narrow = NARROW_STREAM_BYTES_PER_AGENT.get(kernel, 0) * K
-            fetch = 2 * (fetch - narrow) + narrow if fetch > narrow else 2 * fetch
+            fetch *= 2
         return int(fetch + c['WRITE_SIZE'] * 1024), (f'{os.path.relpath(PMC_FILE, ROOT)} (separate --pmc passes of this command, '
-                                                      f'kernel sources sha {doc["kernel_source_sha"]})')
+                                                      f'kernel sources sha {doc["kernel_source_sha"]}; FETCH_SIZE x 2: 128-byte lines)')
     except Exception as e:
         return None, f'unavailable: {type(e).__name__}'
 

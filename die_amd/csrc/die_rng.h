@@ -43,7 +43,11 @@ __host__ __device__ inline die_u32x4 die_draw(uint64_t seed, uint32_t step, uint
 // evaluates the block itself (die_turn_bit) or reads the table a generator kernel has filled (die_turn_bits_fill,
 // die_pic.hip: 1/128 of the Philox work per step) — same bits; oracle/rng.py turn_signs is the numpy twin.
 __host__ __device__ inline uint32_t die_turn_word(uint64_t seed, uint32_t step, uint32_t w) {
-    return die_philox(w >> 2, 0u, step, DIE_STREAM_TURN, (uint32_t)seed, (uint32_t)(seed >> 32)).v[w & 3u];
+    const die_u32x4 r = die_philox(w >> 2, 0u, step, DIE_STREAM_TURN, (uint32_t)seed, (uint32_t)(seed >> 32));
+    // (selects, not r.v[w & 3]: a dynamically indexed register array is moved to LDS by the compiler — in the classic agent kernel
+    // that took 5 KB of LDS per workgroup and, at 1024², 34 µs instead of 13)
+    const uint32_t lo = (w & 1u) ? r.v[1] : r.v[0], hi = (w & 1u) ? r.v[3] : r.v[2];
+    return (w & 2u) ? hi : lo;
 }
 __host__ __device__ inline uint32_t die_turn_bit(uint64_t seed, uint32_t step, uint32_t slot) {
     return (die_turn_word(seed, step, slot >> 5) >> (slot & 31u)) & 1u;

@@ -449,6 +449,8 @@ class Env(_EnvBase):
     # ------------------------------------------------------------------ tile-binned step (die_amd/pic.py)
     def _pic_applies(self, action) -> bool:
         d, ag = self.dynamics, action.agent
+        if self._pic_tile is False:                              # (settled at the first step: this world is too small / does not divide into tiles)
+            return False
         # (dead slots — the reference's default max_agents = W·H — ride behind the tiles' segments: without agents_die they stay dead)
         if not (self._pic_enabled and not d.agents_die and not d.apply_sense_mask and not self._staged
                 and self.medium.world is None and isinstance(d.boundary, BoundaryCondition) and d.diffuse_mode == 'wrap'
@@ -461,8 +463,8 @@ class Env(_EnvBase):
             return False                                         # (a PhysarumAgent with momentum, momentum with dead slots: the classic step)
         if not momentum and ag._prev_grad is not None:
             return False
-        from .pic import step_scale
         W, H = self._field_size
+        from .pic import step_scale
         eff_scale = step_scale(ag)                               # |scale| · the bound of the vector it multiplies (momentum: die_pic_step_bound)
         reach = abs(eff_scale) * (max(W, H) - 1)                 # cells per step, at most
         if self._pic_tile is None:

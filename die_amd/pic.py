@@ -27,10 +27,16 @@ def pick_tile(W: int, H: int, reach_cells: float, shapes=TILE_SHAPES) -> Optiona
 
 def step_scale(agent) -> float:
     """`scale` times the per-axis bound of the vector the action is `scale` times (die_pic_step_bound: 1 without momentum), as the
-    library computes it in float32: what the tile rules take for `scale`."""
+    library computes it in float32: what the tile rules take for `scale`.  (Kept per agent: it is asked for at every step.)"""
+    key = (agent._scale, agent._inertia, agent._noise_scale)
+    hit = agent.__dict__.get('_pic_step_scale')
+    if hit is not None and hit[0] == key:
+        return hit[1]
     import numpy as np
     bound = _lib.lib.die_pic_step_bound(float(agent._inertia), float(agent._noise_scale))
-    return float(np.float32(agent._scale) * np.float32(bound))
+    value = float(np.float32(agent._scale) * np.float32(bound))
+    agent.__dict__['_pic_step_scale'] = (key, value)
+    return value
 
 
 def lazy_ok(agent) -> bool:
