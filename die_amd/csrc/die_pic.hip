@@ -74,6 +74,8 @@ template <int BIT> __device__ __forceinline__ void pic_st2(void* a, uint2 v) {
     if constexpr (pic_nt(BIT)) { pic_u2v t; t.x = v.x; t.y = v.y; __builtin_nontemporal_store(t, (pic_u2v*)a); }
     else *(uint2*)a = v;
 }
+// st_sel: the store's cache policy chosen at run time (wave-uniform flag): non-temporal when the step's state does not fit the
+// 256 MiB Infinity Cache anyway (KbArgs.nt_out)
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
     template <int BIT = -1> static __device__ __forceinline__ void ld(const float* p, float v[4]) {
@@ -82,6 +84,11 @@ template <> struct Vec4<float> {
     }
     template <int BIT = -1> static __device__ __forceinline__ void st(float* p, const float v[4]) {
         pic_st4<BIT>(p, make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])));
+    }
+    template <int BIT = -1> static __device__ __forceinline__ void st_sel(bool nt, float* p, const float v[4]) {
+        if (pic_nt(BIT) || !nt) { st<BIT>(p, v); return; }
+        pic_u4v t; t.x = __float_as_uint(v[0]); t.y = __float_as_uint(v[1]); t.z = __float_as_uint(v[2]); t.w = __float_as_uint(v[3]);
+        __builtin_nontemporal_store(t, (pic_u4v*)p);
     }
 };
 template <> struct Vec4<__half> {
@@ -94,6 +101,12 @@ template <> struct Vec4<__half> {
         const __half2 a = __halves2half2(die_f2h(v[0]), die_f2h(v[1])), b = __halves2half2(die_f2h(v[2]), die_f2h(v[3]));
         uint2 t; t.x = *(const uint32_t*)&a; t.y = *(const uint32_t*)&b;
         pic_st2<BIT>(p, t);
+    }
+    template <int BIT = -1> static __device__ __forceinline__ void st_sel(bool nt, __half* p, const float v[4]) {
+        if (pic_nt(BIT) || !nt) { st<BIT>(p, v); return; }
+        const __half2 a = __halves2half2(die_f2h(v[0]), die_f2h(v[1])), b = __halves2half2(die_f2h(v[2]), die_f2h(v[3]));
+        pic_u2v t; t.x = *(const uint32_t*)&a; t.y = *(const uint32_t*)&b;
+        __builtin_nontemporal_store(t, (pic_u2v*)p);
     }
 };
 
@@ -390,6 +403,9 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #endif
 // element `idx` of a 4-byte-per-agent array: a 32-bit byte offset on the array's (scalar) base — the host refuses worlds of
 // 2^30 agents —, so every stream of an agent shares ONE offset register instead of a 64-bit address of its own
+#ifndef PIC_NT_OUT
+#define PIC_NT_OUT (-1)         // field kernel's plane stores non-temporal: −1 by the state's size (die_pic_forward_env_step), 0 never, 1 always
+#endif
 #ifndef PIC_FOOD_COLS
 #define PIC_FOOD_COLS 0         // 1: the agent kernel's food block has a margin of columns too (the round-4 first cut: every new cell from LDS)
 #endif
@@ -749,13 +765,17 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     uint32_t *ox_ = PIC_KP(out.x, uint32_t*), *oy_ = PIC_KP(out.y, uint32_t*), *os_ = PIC_KP(out.slot, uint32_t*);
                     uint32_t *ohh_ = PIC_KP(out.hhi, uint32_t*), *ohl_ = PIC_KP(out.hlo, uint32_t*);
                     float *oa_ = PIC_KP(out.agent_food, float*), *od_ = PIC_KP(dep, float*);
-                    PIC_AT(ox_, uint32_t, q) = X;                  // (x, y, slot, deposit are read again by the field kernel)
-                    PIC_AT(oy_, uint32_t, q) = Y;
-                    PIC_AT(oa_, float, q) = af;
-                    PIC_AT(os_, uint32_t, q) = sid;
-                    PIC_AT(ohh_, uint32_t, q) = (uint32_t)__double2hiint(hd);
-                    PIC_AT(ohl_, uint32_t, q) = (uint32_t)__double2loint(hd);
-                    PIC_AT(od_, float, q) = dep;
+#ifndef PIC_K1_NT_ST
+#define PIC_K1_NT_ST 0          // bit 0: x, y, slot, deposit (the field kernel reads them next); bit 1: agent_food, heading — non-temporal stores (A/B)
+#endif
+#define PIC_ST(bit, base, type, idx, val) do { if ((PIC_K1_NT_ST >> (bit)) & 1) __builtin_nontemporal_store((type)(val), &PIC_AT(base, type, idx)); else PIC_AT(base, type, idx) = (val); } while (0)
+                    PIC_ST(0, ox_, uint32_t, q, X);                // (x, y, slot, deposit are read again by the field kernel)
+                    PIC_ST(0, oy_, uint32_t, q, Y);
+                    PIC_ST(1, oa_, float, q, af);
+                    PIC_ST(0, os_, uint32_t, q, sid);
+                    PIC_ST(1, ohh_, uint32_t, q, (uint32_t)__double2hiint(hd));
+                    PIC_ST(1, ohl_, uint32_t, q, (uint32_t)__double2loint(hd));
+                    PIC_ST(0, od_, float, q, dep);
                     if (MOM && p.opgx) { PIC_AT(p.opgx, float, q) = pux; PIC_AT(p.opgy, float, q) = puy; }
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
@@ -1553,6 +1573,7 @@ struct KbArgs {
     long long alive_const;
     long long* status_out;                                  // where the reduction workgroup copies the error word (die_pic.status_out), or NULL
     const uint32_t* error;
+    int nt_out;                                             // the chem and food stores are non-temporal (die_pic_forward_env_step decides by the state's size)
     int n_part;                                             // reward partials in part_gain: one per tile, + (dead slots) one per workgroup of k_pic_dead
     uint32_t* turn_bits;                                    // the NEXT step's random turn bits (pic_turn_bits_fill), or NULL
     int64_t turn_words;
@@ -1839,7 +1860,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             if (occ[0] || occ[1] || occ[2] || occ[3]) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
-                Vec4<T>::template st<9>(food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
+                Vec4<T>::template st_sel<9>(a.nt_out != 0, food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
             }
         }
     }
@@ -1887,7 +1908,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             for (int k = 0; k < R; ++k) t += (xf[cc - R + k] + xf[cc + R - k]) * a.w[k];
             o[j] = t * a.keep;
         }
-        Vec4<T>::template st<6>(dst + (int64_t)(x0 + row) * H + y0 + 4 * cg, o);
+        Vec4<T>::template st_sel<6>(a.nt_out != 0, dst + (int64_t)(x0 + row) * H + y0 + 4 * cg, o);
     }
     PIC_STAMP(14);
 }
@@ -2394,6 +2415,14 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
             a.result = result; a.alive_const = dead ? p->n_alive : p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
             a.n_part = NT + (dead ? dead_blocks : 0);
+            // cache policy of the field kernel's two plane stores.  Measured (profiles/r04_nt_stores_by_size.txt): with the planes and
+            // agent arrays beyond the 256 MiB Infinity Cache (4096² fp32: 342 MB, 8192²) non-temporal stores make the step 3.5 % / 2 %
+            // faster — the lines would be evicted before the next kernel reads them anyway and only displace the windows' shared
+            // lines from L2 —, below it (4096² fp16: 241 MB, 2048²) they cost 1–3 %: the next kernel finds them in the cache
+            {
+                const double state = 3.0 * (double)m->W * m->H * esz + 2.0 * 28.0 * (double)p->N;
+                a.nt_out = PIC_NT_OUT < 0 ? (state > 256.0 * 1024 * 1024 ? 1 : 0) : PIC_NT_OUT;
+            }
             a.turn_bits = physarum && !g->turn_sign && k.nty > 2 ? p->turn_bits : nullptr;
             a.turn_words = turn_words; a.turn_seed = g->seed; a.turn_step = g->step + 1u;
             if (tiled) {
