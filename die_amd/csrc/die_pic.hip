@@ -1369,20 +1369,21 @@ __global__ __launch_bounds__(PA_WAVES * DIE_WAVE, 4) void k_pic_agents(FwdArgs f
 // core/env.py:163-172 moves every slot; :224-243 feeds every slot from rate·food·(agents > 0) and sums `gained` over all of them) —
 // it only never claims, deposits or marks a cell.  The binned layouts hold the alive agents in their tiles' segments, entries
 // [0, n_alive), and the dead slots behind them, entries [n_alive, N), in any fixed order; per step, between the agent kernel and the
-// field kernel:  k_pic_mark — the cells the alive agents stand on NOW, one bit per cell (the 'agents' channel of this step, which the
-// binned path never materialises: 2 MB at 4096², L2-resident) — and k_pic_dead — forward from global memory, move, feeding from the
+// field kernel:  k_pic_mark — the cells the alive agents stand on NOW, one byte per cell (the 'agents' channel of this step, which the
+// binned path never materialises: 16 MB at 4096²) — and k_pic_dead — forward from global memory, move, feeding from the
 // food plane as it still is BEFORE the field kernel's consumption, reward partial per workgroup.
-__global__ __launch_bounds__(DIE_BLOCK) void k_pic_mark(PicArgs p, uint32_t n_alive, uint32_t* occ) {
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_mark(PicArgs p, uint32_t n_alive, uint8_t* occ) {
+    // one BYTE per cell, plain stores (every writer writes 1: no atomics — a bit per cell with atomicOr took 83 µs for 2.5 M agents,
+    // neighbouring lanes hitting the same words)
     const uint32_t stride = gridDim.x * blockDim.x;
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n_alive; j += stride) {
         const int cx = die_cell_u(p.out.x[j], p.g.gW), cy = die_cell_u(p.out.y[j], p.g.gH);
-        const uint32_t c = (uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy;
-        atomicOr(&occ[c >> 5], 1u << (c & 31u));
+        occ[(uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy] = 1;
     }
 }
 
 template <typename T, int KIND>
-__global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, uint32_t first, uint32_t count, const uint32_t* occ, long long* part) {
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, uint32_t first, uint32_t count, const uint8_t* occ, long long* part, uint32_t nslots) {
     f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
     f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
     f.g = p.g;
@@ -1408,7 +1409,7 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, ui
         const int cx = die_cell_u(X, p.g.gW), cy = die_cell_u(Y, p.g.gH);
         const uint32_t c = (uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy;
         // _agent_feed (core/env.py:224-233): a dead slot "consumes" iff somebody alive stands on its cell
-        const bool occupied = (occ[c >> 5] >> (c & 31u)) & 1u;
+        const bool occupied = occ[c] != 0;
         const float consumed = occupied ? p.rate_feed * die_ld(food, (int64_t)c) : 0.f;
         const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
         const float gained = consumed - cost;
@@ -1424,7 +1425,8 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, ui
     if (threadIdx.x == 0) {
         long long t = 0;
         for (int w = 0; w < DIE_BLOCK / DIE_WAVE; ++w) t += s_g[w];
-        part[blockIdx.x] = t;
+        if (gridDim.x <= nslots) part[blockIdx.x] = t;
+        else atomicAdd((unsigned long long*)&part[blockIdx.x % nslots], (unsigned long long)t);      // (integers: any order; the slots were zeroed)
     }
 }
 
@@ -2382,22 +2384,32 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
 #undef DIE_PIC_K1
     }
     // dead slots (two-launch form): the cells the alive agents stand on now, then the slots that never lived
-    const int dead_blocks = dead ? (int)((p->N - p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK < NT ? (p->N - p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK : NT) : 0;
+#ifndef PIC_DEAD_BLOCKS_CAP
+#define PIC_DEAD_BLOCKS_CAP 0          // workgroups of k_pic_dead: 0 = one slot per thread, else at most this many (grid-stride)
+#endif
+    const int64_t dead_want = dead ? (p->N - p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK : 0;
+    const int64_t dead_launch = PIC_DEAD_BLOCKS_CAP > 0 && dead_want > PIC_DEAD_BLOCKS_CAP ? PIC_DEAD_BLOCKS_CAP : dead_want;
+    const int dead_blocks = (int)(dead_launch < NT ? dead_launch : NT);       // reward partials the field kernel sums behind the tiles'
     if (dead) {
         DIE_REQUIRE(two, "die_pic_forward_env_step: dead slots exist in the two-launch form only");
         if (stages & 1) {
-            hipError_t e = hipMemsetAsync(p->occ, 0, ((size_t)m->W * m->H + 31) / 32 * 4, s);
+            hipError_t e = hipMemsetAsync(p->occ, 0, (size_t)m->W * m->H, s);
             if (e != hipSuccess) { die_set_error("die_pic_forward_env_step: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
             const int64_t gm = (p->n_alive + DIE_BLOCK - 1) / DIE_BLOCK;
-            k_pic_mark<<<(int)(gm < 4096 ? gm : 4096), DIE_BLOCK, 0, s>>>(k, (uint32_t)p->n_alive, p->occ);
+            k_pic_mark<<<(int)gm, DIE_BLOCK, 0, s>>>(k, (uint32_t)p->n_alive, (uint8_t*)p->occ);
             long long* part = (long long*)p->part_gain + NT;
+            if (dead_launch > NT) {
+                e = hipMemsetAsync(part, 0, (size_t)NT * 8, s);
+                if (e != hipSuccess) { die_set_error("die_pic_forward_env_step: memset failed: %s", hipGetErrorString(e)); return DIE_ERR_HIP; }
+            }
             const uint32_t first = (uint32_t)p->n_alive, count = (uint32_t)(p->N - p->n_alive);
+            const int dg = (int)dead_launch;
             if (m->dtype == DIE_F32) {
-                if (physarum) k_pic_dead<float, DIE_AGENT_PHYSARUM><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
-                else k_pic_dead<float, DIE_AGENT_GRADIENT><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
+                if (physarum) k_pic_dead<float, DIE_AGENT_PHYSARUM><<<dg, DIE_BLOCK, 0, s>>>(f, k, first, count, (const uint8_t*)p->occ, part, (uint32_t)NT);
+                else k_pic_dead<float, DIE_AGENT_GRADIENT><<<dg, DIE_BLOCK, 0, s>>>(f, k, first, count, (const uint8_t*)p->occ, part, (uint32_t)NT);
             } else {
-                if (physarum) k_pic_dead<__half, DIE_AGENT_PHYSARUM><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
-                else k_pic_dead<__half, DIE_AGENT_GRADIENT><<<dead_blocks, DIE_BLOCK, 0, s>>>(f, k, first, count, p->occ, part);
+                if (physarum) k_pic_dead<__half, DIE_AGENT_PHYSARUM><<<dg, DIE_BLOCK, 0, s>>>(f, k, first, count, (const uint8_t*)p->occ, part, (uint32_t)NT);
+                else k_pic_dead<__half, DIE_AGENT_GRADIENT><<<dg, DIE_BLOCK, 0, s>>>(f, k, first, count, (const uint8_t*)p->occ, part, (uint32_t)NT);
             }
         }
     }

@@ -76,9 +76,9 @@ class PicState:
         self.turn_bits = torch.zeros(4 * ((self.turn_slots + 127) // 128), dtype=torch.int32, device=dev)
         self._turn_for = None
         # the reference's default slot layout (max_agents = W·H: most slots never lived): the alive agents in the tiles' segments,
-        # the dead slots behind them (include/die_hip.h `die_pic.n_alive`); `occ`: this step's occupancy bitmap for their feeding
+        # the dead slots behind them (include/die_hip.h `die_pic.n_alive`); `occ`: this step's occupancy map (a byte per cell) for their feeding
         self.n_alive = int(getattr(env, '_pic_n_alive', 0) or 0)
-        self.occ = torch.zeros((W * H + 31) // 32, dtype=torch.int32, device=dev) if 0 < self.n_alive < N else None
+        self.occ = torch.zeros(W * H, dtype=torch.uint8, device=dev) if 0 < self.n_alive < N else None
         # die_pic.queue: the agent kernel as a fixed grid that draws tiles from a queue (opt-in: slower at every size measured)
         self.queue = torch.zeros(2, dtype=torch.int32, device=dev) if (getattr(env, '_pic_queue', False) or os.environ.get('DIE_PIC_QUEUE', '0') == '1') else None
         self.part = torch.zeros(2 * self.NT, dtype=torch.int64, device=dev)       # reward partials | owned agents (decomposed tiles)

@@ -435,11 +435,11 @@ typedef struct die_pic {
     /* The reference's default slot layout on this path (core/data_init.py:143-144: max_agents = W*H slots, most of which never
      * lived): the tiles' segments hold the n_alive alive agents, entries [0, n_alive) of the arrays, the dead slots lie behind them,
      * entries [n_alive, N), where die_pic_bin puts them.  A dead slot acts, moves, burns and "consumes" like the reference's
-     * (core/env.py:163-172, 224-243) — from the occupancy bitmap `occ` (one bit per cell: the cells alive agents stand on in this
-     * step; scratch, (W*H + 31) / 32 words) — and never claims, deposits or marks a cell.  0 (or N): every slot is alive.
+     * (core/env.py:163-172, 224-243) — from the occupancy map `occ` (one BYTE per cell: the cells alive agents stand on in this
+     * step; scratch, W*H bytes) — and never claims, deposits or marks a cell.  0 (or N): every slot is alive.
      * Two-launch form, single-tile worlds. */
     int64_t n_alive;
-    uint32_t* occ;
+    void* occ;
     /* GradientAgent with momentum on this path (core/agent/gradient.py:82-91: inertia and / or noise; normalised gradient).
      * prev_grad[l][0 / 1]: _prev_grad's x / y component in the order of layout[l] (N floats each) — the step reads layout[from]'s
      * and writes layout[1 - from]'s, die_pic_bin carries them from g's arrays into layout[into]'s; all NULL when inertia = 0

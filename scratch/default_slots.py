@@ -6,8 +6,9 @@ import die_amd
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+akw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1)) if (len(sys.argv) > 3 and sys.argv[3] == 'bench') else {}
 env = die_amd.Env((W, W), die_amd.Dynamics(init_agent_ratio=0.15), seed=0, device='cuda:0', max_agents=None, sync=False)
-agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=0)
+agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=0, **akw)
 obs = env._get_current_obs
 for _ in range(30):
     obs, *_ = env.step(agent.forward(obs))
