@@ -406,6 +406,10 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_NT_OUT
 #define PIC_NT_OUT (-1)         // field kernel's plane stores non-temporal: −1 by the state's size (die_pic_forward_env_step), 0 never, 1 always
 #endif
+#ifndef PIC_K1_NT_LD
+#define PIC_K1_NT_LD 0          // agent kernel: its six agent streams (own segment: read once) loaded non-temporally (A/B)
+#endif
+#define PIC_LDN(base, type, idx) (PIC_K1_NT_LD ? __builtin_nontemporal_load(&PIC_AT(base, type, idx)) : PIC_AT(base, type, idx))
 #ifndef PIC_FOOD_COLS
 #define PIC_FOOD_COLS 0         // 1: the agent kernel's food block has a margin of columns too (the round-4 first cut: every new cell from LDS)
 #endif
@@ -515,9 +519,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         pX = 0; pY = 0; pS = 0; pHh = 0; pHl = 0; pA = 0.f;
         if (pidx < own) {
             const uint32_t j = base0 + pidx;
-            pX = PIC_AT(p.in.x, const uint32_t, j); pY = PIC_AT(p.in.y, const uint32_t, j); pS = PIC_AT(p.in.slot, const uint32_t, j);
-            pHh = PIC_AT(p.in.hhi, const uint32_t, j); pHl = PIC_AT(p.in.hlo, const uint32_t, j);
-            pA = PIC_AT(p.in.agent_food, const float, j);
+            pX = PIC_LDN(p.in.x, const uint32_t, j); pY = PIC_LDN(p.in.y, const uint32_t, j); pS = PIC_LDN(p.in.slot, const uint32_t, j);
+            pHh = PIC_LDN(p.in.hhi, const uint32_t, j); pHl = PIC_LDN(p.in.hlo, const uint32_t, j);
+            pA = PIC_LDN(p.in.agent_food, const float, j);
         }
     };
     if (PERSIST && tile < NT) {                                    // the first tile's: nothing to hide them behind
@@ -674,9 +678,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     const uint32_t *ix_ = PIC_KP(in.x, const uint32_t*), *iy_ = PIC_KP(in.y, const uint32_t*), *is_ = PIC_KP(in.slot, const uint32_t*);
                     const uint32_t *ihh_ = PIC_KP(in.hhi, const uint32_t*), *ihl_ = PIC_KP(in.hlo, const uint32_t*);
                     const float* ia_ = PIC_KP(in.agent_food, const float*);
-                    X = PIC_AT(ix_, const uint32_t, j); Y = PIC_AT(iy_, const uint32_t, j); sid = PIC_AT(is_, const uint32_t, j);
-                    hh = PIC_AT(ihh_, const uint32_t, j); hl = PIC_AT(ihl_, const uint32_t, j);
-                    af = PIC_AT(ia_, const float, j);
+                    X = PIC_LDN(ix_, const uint32_t, j); Y = PIC_LDN(iy_, const uint32_t, j); sid = PIC_LDN(is_, const uint32_t, j);
+                    hh = PIC_LDN(ihh_, const uint32_t, j); hl = PIC_LDN(ihl_, const uint32_t, j);
+                    af = PIC_LDN(ia_, const float, j);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
                 const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, PIC_TB, false>(f, tm, X, Y, hd, sid, (int64_t)j)
