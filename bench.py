@@ -86,6 +86,7 @@ def parse():
     p.add_argument('--replicas', type=int, default=0, help='batched env replicas on one GPU (BASELINE configs[4]): R worlds of --size in one launch pair; value = replica-steps/s')
     p.add_argument('--force-dist', action='store_true', help='use the decomposed path even on one rank (testing)')
     p.add_argument('--prewarm', type=int, default=PREWARM_STEPS, help='untimed world steps before --warmup (fixed: every box times the same world steps)')
+    p.add_argument('--step-events-in-timed-region', action='store_true', help='record the per-step HIP events inside the timed region (rounds 1-3 did; default: in a second, untimed pass of K steps)')
     p.add_argument('--no-extras', action='store_true', help='skip the side measurements (sync=True, reference-default slot count)')
     return p.parse_args()
 
@@ -484,16 +485,30 @@ def main():
         for _ in range(args.warmup):
             obs, res, *_ = env.step(agent.forward(obs))
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        inline = args.step_events_in_timed_region
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ev[0].record()
+        if inline:
+            ev[0].record()
         for i in range(args.steps):
             obs, res, *_ = env.step(agent.forward(obs))
-            ev[i + 1].record()
+            if inline:
+                ev[i + 1].record()
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
+        if not inline:
+            # the per-step distribution (step_ms) from a SECOND pass of K steps, outside the timed region: an event after every
+            # step is a marker packet between the step's last kernel and the next step's first one — it costs the loop ≈ 2 % that a
+            # caller's loop does not pay (measured: profiles/r04_step_events_cost.txt)
+            last = res.clone()
+            ev[0].record()
+            for i in range(args.steps):
+                obs, res2, *_ = env.step(agent.forward(obs))
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            res = last
         per_step = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps))
         return dt, res, per_step, n_pre
 
@@ -518,6 +533,7 @@ def main():
                                'and is re-derived bit-identically when read (see step_kind)',
                    'grid': [W, H], 'alive_agents': K, 'agent_slots': K, 'steps_per_rank': args.steps,
                    'parallelism': mode, 'prewarm_steps': n_pre, 'timed_world_steps': [n_pre + args.warmup + 1, n_pre + args.warmup + args.steps],
+                   'step_ms_from': 'HIP events inside the timed region' if args.step_events_in_timed_region else 'a second pass of K steps with an event after every step (outside the timed region)',
                    'last_reward': round(last_reward, 3), 'last_num_agents': last_alive},
         # one HIP event after every timed step (rank 0's stream): device-side step times, host launch gaps included
         'step_ms': {'median': round(med, 4), 'mean': round(sum(per_step) / len(per_step), 4), 'min': round(per_step[0], 4),
