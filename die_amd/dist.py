@@ -816,18 +816,38 @@ class DistEnv:
     def _tick(self, name=None, stagger=False):
         """DIE_DIST_PROFILE=1: synchronising phase timer for _refresh_ghosts (scratch/ghost_phases.py reads self._prof).
         `stagger` (DIE_DIST_PROFILE_STAGGER=1, ranks sharing one GPU): the ranks take the next phases one after the other, so
-        that a phase's time is its own and not its share of a GPU that the other ranks use at the same moment."""
+        that a phase's time is its own and not its share of a GPU that the other ranks use at the same moment.
+        DIE_DIST_PROFILE_EVENTS=1: the phases are bracketed by HIP events instead of host synchronisations — device time of what
+        was enqueued, as in a production run where the host does not wait between phases (a stagger point still synchronises)."""
         if not self._profile:
             return
         import time
+        events = os.environ.get('DIE_DIST_PROFILE_EVENTS', '0') == '1'
+        staggering = stagger and os.environ.get('DIE_DIST_PROFILE_STAGGER', '0') == '1'
+        if events and not staggering:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            pend = self.__dict__.setdefault('_prof_events', [])
+            pend.append((name, ev))
+            return
         torch.cuda.synchronize(self.device)
-        if stagger and os.environ.get('DIE_DIST_PROFILE_STAGGER', '0') == '1':
+        if events:                                             # settle the pending event intervals
+            pend = self.__dict__.get('_prof_events', [])
+            for (_, a), (nm, b) in zip(pend, pend[1:]):
+                if nm is not None:
+                    self._prof[nm + ' [device]'] = self._prof.get(nm + ' [device]', 0.0) + a.elapsed_time(b) * 1e-3
+            self._prof_events = []
+        if staggering:
             dist.barrier(self.comm.group)
             time.sleep(0.004 * self.comm.rank)
         now = time.perf_counter()
-        if name is not None:
+        if name is not None and not events:
             self._prof[name] = self._prof.get(name, 0.0) + now - self._t_last
         self._t_last = now
+        if events:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._prof_events = [(None, ev)]
 
     def _refresh_ghosts(self, action, after_step: bool = False):
         """Re-seat owners, ghosts and the chem / food halos (see _step_ghost)."""
