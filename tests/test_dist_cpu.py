@@ -194,3 +194,42 @@ def test_fill_holes_plans():
         got = sorted(vals[:n_new].tolist())
         want = sorted(torch.arange(n)[~leaving].tolist() + arrivals.tolist())
         assert got == want
+
+
+@pytest.mark.parametrize('grid', [(1, 2), (2, 1), (2, 2), (2, 4), (4, 2), (1, 8), (3, 3), (2, 3), (4, 4)])
+def test_peer_message_layouts_of_all_ranks_fit_together(grid):
+    """peer_message_layout for every rank of a grid at once (no processes: the layout is a pure function) — incl. the 2 x 4 grid
+    `bench.py --gpus 8` launches, which no test can start as 8 processes here.  What rank r packs as its side k must lie, within the
+    ONE message r sends to its neighbour p on that side, exactly where p expects the block of ITS opposite side from r; every
+    message's length agrees on both ends; a rank posts one send and one receive per distinct peer."""
+    Px, Py = grid
+    world = (64 * Px, 64 * Py)
+    h = (8 if Px > 1 else 0, 8 if Py > 1 else 0)
+    geos = [TileGeometry(world, grid, q, h) for q in range(Px * Py)]
+    lay = []
+    for g in geos:
+        nd = len(g.DIRS)
+        sizes = [16 + 8 * k for k in range(nd)]
+        sizes = [sizes[min(k, nd - 1 - k)] + 64 * (abs(g.DIRS[k][0]) + 2 * abs(g.DIRS[k][1])) for k in range(nd)]   # side k and its opposite: same size
+        lay.append((sizes,) + peer_message_layout(g.DIRS, g.neighbour, sizes))
+    for r, g in enumerate(geos):
+        sizes, peers, soff, roff, sspan, rspan = lay[r]
+        nd = len(g.DIRS)
+        assert len(peers) == len(set(g.neighbour(dx, dy) for dx, dy in g.DIRS))
+        for k, (dx, dy) in enumerate(g.DIRS):
+            p_ = g.neighbour(dx, dy)
+            psizes, ppeers, psoff, proff, psspan, prspan = lay[p_]
+            ko = nd - 1 - k                                            # the peer's side that faces me: DIRS negated = reversed
+            assert geos[p_].DIRS[ko] == (-dx, -dy) and geos[p_].neighbour(-dx, -dy) == r
+            assert psizes[ko] == sizes[k]
+            # position inside the message r -> p_ == position inside what p_ receives from r
+            assert soff[k] - sspan[p_][0] == proff[ko] - prspan[r][0], (grid, r, k)
+            assert sspan[p_][1] - sspan[p_][0] == prspan[r][1] - prspan[r][0]
+        # blocks of one message do not overlap and fill it
+        for p_ in peers:
+            mine = sorted((soff[k], sizes[k]) for k in range(nd) if g.neighbour(*g.DIRS[k]) == p_)
+            at = sspan[p_][0]
+            for o, n in mine:
+                assert o == at
+                at += n
+            assert at == sspan[p_][1]
