@@ -138,13 +138,18 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
         xs, ys = [(4, 5), (5, 6), (6, 6), (5, 7)][rs.randint(4)]
         TX, TY = 1 << xs, 1 << ys
         W, H = TX * int(rs.randint(3, 6)), TY * int(rs.randint(3, 5))
+        if rs.rand() < 0.4:                          # 8 .. 17 tiles per row: the workgroup → tile mapping by XCD bands (+ its remainder columns) is on the path
+            W, H = TX * 3, TY * int(rs.randint(8, 18))
         N = int(rs.choice([50, 2000, 20000, W * H // 2]))
-        medium, agents = random_state(W, H, N, N, rs, collide=float(rs.choice([0.0, 0.3, 0.9])))
+        reach_pick = int(rs.randint(3))
+        # dead slots behind the segments (the reference's default slot layout) / a GradientAgent's momentum: short steps only
+        dead = float(rs.choice([0.3, 0.6, 0.85])) if (rs.rand() < 0.3 and reach_pick < 2 and N >= 2000) else 0.0
+        medium, agents = random_state(W, H, N, N - int(dead * N), rs, collide=float(rs.choice([0.0, 0.3, 0.9])))
         f16 = bool(rs.rand() < 0.3)
         dyn = dict(boundary=die_amd.BoundaryCondition(rs.choice(['wrap', 'limit'])), food_infinite=bool(rs.rand() < 0.2),
                    diffuse_sigma=float(rs.choice([0.4, 0.5, 0.8, 1.0])), rate_feed=float(rs.choice([0.1, 0.35])),
                    rate_decay_chem=float(rs.choice([0.01, 0.2])))
-        reach = float(rs.choice([0.7, 1.53, min(TX, TY) - 1.001]))                    # cells per step
+        reach = [0.7, 1.53, min(TX, TY) - 1.001][reach_pick]                          # cells per step
         probe = float(rs.choice([1.2, 10.2, 21.5]))
         kw = dict(scale=reach / (max(W, H) - 1), sense_offset=probe / (max(W, H) - 1), sense_angle=float(rs.choice([60, 90, 120])),
                   deposit=float(rs.choice([1.0, 4.0])))
@@ -153,14 +158,18 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
         switch_at = int(rs.randint(2, 7)) if rs.rand() < 0.4 else None
         poke = rs.choice([0, 0, 0, 1, 2, 3, 4], size=8)
         se = int(rs.choice([0, 2, 3]))
-        gradient = bool(rs.rand() < 0.25)            # GradientAgent without momentum: the binned step stores its action
+        gradient = bool(rs.rand() < 0.3)             # GradientAgent: the binned step stores its action
+        inertia, noise = 0.0, 0.0
+        if gradient and not dead and reach_pick < 2 and rs.rand() < 0.6:              # … with momentum: _prev_grad travels through the layouts
+            inertia, noise = float(rs.choice([0.0, 0.5, 0.9])), float(rs.choice([0.0, 0.025]))
+        prev0 = f32(np.clip(rs.randn(2, N) * 0.4, -2.6, 2.6))
         two_agents = bool(rs.rand() < 0.2)           # two agent objects take turns on one env (each with its own headings)
-        fused = bool(rs.rand() < 0.8)                # two-launch form (one field kernel per tile) / three launches
+        fused = bool(rs.rand() < 0.8) or dead > 0    # two-launch form (one field kernel per tile) / three launches (dead slots: two-launch form only)
         only = os.environ.get('FUZZ_ONLY')
         if only is not None and int(only) != case:
             continue
         if only is not None:
-            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se} gradient={gradient} two={two_agents} fused={fused}', flush=True)
+            print(f'case {case}: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} read={read_mode} switch={switch_at} poke={poke.tolist()} sort_every={se} gradient={gradient} two={two_agents} fused={fused} dead={dead} inertia={inertia} noise={noise}', flush=True)
         outs = []
         for pic in (True, False):
             env = die_amd.Env.from_numpy(medium, agents, die_amd.Dynamics(**dyn), sort_every=se if pic else 3, pic=pic,
@@ -170,9 +179,10 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
             def make(sd):
                 if gradient:
                     g = die_amd.GradientAgent(max_agents=N, seed=sd, scale=kw['scale'], sense_offset=kw['sense_offset'], deposit=kw['deposit'],
-                                              inertia=0.0, noise_scale=0.0, normalized_grad=True)
-                else:
-                    g = die_amd.PhysarumAgent(max_agents=N, seed=sd, **kw)
+                                              inertia=inertia, noise_scale=noise, normalized_grad=True)
+                    g.set_state(dir0, prev_grad=prev0.copy() if inertia else None)
+                    return g
+                g = die_amd.PhysarumAgent(max_agents=N, seed=sd, **kw)
                 g.set_state(dir0)
                 return g
             ags = [make(7), make(8)] if two_agents else [make(7)]
@@ -215,7 +225,7 @@ def fuzz_binned(n_cases=60, seed=0, verbose=True):
                     name = 'actions ' + str([bool(np.array_equal(a[k], b[k])) for k in range(a.shape[0])])
                 if name == 'medium' and a.shape == b.shape:
                     name = 'medium ' + str([bool(np.array_equal(a[c], b[c])) for c in range(3)]) + f' max chem diff {np.abs(a[2] - b[2]).max():.3g} food diff {np.abs(a[1] - b[1]).max():.3g}'
-                print(f'CASE {case} {name} differs: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} gradient={gradient} two={two_agents} dyn={dyn} kw={kw} read={read_mode} switch={switch_at}', flush=True)
+                print(f'CASE {case} {name} differs: W={W} H={H} N={N} tile=({xs},{ys}) f16={f16} gradient={gradient} two={two_agents} dead={dead} inertia={inertia} noise={noise} dyn={dyn} kw={kw} read={read_mode} switch={switch_at}', flush=True)
                 break
         if verbose and case % 10 == 9:
             print(f'  binned: {case + 1} cases, {fails} failures', flush=True)
