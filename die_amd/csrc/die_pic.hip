@@ -2486,8 +2486,8 @@ extern "C" int die_pic_action_physarum(const die_pic* p, int32_t lay, const die_
     DIE_REQUIRE(g->kind == DIE_AGENT_PHYSARUM && g->normalized_grad && g->inertia == 0.f && g->noise_scale == 0.f,
                 "die_pic_action_physarum: a normalised PhysarumAgent without inertia or noise");
     const die_pic_layout& L = p->layout[lay];
-    DIE_REQUIRE(p->N > 0 && act->N == p->N && L.heading_hi && L.heading_lo && p->dep && act->dx && act->dy && act->deposit,
-                "die_pic_action_physarum: bad arrays");
+    DIE_REQUIRE(p->N > 0 && act->N == p->N, "die_pic_action_physarum: the action holds %lld entries, the layout %lld", (long long)act->N, (long long)p->N);
+    DIE_REQUIRE(L.heading_hi && L.heading_lo && p->dep && act->dx && act->dy && act->deposit, "die_pic_action_physarum: null array");
     int64_t grid = (p->N + DIE_BLOCK - 1) / DIE_BLOCK;
     k_pic_action_physarum<<<(int)(grid < 8192 ? grid : 8192), DIE_BLOCK, 0, (hipStream_t)stream>>>(
         p->N, L.heading_hi, L.heading_lo, p->dep, g->scale, act->dx, act->dy, act->deposit);

@@ -215,10 +215,15 @@ class PicState:
 
     def _rebuilder(self, env, agent, out):
         """die_pic_action_physarum on what the step left in `out` (the layout it wrote) — see include/die_hip.h."""
-        lay, N, dep, dev = self.cur, self._n_agents, self.dep, env.device
+        lay, dep, dev = self.cur, self.dep, env.device
         slot, hh, hl = out[3], out[4], out[5]
+        agents = env.agents
 
         def rebuild(act):
+            # the number of entries of the layout the step wrote: the agents' count when the action is read — a decomposed rank's
+            # step that ran inside a ghost refresh (die_amd/dist.py) changed it, and the action was built for the count before
+            # (found by scratch/fuzz_dist.py with a refresh at every step: "bad arrays")
+            N = act.N = int(agents.N)
             L = [_lib.PicLayout(), _lib.PicLayout()]
             L[lay] = _lib.PicLayout(None, None, None, _ptr(slot), _ptr(hh), _ptr(hl), None, None, None, None)
             p = _lib.Pic(self.xs, self.ys, N, (_lib.PicLayout * 2)(*L), _ptr(dep), None, None, None, 0, 0, None, None, None, None, None, 0, 0, 0, None, 0, 0, 0, 0, 0, 0, 0, None)

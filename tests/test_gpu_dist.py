@@ -39,7 +39,7 @@ def _wave_dynamics(die_amd, W, H, kind=True):
 
 
 def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
-            wave=False, f16=False):
+            wave=False, f16=False, read_actions=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -74,8 +74,12 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         obs = env._get_current_obs
         rewards = []
         for _ in range(steps):
-            obs, res = env.step(agent.forward(obs))
+            act = agent.forward(obs)
+            obs, res = env.step(act)
             rewards.append(env.read_result(res))
+            if read_actions:                 # the binned step kept it in registers: re-derived from what the step left behind
+                a = act.to_numpy()
+                assert a.shape[0] == 3 and np.isfinite(a).all()
         if ghosts and env._all_alive:       # every local entry is alive, also those a refresh appended beyond the old count
             assert bool(env.agents.alive[:env.agents.N].all())
         world = env.gather_world()
@@ -204,6 +208,29 @@ def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_ever
         assert np.array_equal(got['medium'][c], m[c])
     assert np.array_equal(got['rewards'][:, 1], r[:, 1])
     assert np.array_equal(got['rewards'][:, 0], r[:, 0])
+
+
+@pytest.mark.parametrize('grid,refresh_every', [((1, 2), 1), ((2, 2), 1), ((2, 1), 2)])
+def test_action_read_after_a_step_that_ran_inside_a_ghost_refresh(tmp_path, grid, refresh_every):
+    """A step that runs inside a deferred ghost refresh works on the NEW layout (another number of local agents than the one its
+    action was built for): reading that action afterwards re-derives it for the new count (PicState._rebuilder).  Found by
+    scratch/fuzz_dist.py with a refresh at every step ("the action holds n entries, the layout m"); the other dist tests never
+    read an action."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    W, H, N, steps = 384, 256, 12000, 7
+    out = str(tmp_path / 'dist.npz')
+    size = grid[0] * grid[1]
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, True, refresh_every, out, 'gloo', True, False, False, True),
+             nprocs=size, join=True)
+    got = np.load(out)
+    assert int(got['pic_steps']) == steps and int(got['overlapped']) == (steps - 1) // refresh_every
+    m, a, r = _single_device_run(W, H, N, N, steps, False, False)
+    assert np.array_equal(got['agents'], a)
+    for c in range(3):
+        assert np.array_equal(got['medium'][c], m[c])
+    assert np.array_equal(got['rewards'], r)
 
 
 @pytest.mark.parametrize('ghosts,migrate_every', [(True, 3), (False, 1), (False, 4)])
