@@ -845,6 +845,8 @@ class DistEnv:
             self._prof[name] = self._prof.get(name, 0.0) + now - self._t_last
         self._t_last = now
         if events:
+            if staggering:
+                torch.cuda._sleep(400000)        # ≈ 0.2 ms of spinning first: what follows is queued behind it, so the intervals hold no host latency
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
             self._prof_events = [(None, ev)]
