@@ -35,6 +35,24 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_rects(RectArgs a) {
     }
 }
 
+// The same copy in 16-byte vectors, one vector per thread (the streaming shape: die_stream_copy below), 32-bit index arithmetic:
+// when every block's columns, pitch, first column and buffer offset are whole vectors (the halo bands of a decomposed rank are:
+// halos are whole tiles wide).  The element-wise kernel above, with its 64-bit division and its grid-stride loop, moved the 35 MB of
+// a rank's eight field bands in 27–33 µs; this one in ≈ 10.
+template <int MODE>
+__global__ __launch_bounds__(DIE_BLOCK) void k_rects_vec(RectArgs a, int vshift) {       // a.first / cols / c0 / pitch in VECTORS, boff in bytes
+    const uint32_t total = (uint32_t)a.first[a.n];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int k = 0;
+    while (i >= (uint32_t)a.first[k + 1]) ++k;
+    const uint32_t e = i - (uint32_t)a.first[k], cols = (uint32_t)a.cols[k];
+    const uint32_t r = e / cols, c = e - r * cols;
+    uint4* p = (uint4*)a.plane[k] + ((size_t)(a.r0[k] + r) * a.pitch[k] + a.c0[k] + c);
+    uint4* b = (uint4*)(a.buf + a.boff[k]) + e;
+    if (MODE == 0) *b = *p; else *p = *b;
+}
+
 static int rects(const die_rect* r, int32_t n, void* buf, int mode, void* stream, const char* who) {
     DIE_REQUIRE(r && buf && n >= 1 && n <= DIE_PACK_MAX, "%s: 1..%d blocks", who, DIE_PACK_MAX);
     RectArgs a;
@@ -49,10 +67,31 @@ static int rects(const die_rect* r, int32_t n, void* buf, int mode, void* stream
         a.first[k + 1] = a.first[k] + (int64_t)(r[k].r1 - r[k].r0) * a.cols[k];
     }
     for (int k = n; k < DIE_PACK_MAX; ++k) { a.plane[k] = nullptr; a.pitch[k] = a.r0[k] = a.c0[k] = a.cols[k] = a.esz[k] = 0; a.boff[k] = 0; a.first[k + 1] = a.first[n]; }
-    int64_t g = (a.first[n] + DIE_BLOCK - 1) / DIE_BLOCK;
-    const int grid = (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
     if (mode == 2)
         for (int k = 0; k < n; ++k) DIE_REQUIRE(a.esz[k] == 8, "%s: max-merge is for 8-byte claim words", who);
+    if (mode != 2) {                                           // the vector form where every block is made of whole 16-byte vectors
+        bool vec = ((uintptr_t)buf % 16) == 0 && a.first[n] / 2 < (1ll << 31);
+        for (int k = 0; vec && k < n; ++k) {
+            const int V = 16 / a.esz[k];
+            vec = a.esz[k] == a.esz[0] && a.cols[k] % V == 0 && a.c0[k] % V == 0 && a.pitch[k] % V == 0 && a.boff[k] % 16 == 0 &&
+                  ((uintptr_t)a.plane[k] % 16) == 0;
+        }
+        if (vec) {
+            RectArgs v = a;
+            const int V = 16 / a.esz[0];
+            for (int k = 0; k < n; ++k) { v.cols[k] = a.cols[k] / V; v.c0[k] = a.c0[k] / V; v.pitch[k] = a.pitch[k] / V; v.first[k + 1] = v.first[k] + (a.first[k + 1] - a.first[k]) / V; }
+            for (int k = n; k < DIE_PACK_MAX; ++k) v.first[k + 1] = v.first[n];
+            const int64_t gv = (v.first[n] + DIE_BLOCK - 1) / DIE_BLOCK;
+            if (gv > 0 && gv < (1ll << 31)) {
+                if (mode == 0) k_rects_vec<0><<<(int)gv, DIE_BLOCK, 0, (hipStream_t)stream>>>(v, 0);
+                else k_rects_vec<1><<<(int)gv, DIE_BLOCK, 0, (hipStream_t)stream>>>(v, 0);
+                DIE_CHECK_LAUNCH(who);
+                return DIE_OK;
+            }
+        }
+    }
+    int64_t g = (a.first[n] + DIE_BLOCK - 1) / DIE_BLOCK;
+    const int grid = (int)(g < 2048 ? (g > 0 ? g : 1) : 2048);
     if (mode == 0) k_rects<0><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
     else if (mode == 1) k_rects<1><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);
     else k_rects<2><<<grid, DIE_BLOCK, 0, (hipStream_t)stream>>>(a);

@@ -94,30 +94,55 @@ template <class PUT> __device__ __forceinline__ uint32_t rf_gather(const RfArgs&
     }
     __syncthreads();
     const uint32_t o = s_base[4], own = s_cnt, ncand = s_pre[9];
-    for (uint32_t i = threadIdx.x; i < own; i += RF_BLOCK) {
-        const uint32_t j = o + i;
-        put(i, L.x[j], L.y[j], __float_as_uint(L.agent_food[j]), L.slot[j], L.heading_hi[j], L.heading_lo[j]);
+    // RF_U items per thread and round with ALL their loads in flight before the first store (the kernels here are bound by the
+    // chain of dependent round trips of a workgroup, not by bytes: one item per thread and trip made the pack of 560 band tiles
+    // 94 µs); a tile of ≈ 600 stayers and ≈ 650 candidates is one round each
+    constexpr int RF_U = 3;
+    for (uint32_t b = 0; b < own; b += RF_U * RF_BLOCK) {
+        uint32_t X[RF_U], Y[RF_U], AF[RF_U], SL[RF_U], HH[RF_U], HL[RF_U];
+#pragma unroll
+        for (int u = 0; u < RF_U; ++u) {
+            const uint32_t i = b + (uint32_t)u * RF_BLOCK + threadIdx.x;
+            if (i < own) {
+                const uint32_t j = o + i;
+                X[u] = L.x[j]; Y[u] = L.y[j]; AF[u] = __float_as_uint(L.agent_food[j]); SL[u] = L.slot[j]; HH[u] = L.heading_hi[j]; HL[u] = L.heading_lo[j];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RF_U; ++u) {
+            const uint32_t i = b + (uint32_t)u * RF_BLOCK + threadIdx.x;
+            if (i < own) put(i, X[u], Y[u], AF[u], SL[u], HH[u], HL[u]);
+        }
     }
     __syncthreads();                                            // (s_cnt is read above, added to below)
     const int lane = threadIdx.x & (DIE_WAVE - 1);
     const unsigned long long below = (1ull << lane) - 1ull;
-    for (uint32_t c0 = threadIdx.x - lane; c0 < ncand; c0 += RF_BLOCK) {                 // wave-uniform trip count
-        const uint32_t c = c0 + lane;
-        uint32_t X = 0, Y = 0, af = 0, sl = 0, hh = 0, hl = 0;
-        bool hit = false;
-        if (c < ncand) {
-            int k = 0;
-            while (k < 8 && c >= s_pre[k + 1]) ++k;
-            const uint32_t j = s_base[k] + (c - s_pre[k]);
-            X = L.x[j]; Y = L.y[j]; af = __float_as_uint(L.agent_food[j]); sl = L.slot[j]; hh = L.heading_hi[j]; hl = L.heading_lo[j];
-            hit = rf_tile_of(a, X, Y) == t;
+    for (uint32_t b = 0; b < ncand; b += RF_U * RF_BLOCK) {                              // wave-uniform trip counts throughout
+        uint32_t X[RF_U], Y[RF_U], AF[RF_U], SL[RF_U], HH[RF_U], HL[RF_U];
+        bool hit[RF_U];
+#pragma unroll
+        for (int u = 0; u < RF_U; ++u) {
+            const uint32_t c = b + (uint32_t)u * RF_BLOCK + threadIdx.x;
+            hit[u] = false;
+            X[u] = Y[u] = AF[u] = SL[u] = HH[u] = HL[u] = 0;
+            if (c < ncand) {
+                int k = 0;
+                while (k < 8 && c >= s_pre[k + 1]) ++k;
+                const uint32_t j = s_base[k] + (c - s_pre[k]);
+                X[u] = L.x[j]; Y[u] = L.y[j]; AF[u] = __float_as_uint(L.agent_food[j]); SL[u] = L.slot[j]; HH[u] = L.heading_hi[j]; HL[u] = L.heading_lo[j];
+            }
         }
-        const unsigned long long m = __ballot(hit);
-        if (!m) continue;
-        uint32_t at = 0;
-        if (lane == 0) at = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-        at = __shfl(at, 0, DIE_WAVE);
-        if (hit) put(at + (uint32_t)__popcll(m & below), X, Y, af, sl, hh, hl);
+#pragma unroll
+        for (int u = 0; u < RF_U; ++u) {
+            const uint32_t c = b + (uint32_t)u * RF_BLOCK + threadIdx.x;
+            hit[u] = c < ncand && rf_tile_of(a, X[u], Y[u]) == t;
+            const unsigned long long m = __ballot(hit[u]);
+            if (!m) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            at = __shfl(at, 0, DIE_WAVE);
+            if (hit[u]) put(at + (uint32_t)__popcll(m & below), X[u], Y[u], AF[u], SL[u], HH[u], HL[u]);
+        }
     }
     __syncthreads();
     return s_cnt;
@@ -242,11 +267,24 @@ __global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_merge(RfArgs a) {
     const uint32_t* counts = S.recv_counts;
     const uint32_t before = rf_block_sum(i, [&](int q) { return counts[q]; }), cap = S.cap;
     const uint32_t* rec = S.recv_rec;
-    for (uint32_t q = threadIdx.x; q < c; q += RF_BLOCK) {
-        const uint32_t from = before + q, at = base + q;
-        if (from >= cap || at >= capacity) { rf_flag(a, from >= cap ? RF_FLAG_RECV : RF_FLAG_CAPACITY); continue; }
-        D.x[at] = rec[from]; D.y[at] = rec[cap + from]; D.agent_food[at] = __uint_as_float(rec[2 * cap + from]);
-        D.slot[at] = rec[3 * cap + from]; D.heading_hi[at] = rec[4 * cap + from]; D.heading_lo[at] = rec[5 * cap + from];
+    constexpr int U = 3;                                        // (all loads of a round before its first store: see rf_gather)
+    for (uint32_t b = 0; b < c; b += U * RF_BLOCK) {
+        uint32_t v[U][6];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = b + (uint32_t)u * RF_BLOCK + threadIdx.x, from = before + q, at = base + q;
+            ok[u] = q < c;
+            if (ok[u] && (from >= cap || at >= capacity)) { rf_flag(a, from >= cap ? RF_FLAG_RECV : RF_FLAG_CAPACITY); ok[u] = false; }
+            if (ok[u]) for (int w = 0; w < 6; ++w) v[u][w] = rec[(uint32_t)w * cap + from];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t at = base + b + (uint32_t)u * RF_BLOCK + threadIdx.x;
+            if (!ok[u]) continue;
+            D.x[at] = v[u][0]; D.y[at] = v[u][1]; D.agent_food[at] = __uint_as_float(v[u][2]);
+            D.slot[at] = v[u][3]; D.heading_hi[at] = v[u][4]; D.heading_lo[at] = v[u][5];
+        }
     }
 }
 
