@@ -142,7 +142,8 @@ struct PicLayout {
     uint32_t* slot;
     uint32_t *hhi, *hlo;            // heading, float64 halves
     uint32_t *off, *n, *s, *inc;    // per tile
-};
+    float* fpre;                    // food stream (two-launch form, single-tile worlds): the food under the agent BEFORE the consumption
+};                                  // of the step that wrote this layout — see "Food stream" below
 
 struct PicArgs {
     die_geo g;
@@ -156,6 +157,8 @@ struct PicArgs {
     const void* food;
     float rate_feed, w_dep, w_dist;
     int boundary, cost;
+    int fs_fresh, food_infinite;    // food stream: in.fpre holds the food under the agent as it is NOW and agent_food is complete (after
+                                    // die_pic_bin / die_pic_settle); Dynamics.food_infinite
     long long* part_gain;           // one fixed-point partial per tile
     uint32_t* error;                // device word, sticky: bit 0 segment bookkeeping broken, bit 1 an agent jumped further than a
                                     // tile, bit 2 a rim record left the 3×3 neighbourhood
@@ -169,7 +172,6 @@ struct PicArgs {
     uint8_t* rim_code;
     uint32_t* rim_cnt;              // [tile]: entries the tile had (may exceed rim_cap: the reader then scans the segment)
     int rim_cap, rim_r;             // gaussian radius R = width of the rim
-    uint32_t* queue;                // PERSIST: [0] next tile to hand out, [1] workgroups that have finished (both 0 between launches)
     // a launch over a SUBSET of the tiles (die_pic.sub_*: a decomposed rank steps the tiles that need nothing from its neighbours
     // while the ghost refresh's messages are in flight, the others afterwards): 0 all tiles; 1 the rectangle only (the grid is the
     // rectangle); 2 all but the rectangle (full grid, the rectangle's workgroups return at once)
@@ -221,16 +223,7 @@ __device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty)
     return true;
 }
 
-// LDS-DMA (global_load_lds: a load that writes LDS directly — no staging registers, no ds_write pass; destination = wave-uniform
-// base + lane·size, source per lane) and the waits / barrier that go with it
-#define PA_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define PA_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-typedef const void __attribute__((address_space(1)))* pa_gptr;
-typedef void __attribute__((address_space(3)))* pa_lptr;
-__device__ __forceinline__ void pa_dma16(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 16, 0, 0); }
-__device__ __forceinline__ void pa_dma4(const void* src, void* lds_wave_base) { __builtin_amdgcn_global_load_lds((pa_gptr)src, (pa_lptr)lds_wave_base, 4, 0, 0); }
-__device__ __forceinline__ uint32_t pa_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-
 // (PA_BARRIER instead of __syncthreads() where only LDS is handed over: __syncthreads() is a workgroup-scope fence too and makes
 // every wave wait for its outstanding global stores and atomics — in the agent kernel that drained each tile's stores at every barrier)
 // plane row / column of the cell an agent stands on.  TILED: the planes are a tile of a decomposed world (die_medium.gW > 0) —
@@ -395,9 +388,6 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #ifndef PIC_K1_MINW
 #define PIC_K1_MINW 6
 #endif
-#ifndef PIC_QUEUE
-#define PIC_QUEUE 1             // two-launch form: the agent kernel as a fixed grid that draws tiles from a queue and prefetches the next tile's agents
-#endif
 #ifndef PIC_STATIC_CHUNKS
 #define PIC_STATIC_CHUNKS 0     // 1: wave w takes chunks w, w + waves, … instead of drawing them from an LDS counter
 #endif
@@ -417,11 +407,21 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #define PIC_TB true             // the agent kernel reads a PhysarumAgent's random turn bit from the step's table (false: one Philox block per agent whose turn is random)
 #endif
 #define PIC_AT(base, type, idx) (*(type*)((char*)(base) + (size_t)(uint32_t)((uint32_t)(idx) << 2)))
-// PERSIST: a fixed grid of workgroups (three per CU) that draw tiles from a queue (p.queue, one atomic per tile, claimed two
-// tiles ahead) and prefetch the NEXT tile's per-tile words, first stayers and candidate arrivals into registers while they work
-// on the current one — two of the four memory round trips of a tile's chain leave its critical path; LDS per workgroup is
-// unchanged (the windows are NOT double-buffered: that costs a resident workgroup, k_pic_agents below).
-template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool PERSIST = false, bool MOM = false>
+// Food stream (FS = two-launch form on a single-tile world).  The forward needs the food under the agent (deposit =
+// deposit·food·mask, gradient.py:114-117), feeding the food under its NEW cell before this step's consumption (core/env.py:224-225).
+// Reading both from the plane made this kernel stage the whole food tile — 67 MB per step at 4096² for two 4-byte values per agent,
+// and 18 KB of LDS per workgroup.  Instead the value travels with the agent: layout.fpre[j] = the food under agent j BEFORE the
+// consumption of the step that wrote the layout — written by the field kernel for the agents that stay on its tile (it holds the
+// tile's food anyway), by this kernel for the ≈ 13 % that walk onto another tile (one gather from the plane, which the field kernel
+// of this step has not touched yet).  The next step's agent kernel completes the feeding — agent_food ← (agent_food − cost) + rate·fpre
+// (die_feed: the association every implementation uses) — and takes fpre − rate·fpre, the cell's food after that consumption, as the
+// food under the agent: no food plane here.  The reward's two halves meet in the field kernel (Σ fix(consumed) of its stayers added
+// to this kernel's per-tile partial: integers).  Between steps agent_food lacks the last consumption; die_pic_settle adds it when
+// somebody reads the array (fs_fresh then tells the next step that fpre already holds the food under the agent as it is NOW).
+// (Two persistent forms of this kernel — a tile queue with the next tile's agents prefetched, and one 16-wave workgroup per CU with
+// LDS-DMA loader waves — were built, bit-equal, and measured slower in round 4 (96 / 101 µs against 75–81): DESIGN.md §3.1,
+// scratch/refuted_r04/.)
+template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool MOM = false>
 __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
@@ -445,10 +445,10 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
 #else
 #define PIC_KP(field, type) (p.field)
 #endif
-    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile ± its margin
+    constexpr bool FS = RIM && !TILED;                             // food stream: no food plane in this kernel (above)
+    constexpr bool SFOOD = STAGE && !FS;                           // the food block is staged
+    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then (SFOOD) food of the tile ± its margin
     __shared__ uint32_t s_base[9], s_pre[10];                     // ranges of the current tile
-    __shared__ uint32_t s_nbase[9], s_nlen[9];                     // PERSIST: first index and length of the NEXT tile's ranges
-    __shared__ int s_claim[2];                                     // PERSIST: tiles drawn from the queue
     __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
     __shared__ uint32_t s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
@@ -464,44 +464,21 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     constexpr int SV = 16 / (int)sizeof(T);
     const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P;
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
-    // the tile(s) of this workgroup.  PERSIST: two claimed up front (one atomic), then one more per tile, two tiles ahead
-    int btx = (int)blockIdx.y, bty = (int)blockIdx.x;
-    if (!PERSIST && p.sub_mode == 0) pic_xcd_tile(btx, bty, p.ntx);
-    if (!PERSIST && !pic_sub_tile(p, btx, bty)) return;
-    int tile = btx * p.nty + bty, tile1 = NT;
-    // the per-tile counters (PERSIST: reset again behind every tile's epilogue — the two barriers of the next tile's ranges lie
-    // between a reset and the first wave that counts)
+    // the tile of this workgroup
+    int tx = (int)blockIdx.y, ty = (int)blockIdx.x;
+    if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx);
+    if (!pic_sub_tile(p, tx, ty)) return;
+    const int tile = tx * p.nty + ty;
+    (void)NT;
+    // the per-tile counters
     if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
     if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
-    if (PERSIST) {
-        if (threadIdx.x == 0) { const int t = (int)atomicAdd(&p.queue[0], 2u); s_claim[0] = t; s_claim[1] = t + 1; }
-        PA_BARRIER();
-        tile = s_claim[0]; tile1 = s_claim[1];
-        PA_BARRIER();
-    }
-    // what a tile's first pass needs from memory besides its windows, in registers one tile ahead: the segment words (ranges in
-    // LDS set `cur`), this thread's first candidate arrival and the six streams of this wave's first chunk of stayers
-    [[maybe_unused]] unsigned long long stamp_prev = 0ull;
+    // what the first pass needs from memory besides the windows: this thread's first candidate arrival and the six streams of
+    // this wave's first chunk of stayers
     uint32_t cj = 0, cX = 0, cY = 0, pX = 0, pY = 0, pS = 0, pHh = 0, pHl = 0;
     float pA = 0.f;
+    [[maybe_unused]] float pF = 0.f;
     bool chas = false;
-    // (PERSIST: the words go through s_nbase / s_nlen — also for the first tile — so that the kernel holds ONE set of ranges and
-    // no more static LDS than the plain form: 48 bytes more cost the third resident workgroup per CU)
-    auto ranges_from_next = [&]() {                               // between two barriers: s_nbase / s_nlen → s_base / s_pre
-        if (threadIdx.x < 9) s_base[threadIdx.x] = s_nbase[threadIdx.x];
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int q = 0; q < 9; ++q) { s_pre[q] = run; run += s_nlen[q]; }
-            s_pre[9] = run;
-        }
-    };
-    auto words_to_next = [&](const PicMeta& m) {
-        if (threadIdx.x < 9) {
-            const bool own_ = threadIdx.x == 0;
-            s_nbase[threadIdx.x] = own_ ? m.o : m.o + m.s;
-            s_nlen[threadIdx.x] = m.s > m.n ? 0u : (own_ ? m.s : m.n - m.s);      // (s > n: broken bookkeeping — never loop over garbage)
-        }
-    };
     auto prefetch_agents = [&]() {
         const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
         // this thread's first candidate arrival and the agent streams of this wave's first chunk of stayers
@@ -522,76 +499,25 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             pX = PIC_LDN(p.in.x, const uint32_t, j); pY = PIC_LDN(p.in.y, const uint32_t, j); pS = PIC_LDN(p.in.slot, const uint32_t, j);
             pHh = PIC_LDN(p.in.hhi, const uint32_t, j); pHl = PIC_LDN(p.in.hlo, const uint32_t, j);
             pA = PIC_LDN(p.in.agent_food, const float, j);
+            if (FS) pF = PIC_LDN(p.in.fpre, const float, j);
         }
     };
-    if (PERSIST && tile < NT) {                                    // the first tile's: nothing to hide them behind
-        const int tx_ = tile / p.nty;
-        words_to_next(pic_meta_load(p.in, tx_, tile - tx_ * p.nty, p.ntx, p.nty));
-        PA_BARRIER();
-        ranges_from_next();
-        PA_BARRIER();
-        prefetch_agents();
-    }
-  for (; !PERSIST || tile < NT; ) {
-    const int tx = PERSIST ? tile / p.nty : btx, ty = PERSIST ? tile - tx * p.nty : bty;
     const int x0 = tx << p.xs, y0 = ty << p.ys;
     PIC_STAMP(0);
-#if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
-    if (PERSIST && threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");
-        ((unsigned long long*)(p.error + 2))[(size_t)tile * 16 + 6] = stamp_prev ? t_ - stamp_prev : 0ull; }
-#endif
     PIC_SETPRIO(PIC_PRIO_K1, 0);
     // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
     // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
-    // (PERSIST: the NEXT tile's words — this tile's ranges are in LDS already)
-    PicMeta mt = {0u, 0u, 0u};
-    if (!PERSIST) mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
-    else if (tile1 < NT) { const int tx1 = tile1 / p.nty; mt = pic_meta_load(p.in, tx1, tile1 - tx1 * p.nty, p.ntx, p.nty); }
+    const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
     // the tiles to stage depend on nothing but the tile index: their loads go out next and overlap both round trips
     const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, (int)blockDim.x / (pitch / SV)};
     const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, (int)blockDim.x / (fpitch / SV)};
-    uint4 sc[4], sf[3];                   // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
-    if (STAGE && !PERSIST) {
-        st_c.issue(sc);
-        st_f.issue(sf);
-    }
-    if (STAGE && PERSIST) {
-        // by LDS-DMA: the 28 staging registers are what the prefetched agents of the next tile need (with both in registers
-        // the kernel spilled to scratch), and the commit pass goes.  Instruction q of the block copies vectors q·64 .. q·64 + 63
-        // (row-major image, as PicStageRows leaves it); the waves take the instructions in turn.
-        unsigned char* wb = pic_smem;
-        const T* chem = (const T*)f.chem;
-        const int vpr_c = pitch / SV, vpr_f = fpitch / SV, nvc = rows * vpr_c, nvf = frows * vpr_f;
-        for (int q = wave; q * DIE_WAVE < nvc; q += nwaves) {
-            const int i = q * DIE_WAVE + lane;
-            if (i < nvc) {
-                const int row = (int)(((uint32_t)i * p.mg_c) >> 20), cv = i - row * vpr_c;
-                const int gx = min(max(x0 - P + row, 0), p.g.W - 1), gy = min(max(y0 - P + cv * SV, 0), p.g.H - SV);
-                pa_dma16(chem + (__mul24(gx, p.g.H) + gy), wb + (size_t)q * DIE_WAVE * 16);
-            }
-        }
-        wb += (size_t)rows * pitch * sizeof(T);
-        for (int q = wave; q * DIE_WAVE < nvf; q += nwaves) {
-            const int i = q * DIE_WAVE + lane;
-            if (i < nvf) {
-                const int row = (int)(((uint32_t)i * p.mg_f) >> 20), cv = i - row * vpr_f;
-                int gx = x0 - FR + row, gy = y0 - FC + cv * SV;
-                gx += gx < 0 ? p.g.W : 0; gx -= gx >= p.g.W ? p.g.W : 0;
-                gy += gy < 0 ? p.g.H : 0; gy -= gy >= p.g.H ? p.g.H : 0;
-                pa_dma16(food + (__mul24(gx, p.g.H) + gy), wb + (size_t)q * DIE_WAVE * 16);
-            }
-        }
-    }
+    uint4 sc[4];                          // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
+    [[maybe_unused]] uint4 sf[3];
+    if (STAGE) st_c.issue(sc);
+    if (SFOOD) st_f.issue(sf);
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
-    // the tile after the next: ONE thread of the LAST wave asks the queue.  The compiler waits for a returning atomic right where
-    // it stands (wave-aggregated add + readfirstlane) — a round trip of 2 000–4 000 cycles; in the last wave it runs beside the
-    // window loads, which every wave waits for anyway (in thread 0 it held up the whole workgroup at the top of every tile).
-    // Needed behind this tile's last barrier.
-    if (PERSIST && threadIdx.x == blockDim.x - 1) s_claim[0] = (int)atomicAdd(&p.queue[0], 1u);
-    if (!PERSIST) {
-        pic_ranges_finish(mt, s_base, s_pre);
-        prefetch_agents();
-    }
+    pic_ranges_finish(mt, s_base, s_pre);
+    prefetch_agents();
     PIC_STAMP(1);
     const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
     PIC_SETPRIO(PIC_PRIO_K1, 1);
@@ -600,9 +526,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     T* s_food = nullptr;
     if (STAGE) {
         T* s_chem = (T*)pic_smem;
-        s_food = s_chem + rows * pitch;
-        if (!PERSIST) {
-            st_c.commit(s_chem, sc);
+        st_c.commit(s_chem, sc);
+        if (SFOOD) {
+            s_food = s_chem + rows * pitch;
             st_f.commit(s_food, sf);
         }
         tm.food = s_food; tm.fx0 = x0 - FR; tm.fy0 = y0 - FC; tm.fpitch = fpitch;
@@ -635,14 +561,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             at = __shfl(at, 0, DIE_WAVE);
             if (hit) s_list[at + (uint32_t)__popcll(m & below)] = j;
         }
-        if (PERSIST && STAGE && cb == 0) PA_WAIT_VM();             // this wave's window DMAs have landed
         PA_BARRIER();                                           // publishes the staged tiles and the list
-        if (PERSIST && cb == 0) {
-            // everything requested at the top of the tile is here now: the next tile's segment words and the tile drawn from the
-            // queue go to LDS at once — a use behind the chunk loop would make the compiler drain this tile's stores first
-            // (it cannot count a wait across the loop: the tail of a tile took 9 000 cycles that way)
-            words_to_next(mt);
-        }
         PIC_STAMP(3);
         PIC_SETPRIO(PIC_PRIO_K1, 2);
         const uint32_t n_own = cb == 0 ? own : 0u, count = n_own + s_nlist;
@@ -665,14 +584,16 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             bool stay = false;
             uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0;
             float af = 0.f, dep = 0.f;
-            [[maybe_unused]] float pux = 0.f, puy = 0.f;
+            [[maybe_unused]] float pux = 0.f, puy = 0.f, fnew = 0.f;
             double hd = 0.0;
             uint32_t code = 0;
             bool listed = false;
             if (act) {
                 const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
+                [[maybe_unused]] float fp = 0.f;
                 if (first && idx < n_own) {                      // (this wave's prefetched chunk: idx = wave·64 + lane < own)
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
+                    if (FS) fp = pF;
                 } else {
                     // (the pointers first — their scalar loads go out together —, then all six streams in flight together)
                     const uint32_t *ix_ = PIC_KP(in.x, const uint32_t*), *iy_ = PIC_KP(in.y, const uint32_t*), *is_ = PIC_KP(in.slot, const uint32_t*);
@@ -681,10 +602,21 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     X = PIC_LDN(ix_, const uint32_t, j); Y = PIC_LDN(iy_, const uint32_t, j); sid = PIC_LDN(is_, const uint32_t, j);
                     hh = PIC_LDN(ihh_, const uint32_t, j); hl = PIC_LDN(ihl_, const uint32_t, j);
                     af = PIC_LDN(ia_, const float, j);
+                    if (FS) fp = PIC_LDN(PIC_KP(in.fpre, const float*), const float, j);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
-                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, PIC_TB, false>(f, tm, X, Y, hd, sid, (int64_t)j)
-                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, PIC_TB, false>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
+                // FS: the previous step's consumption completes agent_food, and what that consumption left on the cell is the food
+                // under the agent (fs_fresh: both done already — a layout fresh from die_pic_bin / die_pic_settle)
+                float f_own = 0.f;
+                if (FS) {
+                    const bool fresh = p.fs_fresh != 0;
+                    const float done = __fadd_rn(af, die_consumed(p.rate_feed, fp));
+                    const float left = p.food_infinite ? fp : die_as_stored<T>(die_food_after(p.rate_feed, fp));
+                    af = fresh ? af : done;
+                    f_own = fresh ? fp : left;
+                }
+                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, PIC_TB, false, FS>(f, tm, X, Y, hd, sid, (int64_t)j, f_own)
+                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, PIC_TB, false, FS>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j, f_own);
                 if (MOM) { pux = o.ux; puy = o.uy; }
                 if (ACT && p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
@@ -702,30 +634,38 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 const int cy = TILED ? die_plane_coord(gcy, p.g.oy, p.g.H, p.g.gH) : gcy;
                 const int ntx_ = cx >> p.xs, nty_ = cy >> p.ys;
                 stay = ntx_ == tx && nty_ == ty;
-                // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption —
-                // from the staged food block, whose margin holds every cell an agent of the tile can reach in one step (a flat
-                // load from "LDS or global memory" here made every wave drain its outstanding stores before each chunk)
-                float fnew;
-                if (STAGE) {
-                    int rx = cx - x0, ry = cy - y0;                                    // relative to the tile, periodic
-                    rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
-                    ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
-                    rx = min(max(rx + FR, 0), frows - 1);                              // (a longer jump is an error, flagged below: never out of the block)
-                    // the block has a margin of ROWS only by default (fm_c = 0): a row of the plane starts on a 256-byte boundary of
-                    // the tile, so whole rows cost no partial cache lines, while ± 4 columns made every row touch two more 128-byte
-                    // lines (70 rows × 4 lines instead of 64 × 2: + 65 MB of fetches per step at 4096²).  The few agents that leave
-                    // the tile's columns (≈ 1 % per step at the benchmark's step length) read their cell from global memory
-                    if (ry >= -FC && ry < TY + FC) fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry + FC));
-                    else fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
-                } else {
-                    fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
-                }
-                const float consumed = p.rate_feed * fnew;
+                // _agent_feed for this (alive) agent (core/env.py:220-243)
                 const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
-                const float gained = consumed - cost;
-                af += gained;
-                // (a ghost is its owner's to count; die_owned on the plane element: a cell beyond the planes maps to an edge element, never owned)
-                if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_fix(gained); ++nowned; }
+                if (FS) {
+                    // the cost now; the consumption when the food under the new cell is known: the field kernel writes fpre for the
+                    // agents that stay on this tile, the others read their cell here — from the plane, which still holds the food
+                    // BEFORE this step's consumption — and count their consumption into this tile's partial
+                    af = __fsub_rn(af, cost);
+                    gsum -= die_fix(cost);
+                    if (!stay) fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
+                } else {
+                    // the food under it BEFORE this step's consumption — from the staged food block, whose margin holds every cell
+                    // an agent of the tile can reach in one step (a flat load from "LDS or global memory" here made every wave
+                    // drain its outstanding stores before each chunk)
+                    if (SFOOD) {
+                        int rx = cx - x0, ry = cy - y0;                                    // relative to the tile, periodic
+                        rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
+                        ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
+                        rx = min(max(rx + FR, 0), frows - 1);                              // (a longer jump is an error, flagged below: never out of the block)
+                        // the block has a margin of ROWS only by default (fm_c = 0): a row of the plane starts on a 256-byte boundary of
+                        // the tile, so whole rows cost no partial cache lines, while ± 4 columns made every row touch two more 128-byte
+                        // lines (70 rows × 4 lines instead of 64 × 2: + 65 MB of fetches per step at 4096²).  The few agents that leave
+                        // the tile's columns (≈ 1 % per step at the benchmark's step length) read their cell from global memory
+                        if (ry >= -FC && ry < TY + FC) fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry + FC));
+                        else fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
+                    } else {
+                        fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
+                    }
+                    const float consumed = die_consumed(p.rate_feed, fnew);
+                    af = die_feed(af, cost, consumed);
+                    // (a ghost is its owner's to count; die_owned on the plane element: a cell beyond the planes maps to an edge element, never owned)
+                    if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_feed_fix(cost, consumed); ++nowned; }
+                }
                 hd = o.heading;
                 dep = o.dep;
                 int ddx = 0, ddy = 0;
@@ -781,6 +721,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     PIC_ST(1, ohl_, uint32_t, q, (uint32_t)__double2loint(hd));
                     PIC_ST(0, od_, float, q, dep);
                     if (MOM && p.opgx) { PIC_AT(p.opgx, float, q) = pux; PIC_AT(p.opgy, float, q) = puy; }
+                    // FS: a leaver's food stream entry and its consumption (the gather was issued before the position atomics)
+                    if (FS && !stay) { PIC_AT(PIC_KP(out.fpre, float*), float, q) = fnew; gsum += die_fix(die_consumed(p.rate_feed, fnew)); }
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
@@ -803,9 +745,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     }
     PA_BARRIER();
     PIC_STAMP(5);
-#if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
-    if (PERSIST && threadIdx.x == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev) :: "memory"); }
-#endif
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
         const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
         atomicAdd(&PIC_KP(out.inc, uint32_t*)[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
@@ -830,542 +769,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
         p.out.s[tile] = nfront;
         if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
     }
-    if (!PERSIST) break;
-    // the next tile: its ranges from the words requested at the top of this one (pic_ranges_finish, with the per-tile counters
-    // reset BETWEEN its two barriers: every wave has read this tile's counts before the first, none counts for the next tile before
-    // the second), then its first candidates and stayers — in flight while the next windows load
-    PA_BARRIER();
-    ranges_from_next();
-    if (threadIdx.x == 0) { s_cnt = 0ull; s_next = (uint32_t)(nwaves * DIE_WAVE); s_nlist = 0; }
-    if (threadIdx.x < 9) s_inc[threadIdx.x] = 0;
-    PA_BARRIER();
-    tile = tile1;
-    tile1 = s_claim[0];
-    if (tile < NT) prefetch_agents();
-  }
-    if (PERSIST) {                                                 // the last workgroup out leaves the queue ready for the next launch
-        PA_BARRIER();
-        if (threadIdx.x == 0 && atomicAdd(&p.queue[1], 1u) == gridDim.x - 1u) { p.queue[0] = 0u; p.queue[1] = 0u; }
-    }
-}
-
-// ---- the agent kernel as ONE persistent workgroup per CU (two-launch form, 64×64 tiles, PhysarumAgent) ---------------------------
-// k_pic_forward_move above lives 24 000 cycles per tile of which 10 000 compute: the rest is a chain of four memory round
-// trips (per-tile words → agent streams and candidate arrivals → the arrivals' records → stores) that its three workgroups per
-// CU cannot overlap, and cutting a sixth of its instructions changed nothing (round 4: 81.6 vs 80.7 µs).  Here the chain runs
-// AHEAD of the arithmetic: a workgroup of 16 waves walks over its tiles t_0, t_1, … (tile = blockIdx.x + k·gridDim.x);
-// 4 LOADER waves (one per SIMD) move everything a tile needs into LDS by LDS-DMA (global_load_lds: no staging registers, no
-// ds_write pass) one to three tiles ahead, 12 COMPUTE waves read LDS only and store the results.  In iteration k:
-//     loaders   chem window ± probe reach and food block of t_{k+1}        (16-byte DMA, two buffers)
-//               the six streams of t_{k+1}'s stayers                        (4-byte DMA, two buffers)
-//               (x, y) of the candidate arrivals of t_{k+2}                 (three buffers; needs the per-tile words of t_{k+2})
-//               the per-tile words of t_{k+3}                               (ring of four)
-//               filter of t_{k+1}'s candidates (landed during iteration k − 1) → list → the hits' records (gather DMA)
-//               flush of t_{k−1}'s counters (arrival counts, rim codes, reward partial, stayers)
-//     compute   one chunk of 64 agents of t_k per wave (stayers, then arrivals) — forward, move, feeding, positions, stores —
-//               exactly the arithmetic and the outputs of k_pic_forward_move
-//   ONE workgroup barrier per tile; every loader drains its DMAs (s_waitcnt vmcnt(0)) before it, the compute waves never wait
-//   for memory (their stores are fire-and-forget, they issue no loads).  Tiles that exceed the staged capacities (640 stayers,
-//   512 candidates, 128 arrivals: crowds) finish with passes that load directly — slower, same results.
-#define PA_WAVES 16
-#define PA_LOADERS 4
-#define PA_CW (PA_WAVES - PA_LOADERS)
-#define PA_SCAP 640
-#define PA_CCAP 512
-#define PA_ACAP 128
-#define PA_MWORDS 32            // per-tile words of a tile's neighbourhood: off[9], s[9], n[9] (own tile first, then the ring), out.off, out.n
-
-struct PaTileIn {               // what the loaders leave for the compute waves of a tile
-    uint32_t tile, own, ncand, nh, cstop, obase, on, base0;
-    int32_t tx, ty;
-    uint32_t base[9], pre[10];
-    uint32_t pad;
-};
-struct PaTileAcc {              // what the compute waves leave for the flush
-    unsigned long long cnt;     // stayers | leavers << 21 | rim entries << 42
-    uint32_t inc[9];
-    uint32_t alv[PA_CW];
-    uint32_t pad;
-    long long gain[PA_CW];
-    uint8_t rimc[PIC_RIM_CAP_MAX];
-};
-static_assert(sizeof(PaTileIn) % 8 == 0 && sizeof(PaTileAcc) % 8 == 0, "LDS carve-up of k_pic_agents");
-
-struct PaLds {                  // byte offsets into the dynamic LDS block (host: pa_lds_layout)
-    uint32_t w[2], s[2], c[3], a[2], mr, tin, tacc, ranges, total;
-    uint32_t food_off;          // food block inside a w buffer
-};
-
-#ifdef PIC_STAMPS
-#define PA_STAMP(k, tile_) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
-                                 ((unsigned long long*)(p.error + 2))[(size_t)(tile_) * 16 + (k)] = t_; } } while (0)
-#else
-#define PA_STAMP(k, tile_) do { } while (0)
-#endif
-// per-tile words of `tile`'s neighbourhood → LDS (one DMA instruction, lanes 0..28)
-__device__ __forceinline__ void pa_meta_issue(const PicArgs& p, int tile, uint32_t* mr_slot, int lane) {
-    const int tx = tile / p.nty, ty = tile - tx * p.nty;
-    if (lane < 29) {
-        const uint32_t* src;
-        if (lane < 27) {
-            const int which = lane / 9, q = lane - which * 9;
-            const int k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
-            const int t = pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty);
-            src = (which == 0 ? p.in.off : (which == 1 ? p.in.s : p.in.n)) + t;
-        } else {
-            src = (lane == 27 ? p.out.off : p.out.n) + tile;
-        }
-        pa_dma4(src, mr_slot);
-    }
-}
-// base[r] = first array index of range r, pre[r] = exclusive prefix of the lengths ([0] own stayers, [1..8] the ring's leavers)
-__device__ __forceinline__ void pa_ranges(const uint32_t* mr_slot, uint32_t* base, uint32_t* pre, int lane) {
-    uint32_t len = 0;
-    if (lane < 9) {
-        const uint32_t o = mr_slot[lane], st = mr_slot[9 + lane], n = mr_slot[18 + lane];
-        base[lane] = lane == 0 ? o : o + st;
-        len = st > n ? 0u : (lane == 0 ? st : n - st);              // (s > n: broken bookkeeping — never loop over garbage)
-    }
-    uint32_t run = len;                                             // inclusive scan over lanes 0..8 (wave shuffles)
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { const uint32_t v = __shfl_up(run, o, DIE_WAVE); if (lane >= o) run += v; }
-    if (lane < 9) pre[lane + 1] = run;
-    if (lane == 0) pre[0] = 0;
-}
-
-template <typename T, bool TILED>
-__global__ __launch_bounds__(PA_WAVES * DIE_WAVE, 4) void k_pic_agents(FwdArgs f, PicArgs p, PaLds L) {
-    f.pgx = nullptr; f.pgy = nullptr; f.step_base = nullptr; f.mask = nullptr;
-    f.inertia = 0.f; f.noise_scale = 0.f; f.normalized = 1;
-    f.g = p.g;
-    struct KArgs { FwdArgs f; PicArgs p; };
-    const volatile KArgs __attribute__((address_space(4)))* ka = (const volatile KArgs __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr();
-    extern __shared__ __align__(16) unsigned char pic_smem[];
-    constexpr int XS = 6, YS = 6, TX = 1 << XS, TY = 1 << YS, SV = 16 / (int)sizeof(T);
-    const int lane = threadIdx.x & (DIE_WAVE - 1), wave = (int)pa_uni(threadIdx.x / DIE_WAVE);
-    const int NT = p.ntx * p.nty, G = (int)gridDim.x, bid = (int)blockIdx.x;
-    const int nk = bid < NT ? (NT - bid + G - 1) / G : 0;            // tiles of this workgroup: bid, bid + G, …
-    const int P = p.margin, pitch = TY + 2 * P, rows = TX + 2 * P, vpr_c = pitch / SV;
-    const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR, vpr_f = fpitch / SV;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    uint32_t* mr = (uint32_t*)(pic_smem + L.mr);
-    PaTileIn* tin = (PaTileIn*)(pic_smem + L.tin);
-    PaTileAcc* tacc = (PaTileAcc*)(pic_smem + L.tacc);
-    if (threadIdx.x < 2 * sizeof(PaTileAcc) / 4) ((uint32_t*)tacc)[threadIdx.x] = 0u;
-    if (nk == 0) return;
-
-    // ---------------------------------------------------------------- loaders' work items
-    // A wave issues an instruction every 5–8 cycles, so a loader's budget per tile is a few hundred instructions: everything
-    // below is shaped for few instructions per DMA (first cut: 40 per DMA, 16 000 cycles per tile — stamps, round 4).
-    // The chem window and food block of `tile` → w buffer `b`, waves 1..3.  The image of a block is the same for every tile:
-    // instruction q of a wave copies vectors q·64 .. q·64 + 63, lane l the vector at (row, column vector) = divmod(q·64 + l,
-    // vectors per row).  Each lane keeps that vector's offset from the block's first element for its (up to) PA_NWC + PA_NWF
-    // instructions in registers; for a tile whose blocks lie inside the planes a DMA is then one scalar base + that offset.
-    // Tiles at the planes' edge (6 % at 4096²) recompute every vector's address with the clamp / the periodic wrap.
-    const int nvc = rows * vpr_c, nvf = frows * vpr_f;
-    // one block (chem window: wave 2; food block: wave 3) of `tile` → w buffer `b`
-    auto issue_block = [&](const T* plane, int gx0, int gy0, int nv, int vpr, uint32_t mg, bool wrap, unsigned char* dst) {
-        const bool inside = gx0 >= 0 && gx0 + nv / vpr <= p.g.W && gy0 >= 0 && gy0 + vpr * SV <= p.g.H;
-        if (inside) {
-            const char* base = (const char*)(plane + ((int64_t)gx0 * p.g.H + gy0));
-            const int full = nv / DIE_WAVE;
-            int i = lane;
-            for (int q = 0; q < full; ++q, i += DIE_WAVE, dst += DIE_WAVE * 16) {
-                const int row = (int)(((uint32_t)i * mg) >> 20), cv = i - row * vpr;
-                pa_dma16(base + (size_t)((uint32_t)(row * p.g.H + cv * SV) * (uint32_t)sizeof(T)), dst);
-            }
-            if (i < nv) {
-                const int row = (int)(((uint32_t)i * mg) >> 20), cv = i - row * vpr;
-                pa_dma16(base + (size_t)((uint32_t)(row * p.g.H + cv * SV) * (uint32_t)sizeof(T)), dst);
-            }
-        } else {
-            for (int q = 0; q * DIE_WAVE < nv; ++q) {
-                const int i = q * DIE_WAVE + lane;
-                if (i < nv) {
-                    const int row = (int)(((uint32_t)i * mg) >> 20), cv = i - row * vpr;
-                    int gx = gx0 + row, gy = gy0 + cv * SV;
-                    if (wrap) {
-                        gx += gx < 0 ? p.g.W : 0; gx -= gx >= p.g.W ? p.g.W : 0;
-                        gy += gy < 0 ? p.g.H : 0; gy -= gy >= p.g.H ? p.g.H : 0;
-                    } else {
-                        gx = min(max(gx, 0), p.g.W - 1); gy = min(max(gy, 0), p.g.H - SV);
-                    }
-                    pa_dma16(plane + (__mul24(gx, p.g.H) + gy), dst + (size_t)q * DIE_WAVE * 16);
-                }
-            }
-        }
-    };
-    auto issue_window = [&](int tile, int b) {                     // waves 2 (chem) and 3 (food)
-        const int tx = tile / p.nty, ty = tile - tx * p.nty, x0 = tx << XS, y0 = ty << YS;
-        unsigned char* wb = pic_smem + L.w[b];
-        if (wave == 2) issue_block((const T*)f.chem, x0 - P, y0 - P, nvc, vpr_c, p.mg_c, false, wb);
-        else issue_block((const T*)p.food, x0 - FR, y0 - FC, nvf, vpr_f, p.mg_f, true, wb + L.food_off);
-    };
-    // the six streams of the tile's first PA_SCAP stayers → s buffer `b`: wave 2 takes x, y, slot, wave 3 the heading halves and
-    // agent_food.  16-byte DMAs — four agents per lane, 256 per instruction: an LDS-DMA costs its wave ≈ 110 cycles whatever its
-    // width (stamps, round 4), and its SOURCE needs no more than 4-byte alignment (scratch/kbench_dma/dma_unaligned.hip) — and one
-    // 4-byte DMA for the last own % 4 agents (a vector must not read past the end of the arrays).
-    auto issue_stayers = [&](const uint32_t* mr_slot, int b) {
-        const uint32_t o = pa_uni(mr_slot[0]), st = pa_uni(mr_slot[9]), n = pa_uni(mr_slot[18]);
-        const uint32_t own = st > n ? 0u : min(st, (uint32_t)PA_SCAP), nvec = own >> 2, tail = own & 3u;
-        const char *a0, *a1, *a2;
-        if (wave == 2) { a0 = (const char*)p.in.x; a1 = (const char*)p.in.y; a2 = (const char*)p.in.slot; }
-        else { a0 = (const char*)p.in.hhi; a1 = (const char*)p.in.hlo; a2 = (const char*)p.in.agent_food; }
-        unsigned char* d0 = pic_smem + L.s[b] + (size_t)(3 * (wave - 2)) * PA_SCAP * 4;
-        uint32_t voff = (o + 4u * (uint32_t)lane) << 2;
-        for (uint32_t v0 = 0; v0 < nvec; v0 += DIE_WAVE, voff += DIE_WAVE * 16, d0 += DIE_WAVE * 16) {
-            if (v0 + (uint32_t)lane < nvec) {
-                pa_dma16(a0 + (size_t)voff, d0);
-                pa_dma16(a1 + (size_t)voff, d0 + PA_SCAP * 4);
-                pa_dma16(a2 + (size_t)voff, d0 + 2 * PA_SCAP * 4);
-            }
-        }
-        if (tail && (uint32_t)lane < tail) {
-            const uint32_t toff = (o + 4u * nvec + (uint32_t)lane) << 2;
-            unsigned char* dt = pic_smem + L.s[b] + (size_t)(3 * (wave - 2)) * PA_SCAP * 4 + (size_t)nvec * 16;
-            pa_dma4(a0 + (size_t)toff, dt);
-            pa_dma4(a1 + (size_t)toff, dt + PA_SCAP * 4);
-            pa_dma4(a2 + (size_t)toff, dt + 2 * PA_SCAP * 4);
-        }
-    };
-    // a candidate arrival's array index from its running number c: the leavers of the 8 ring tiles follow one another;
-    // pre[1..9] in scalar registers → 8 compares, no LDS search loop (that loop was 3 000 cycles per tile)
-    struct PaRanges { uint32_t own, ncand; uint32_t pre[10], adj[9]; };      // adj[r] = base[r] − pre[r]
-    auto load_ranges = [&](const uint32_t* mr_slot, PaRanges& R) {
-        uint32_t len = 0, bs = 0;
-        if (lane < 9) {
-            const uint32_t o = mr_slot[lane], st = mr_slot[9 + lane], n = mr_slot[18 + lane];
-            bs = lane == 0 ? o : o + st;
-            len = st > n ? 0u : (lane == 0 ? st : n - st);            // (s > n: broken bookkeeping — never loop over garbage)
-        }
-        uint32_t run = len;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { const uint32_t v = __shfl_up(run, o, DIE_WAVE); if (lane >= o) run += v; }
-        R.pre[0] = 0;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            R.pre[r + 1] = (uint32_t)__builtin_amdgcn_readlane((int)run, r);
-            R.adj[r] = (uint32_t)__builtin_amdgcn_readlane((int)bs, r) - R.pre[r];
-        }
-        R.own = R.pre[1];
-        R.ncand = R.pre[9] - R.own;
-    };
-    auto cand_index = [&](const PaRanges& R, uint32_t c) {               // c < ncand
-        const uint32_t idx = R.own + c;
-        uint32_t adj = R.adj[1];
-#pragma unroll
-        for (int r = 2; r < 9; ++r) adj = idx >= R.pre[r] ? R.adj[r] : adj;
-        return idx + adj;
-    };
-    // (x, y) and the array index of the tile's first PA_CCAP candidate arrivals → c buffer `b` (wave 1)
-    auto issue_candidates = [&](const uint32_t* mr_slot, int b) {
-        PaRanges R;
-        load_ranges(mr_slot, R);
-        const uint32_t ncand = min(R.ncand, (uint32_t)PA_CCAP);
-        unsigned char* cb = pic_smem + L.c[b];
-        for (uint32_t c0 = 0; c0 < ncand; c0 += DIE_WAVE) {
-            const uint32_t c = c0 + lane;
-            if (c < ncand) {
-                const uint32_t j = cand_index(R, c);
-                ((uint32_t*)cb)[2 * PA_CCAP + c] = j;
-                pa_dma4((const char*)p.in.x + (size_t)(uint32_t)(j << 2), cb + (size_t)c0 * 4);
-                pa_dma4((const char*)p.in.y + (size_t)(uint32_t)(j << 2), cb + ((size_t)PA_CCAP + c0) * 4);
-            }
-        }
-    };
-    // wave 0: which of the staged candidates stand on the tile → the hits' array indices (stream 6 of a buffer `ab`) and their
-    // six streams (gather DMA); the tile's words for the compute waves
-    auto filter_tile = [&](int tile, const uint32_t* mr_slot, int cbuf, int ab, PaTileIn* ti) {
-        PaRanges R;
-        load_ranges(mr_slot, R);
-        const uint32_t own = R.own, ncand = R.ncand, nscan = min(ncand, (uint32_t)PA_CCAP);
-        const uint32_t* cx_ = (const uint32_t*)(pic_smem + L.c[cbuf]);
-        uint32_t* al = (uint32_t*)(pic_smem + L.a[ab]);
-        const int tx = tile / p.nty, ty = tile - tx * p.nty;
-        uint32_t nh = 0, cstop = nscan;
-        for (uint32_t c0 = 0; c0 < nscan; c0 += DIE_WAVE) {
-            const uint32_t c = c0 + lane;
-            bool hit = false;
-            uint32_t j = 0;
-            if (c < nscan) {
-                j = cx_[2 * PA_CCAP + c];
-                hit = (pic_row<TILED>(p.g, cx_[c]) >> XS) == tx && (pic_col<TILED>(p.g, cx_[PA_CCAP + c]) >> YS) == ty;
-            }
-            const unsigned long long m = __ballot(hit);
-            const uint32_t cm = (uint32_t)__popcll(m);
-            if (nh + cm > (uint32_t)PA_ACAP) { cstop = c0; break; }           // (wave-uniform) the rest: the compute waves' direct pass
-            if (hit) al[6 * PA_ACAP + nh + (uint32_t)__popcll(m & below)] = j;
-            nh += cm;
-        }
-        // the tile's words for the compute waves (ranges: for their direct passes over crowds)
-#pragma unroll
-        for (int r = 0; r < 9; ++r) if (lane == r) { ti->base[r] = R.adj[r] + R.pre[r]; ti->pre[r] = R.pre[r]; }
-        if (lane == 0) {
-            ti->pre[9] = R.pre[9];
-            ti->tile = (uint32_t)tile; ti->own = own; ti->ncand = ncand; ti->nh = nh; ti->cstop = cstop;
-            ti->obase = mr_slot[27]; ti->on = mr_slot[28]; ti->base0 = mr_slot[0];
-            ti->tx = tx; ti->ty = ty;
-        }
-        for (uint32_t h0 = 0; h0 < nh; h0 += DIE_WAVE) {
-            const uint32_t h = h0 + lane;
-            if (h < nh) {
-                const size_t jo = (size_t)(uint32_t)(al[6 * PA_ACAP + h] << 2);
-                pa_dma4((const char*)p.in.x + jo, al + h0);
-                pa_dma4((const char*)p.in.y + jo, al + PA_ACAP + h0);
-                pa_dma4((const char*)p.in.slot + jo, al + 2 * PA_ACAP + h0);
-                pa_dma4((const char*)p.in.hhi + jo, al + 3 * PA_ACAP + h0);
-                pa_dma4((const char*)p.in.hlo + jo, al + 4 * PA_ACAP + h0);
-                pa_dma4((const char*)p.in.agent_food + jo, al + 5 * PA_ACAP + h0);
-            }
-        }
-    };
-    // wave 0: a finished tile's counters → global memory (what k_pic_forward_move does behind its last barrier); reset
-    auto flush_tile = [&](const PaTileIn* ti, PaTileAcc* ta) {
-        const int tile = (int)pa_uni(ti->tile), tx = (int)pa_uni((uint32_t)ti->tx), ty = (int)pa_uni((uint32_t)ti->ty);
-        const uint32_t on = pa_uni(ti->on);
-        const unsigned long long cnt = ta->cnt;
-        if (lane < 9 && ta->inc[lane]) {
-            const int ddx = lane / 3 - 1, ddy = lane % 3 - 1;
-            atomicAdd(&p.out.inc[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], ta->inc[lane]);
-        }
-        const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(cnt >> 42) & 0x1FFFFFu;
-        for (uint32_t i = lane; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += DIE_WAVE)
-            ((uint32_t*)p.rim_code)[((size_t)tile * p.rim_cap) / 4 + i] = ((const uint32_t*)ta->rimc)[i];
-        if (lane == 0) {
-            p.rim_cnt[tile] = nr;
-            long long t = 0;
-            for (int i = 0; i < PA_CW; ++i) t += ta->gain[i];
-            p.part_gain[tile] = t;
-            if (TILED) {
-                long long c = 0;
-                for (int i = 0; i < PA_CW; ++i) c += ta->alv[i];
-                p.part_gain[(size_t)NT + tile] = c;
-            }
-            const uint32_t nfront = (uint32_t)cnt & 0x1FFFFFu, nback = (uint32_t)(cnt >> 21) & 0x1FFFFFu;
-            p.out.s[tile] = nfront;
-            if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
-            ta->cnt = 0ull;
-        }
-        if (lane < 9) ta->inc[lane] = 0u;
-    };
-
-#ifndef PA_LOADER_PRIO
-#define PA_LOADER_PRIO 3
-#endif
-    // the loaders are the critical path of an iteration (four waves against twelve): they win the issue arbitration
-    if (wave < PA_LOADERS && PA_LOADER_PRIO) __builtin_amdgcn_s_setprio(PA_LOADER_PRIO);
-    // ---------------------------------------------------------------- prologue: fill the pipeline
-    if (wave == 1) {
-        for (int d = 0; d < 3 && d < nk; ++d) pa_meta_issue(p, bid + d * G, mr + (d & 3) * PA_MWORDS, lane);
-        PA_WAIT_VM();
-    }
-    PA_BARRIER();
-    if (wave == 1) {
-        issue_candidates(mr, 0);
-        if (nk > 1) issue_candidates(mr + PA_MWORDS, 1);
-    }
-    if (wave == 2 || wave == 3) {
-        issue_window(bid, 0);
-        issue_stayers(mr, 0);
-    }
-    if (wave < PA_LOADERS) PA_WAIT_VM();
-    PA_BARRIER();
-    if (wave == 0) {
-        filter_tile(bid, mr, 0, 0, &tin[0]);
-        PA_WAIT_VM();
-    }
-    PA_BARRIER();
-
-    // ---------------------------------------------------------------- the tiles
-    // roles of the loaders in iteration k — wave 0: which candidates of t_{k+1} arrive, their records (a chain of LDS reads and
-    // ballots, then gathers); wave 1: (x, y) of t_{k+2}'s candidates, per-tile words of t_{k+3}; wave 2: chem window and half the
-    // stayers' streams of t_{k+1}; wave 3: counters of t_{k−1} to memory, food block and the other streams of t_{k+1}.  Waves 2
-    // and 3 run at the rate memory delivers (every CU pulls its windows at the same time), 0 and 1 at their instruction rate.
-    for (int k = 0; k < nk; ++k) {
-        const int b = k & 1;
-        [[maybe_unused]] const int stile = bid + k * G;
-        if (wave < PA_LOADERS) {
-            if (wave == 0) {
-                PA_STAMP(0, stile);
-                if (k + 1 < nk) filter_tile(bid + (k + 1) * G, mr + ((k + 1) & 3) * PA_MWORDS, (k + 1) % 3, b ^ 1, &tin[(k + 1) % 3]);
-                PA_STAMP(2, stile);
-            } else if (wave == 1) {
-                if (k + 2 < nk) issue_candidates(mr + ((k + 2) & 3) * PA_MWORDS, (k + 2) % 3);
-                if (k + 3 < nk) pa_meta_issue(p, bid + (k + 3) * G, mr + ((k + 3) & 3) * PA_MWORDS, lane);
-                PA_STAMP(4, stile);
-            } else {
-                if (wave == 3 && k >= 1) flush_tile(&tin[(k - 1) % 3], &tacc[b ^ 1]);
-                if (wave == 3) PA_STAMP(1, stile);
-                if (k + 1 < nk) {
-                    issue_window(bid + (k + 1) * G, b ^ 1);
-                    if (wave == 2) PA_STAMP(5, stile);
-                    issue_stayers(mr + ((k + 1) & 3) * PA_MWORDS, b ^ 1);
-                }
-                if (wave == 2) PA_STAMP(6, stile);
-            }
-            PA_WAIT_VM();
-            if (wave == 0) PA_STAMP(3, stile);
-            if (wave == 2) PA_STAMP(7, stile);
-        } else {
-            // ------------------------------------------------------------ compute waves: tile t_k from LDS
-            const int cw = wave - PA_LOADERS;
-            const PaTileIn* ti = &tin[k % 3];
-            PaTileAcc* ta = &tacc[b];
-            const int tile = (int)pa_uni(ti->tile), tx = (int)pa_uni((uint32_t)ti->tx), ty = (int)pa_uni((uint32_t)ti->ty);
-            const uint32_t own = pa_uni(ti->own), ncand = pa_uni(ti->ncand), nh = pa_uni(ti->nh), cstop = pa_uni(ti->cstop);
-            const uint32_t obase = pa_uni(ti->obase), on = pa_uni(ti->on), base0 = pa_uni(ti->base0);
-            const int x0 = tx << XS, y0 = ty << YS;
-            const uint32_t sown = min(own, (uint32_t)PA_SCAP), nmain_agents = sown + nh;
-            const uint32_t n_main = (nmain_agents + DIE_WAVE - 1) / DIE_WAVE;
-            const uint32_t n_ovs = (own - sown + DIE_WAVE - 1) / DIE_WAVE;
-            const uint32_t n_ovc = (ncand - cstop + DIE_WAVE - 1) / DIE_WAVE;
-            const uint32_t* sb = (const uint32_t*)(pic_smem + L.s[b]);
-            const uint32_t* ab = (const uint32_t*)(pic_smem + L.a[b]);
-            FwdTileMem<T, TILED> tm;
-            tm.g = p.g;
-            T* s_chem = (T*)(pic_smem + L.w[b]);
-            T* s_food = (T*)(pic_smem + L.w[b] + L.food_off);
-            tm.food = s_food; tm.fx0 = x0 - FR; tm.fy0 = y0 - FC; tm.fpitch = fpitch;
-            tm.chem = s_chem; tm.cx0 = x0 - P; tm.cy0 = y0 - P; tm.pitch = pitch;
-            long long gsum = 0;
-            uint32_t nowned = 0;
-            for (uint32_t item = (uint32_t)cw; item < n_main + n_ovs + n_ovc; item += PA_CW) {
-                bool act = false;
-                uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0, j = 0;
-                float af = 0.f;
-                if (item < n_main) {                                 // staged: stayers, then arrivals
-                    const uint32_t idx = item * DIE_WAVE + lane;
-                    act = idx < nmain_agents;
-                    if (act) {
-                        if (idx < sown) {
-                            X = sb[idx]; Y = sb[PA_SCAP + idx]; sid = sb[2 * PA_SCAP + idx]; hh = sb[3 * PA_SCAP + idx]; hl = sb[4 * PA_SCAP + idx];
-                            af = __uint_as_float(sb[5 * PA_SCAP + idx]);
-                            j = base0 + idx;
-                        } else {
-                            const uint32_t a = idx - sown;
-                            X = ab[a]; Y = ab[PA_ACAP + a]; sid = ab[2 * PA_ACAP + a]; hh = ab[3 * PA_ACAP + a]; hl = ab[4 * PA_ACAP + a];
-                            af = __uint_as_float(ab[5 * PA_ACAP + a]);
-                            j = ab[6 * PA_ACAP + a];
-                        }
-                    }
-                } else {                                             // crowds: beyond the staged capacities, loaded directly
-                    const uint32_t *ix_ = (const uint32_t*)ka->p.in.x, *iy_ = (const uint32_t*)ka->p.in.y, *is_ = (const uint32_t*)ka->p.in.slot;
-                    const uint32_t *ihh_ = (const uint32_t*)ka->p.in.hhi, *ihl_ = (const uint32_t*)ka->p.in.hlo;
-                    const float* ia_ = (const float*)ka->p.in.agent_food;
-                    if (item < n_main + n_ovs) {
-                        const uint32_t idx = (uint32_t)PA_SCAP + (item - n_main) * DIE_WAVE + lane;
-                        act = idx < own;
-                        j = base0 + idx;
-                        if (act) { X = PIC_AT(ix_, const uint32_t, j); Y = PIC_AT(iy_, const uint32_t, j); }
-                    } else {
-                        const uint32_t c = cstop + (item - n_main - n_ovs) * DIE_WAVE + lane;
-                        if (c < ncand) {
-                            const uint32_t idx = own + c;
-                            int r = 1;
-                            while (idx >= ti->pre[r + 1]) ++r;
-                            j = ti->base[r] + (idx - ti->pre[r]);
-                            X = PIC_AT(ix_, const uint32_t, j); Y = PIC_AT(iy_, const uint32_t, j);
-                            act = pic_tile_of<TILED>(p, X, Y) == tile;
-                        }
-                    }
-                    if (act) {
-                        sid = PIC_AT(is_, const uint32_t, j); hh = PIC_AT(ihh_, const uint32_t, j); hl = PIC_AT(ihl_, const uint32_t, j);
-                        af = PIC_AT(ia_, const float, j);
-                    }
-                }
-                bool stay = false, listed = false;
-                float dep = 0.f;
-                double hd = 0.0;
-                uint32_t code = 0;
-                if (act) {
-                    hd = __hiloint2double((int)hh, (int)hl);
-                    const FwdOut o = die_forward_agent_mem<T, DIE_AGENT_PHYSARUM, false, FwdTileMem<T, TILED>, true>(f, tm, X, Y, hd, sid, (int64_t)j);
-                    if (p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }
-                    // _agent_move (core/env.py:163-172)
-                    if (p.boundary == DIE_BOUNDARY_WRAP) {
-                        X += (uint32_t)die_q32_small(o.dx);
-                        Y += (uint32_t)die_q32_small(o.dy);
-                    } else {
-                        const int64_t qx = (int64_t)X + die_q32_small(o.dx), qy = (int64_t)Y + die_q32_small(o.dy);
-                        X = (uint32_t)(qx < 0 ? 0 : (qx > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qx));
-                        Y = (uint32_t)(qy < 0 ? 0 : (qy > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : qy));
-                    }
-                    const int gcx = die_cell_u(X, p.g.gW), gcy = die_cell_u(Y, p.g.gH);
-                    const int cx = TILED ? die_plane_coord(gcx, p.g.ox, p.g.W, p.g.gW) : gcx;
-                    const int cy = TILED ? die_plane_coord(gcy, p.g.oy, p.g.H, p.g.gH) : gcy;
-                    const int ntx_ = cx >> XS, nty_ = cy >> YS;
-                    stay = ntx_ == tx && nty_ == ty;
-                    // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption
-                    int rx = cx - x0, ry = cy - y0;
-                    rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
-                    ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
-                    rx = min(max(rx + FR, 0), frows - 1); ry = min(max(ry + FC, 0), fpitch - 1);
-                    const float fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry));
-                    const float consumed = p.rate_feed * fnew;
-                    const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
-                    const float gained = consumed - cost;
-                    af += gained;
-                    if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_fix(gained); ++nowned; }
-                    hd = o.heading;
-                    dep = o.dep;
-                    int ddx = 0, ddy = 0;
-                    if (!stay) {
-                        ddx = ntx_ - tx; ddy = nty_ - ty;
-                        ddx = ddx > 1 ? ddx - p.ntx : (ddx < -1 ? ddx + p.ntx : ddx);
-                        ddy = ddy > 1 ? ddy - p.nty : (ddy < -1 ? ddy + p.nty : ddy);
-                        if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) { atomicOr(p.error, 2u); ddx = ddy = 0; }
-                        else atomicAdd(&ta->inc[(ddx + 1) * 3 + ddy + 1], 1u);
-                    }
-                    const int lx = cx & (TX - 1), ly = cy & (TY - 1), Rr = p.rim_r;
-                    const int ex = lx < Rr ? 0 : (lx >= TX - Rr ? 2 : 1), ey = ly < Rr ? 0 : (ly >= TY - Rr ? 2 : 1);
-                    code = (uint32_t)(((ddx + 1) * 3 + ddy + 1) * 9 + ex * 3 + ey);
-                    listed = !stay || ex != 1 || ey != 1;
-                }
-                const unsigned long long m_stay = __ballot(act && stay), m_leave = __ballot(act && !stay), m_rim = __ballot(act && listed);
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&ta->cnt, (unsigned long long)__popcll(m_stay) | ((unsigned long long)__popcll(m_leave) << 21) |
-                                                          ((unsigned long long)__popcll(m_rim) << 42));
-                base = __shfl(base, 0, DIE_WAVE);
-                const uint32_t bf = (uint32_t)base & 0x1FFFFFu, bb = (uint32_t)(base >> 21) & 0x1FFFFFu, br = (uint32_t)(base >> 42) & 0x1FFFFFu;
-                const uint32_t kk = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
-                if (act && listed) {
-                    const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
-                    if (at < (uint32_t)p.rim_cap) {
-                        ta->rimc[at] = (uint8_t)code;
-                        ((uint4*)ka->p.rim)[(size_t)tile * p.rim_cap + at] = make_uint4(X, Y, sid, __float_as_uint(dep));
-                    }
-                }
-                if (act) {
-                    if (kk < on) {
-                        const uint32_t q = obase + kk;
-                        uint32_t *ox_ = (uint32_t*)ka->p.out.x, *oy_ = (uint32_t*)ka->p.out.y, *os_ = (uint32_t*)ka->p.out.slot;
-                        uint32_t *ohh_ = (uint32_t*)ka->p.out.hhi, *ohl_ = (uint32_t*)ka->p.out.hlo;
-                        float *oa_ = (float*)ka->p.out.agent_food, *od_ = (float*)ka->p.dep;
-                        PIC_AT(ox_, uint32_t, q) = X;
-                        PIC_AT(oy_, uint32_t, q) = Y;
-                        PIC_AT(oa_, float, q) = af;
-                        PIC_AT(os_, uint32_t, q) = sid;
-                        PIC_AT(ohh_, uint32_t, q) = (uint32_t)__double2hiint(hd);
-                        PIC_AT(ohl_, uint32_t, q) = (uint32_t)__double2loint(hd);
-                        PIC_AT(od_, float, q) = dep;
-                    } else {
-                        atomicOr((uint32_t*)ka->p.error, 1u);
-                    }
-                }
-            }
-            gsum = die_wave_sum(gsum);
-            if (lane == 0) ta->gain[cw] = gsum;
-            if (TILED) {
-                const long long c = die_wave_sum((long long)nowned);
-                if (lane == 0) ta->alv[cw] = (uint32_t)c;
-            }
-            if (cw == 0) PA_STAMP(8, stile);
-            if (cw == PA_CW - 1) PA_STAMP(9, stile);
-        }
-        PA_BARRIER();
-        if (wave == 0) PA_STAMP(10, stile);
-    }
-    if (wave == 0) flush_tile(&tin[(nk - 1) % 3], &tacc[(nk - 1) & 1]);
 }
 
 // ---- dead slots on the tile-binned path (the reference's default layout: max_agents = W·H slots, core/data_init.py:143-144) ----------
@@ -1414,11 +817,10 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, ui
         const uint32_t c = (uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy;
         // _agent_feed (core/env.py:224-233): a dead slot "consumes" iff somebody alive stands on its cell
         const bool occupied = occ[c] != 0;
-        const float consumed = occupied ? p.rate_feed * die_ld(food, (int64_t)c) : 0.f;
+        const float consumed = occupied ? die_consumed(p.rate_feed, die_ld(food, (int64_t)c)) : 0.f;
         const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
-        const float gained = consumed - cost;
-        gsum += die_fix(gained);
-        p.out.x[j] = X; p.out.y[j] = Y; p.out.agent_food[j] = p.in.agent_food[j] + gained; p.out.slot[j] = sid;
+        gsum += die_feed_fix(cost, consumed);
+        p.out.x[j] = X; p.out.y[j] = Y; p.out.agent_food[j] = die_feed(p.in.agent_food[j], cost, consumed); p.out.slot[j] = sid;
         p.out.hhi[j] = (uint32_t)__double2hiint(o.heading); p.out.hlo[j] = (uint32_t)__double2loint(o.heading);
         p.dep[j] = o.dep;
     }
@@ -1542,7 +944,7 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
         *(uint4*)(dep_plane + off) = make_uint4(o[0], o[1], o[2], o[3]);
         if (FEED && (c[0] | c[1] | c[2] | c[3])) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (c[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
+            for (int q = 0; q < 4; ++q) if (c[q]) fd[g][q] = die_food_after(p.rate_feed, fd[g][q]);
             Vec4<T>::st((T*)p.food + off, fd[g]);
         }
     }
@@ -1585,7 +987,27 @@ struct KbArgs {
     int64_t turn_words;
     uint64_t turn_seed;
     uint32_t turn_step;
+    // food stream (single-tile worlds): the step's reward = the agent kernel's per-tile partials (costs, leavers' consumption) + the
+    // consumption of every tile's stayers, known to that tile's workgroup here.  Every workgroup adds its share to *acc and draws a
+    // ticket from *done; the one that draws the last of `tickets` writes the result and leaves both words 0 for the next step.
+    unsigned long long* acc;
+    uint32_t* done;
+    uint32_t tickets;
 };
+
+// One workgroup's share of the step's reward (thread-level: ONE thread calls this).  Integers: any order.
+__device__ __forceinline__ void kb_contribute(const KbArgs& a, long long share) {
+    atomicAdd(a.acc, (unsigned long long)share);
+    __threadfence();                                            // the share is in before the ticket is drawn
+    const uint32_t t = atomicAdd(a.done, 1u);
+    if (t + 1u != a.tickets) return;
+    __threadfence();
+    const long long total = (long long)atomicAdd(a.acc, 0ull);  // every other workgroup's share went in before its ticket
+    a.result->reward = (double)total / DIE_FIX_ONE; a.result->num_alive = a.alive_const;
+    if (a.status_out) *a.status_out = (long long)*a.error;      // (set by the agent kernel: a kernel boundary lies in between)
+    atomicExch(a.acc, 0ull);
+    atomicExch(a.done, 0u);
+}
 
 template <int XS, int YS> struct KbShape {
     static constexpr int BLOCK = ((1 << XS) * (1 << YS) >= 4096) ? 512 : 256;
@@ -1604,7 +1026,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     constexpr int WR = TX + 2 * R, WC = TY + 2 * R;        // the window
     constexpr int CP = TY + 2 * A, NV = CP / A;            // staged columns [y0 − A, y0 + TY + A): whole vectors; vectors per row
     static_assert(R >= 1 && R <= 4 && R <= A, "the rim lies inside one vector beside the tile");
+    constexpr bool FS = !TILED;                             // food stream (see k_pic_forward_move): this kernel writes fpre of its stayers
     extern __shared__ __align__(16) unsigned char kb_smem[];
+    __shared__ long long s_kg[FS ? BLOCK / DIE_WAVE : 1];   // FS: the waves' sums of their stayers' consumption
     float* s_chem = (float*)kb_smem;                        // WR × CP, window cell (r, c) at r·CP + c − R + A
     uint32_t* s_claim = (uint32_t*)(s_chem + WR * CP);      // WR × WC; after the deposits: s_tmp, TX × CP (the x pass)
     float* s_tmp = (float*)s_claim;
@@ -1671,8 +1095,12 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
-                if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
+                if (FS) {
+                    kb_contribute(a, s_g[0]);
+                } else {
+                    a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
+                    if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
+                }
             }
         } else if (blockIdx.x >= 2 && a.turn_bits) {        // the rest of the row: the next step's turn bits (this step's agent kernel is done with the table)
             pic_turn_bits_fill(a.turn_bits, a.turn_words, a.turn_seed, a.turn_step, (int64_t)(blockIdx.x - 2) * BLOCK + threadIdx.x,
@@ -1760,6 +1188,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     if constexpr (NCV > 2) window_commit(2, cv2);
     const uint32_t own0 = s_own[0], nown = s_own[1];
     // window cell of an agent standing on the tile at (ux, uy) tiles from d; 0xFFFFFFFF: outside the window
+    [[maybe_unused]] long long kgain = 0;
+    // FS, a stayer: its cell of the food plane (it stands on this tile: the element is this workgroup's to read and to feed)
+    auto food_at = [&](uint32_t X, uint32_t Y) { return (int64_t)pic_row<TILED>(p.g, X) * H + pic_col<TILED>(p.g, Y); };
     auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
         const int cx = pic_row<TILED>(p.g, X), cy = pic_col<TILED>(p.g, Y);
         const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
@@ -1801,6 +1232,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     constexpr int FG = (TX * TY / 4 + BLOCK - 1) / BLOCK;
     float fd[FG][4];
     uint32_t cw[2 + NE], cs[2 + NE], cd[2 + NE];
+    [[maybe_unused]] float fpv[2] = {0.f, 0.f};             // FS: the food under this thread's two stayers, before this step's consumption
     {
         uint32_t X[2 + NE], Y[2 + NE], uc[NE];
         const uint32_t rj[NE] = {rim_decode(0, uc[0]), rim_decode(1, uc[1]), rim_decode(2, uc[2]), rim_decode(3, uc[3])};
@@ -1826,6 +1258,12 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::template ld<4>(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
             }
         }
+        // FS: the food under the stayers — one 4-byte gather each, behind the tile's own 16-byte loads of the same lines, ahead of the
+        // barrier that separates every read of the tile's food from its consumption below
+        if (FS) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (cw[u] != 0xFFFFFFFFu) fpv[u] = die_ld((const T*)food, food_at(X[u], Y[u]));
+        }
 #pragma unroll
         for (int u = 0; u < 2 + NE; ++u) {
             if (cw[u] == 0xFFFFFFFFu) continue;
@@ -1834,8 +1272,13 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         }
     }
     for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
-        const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
+        const uint32_t j = own0 + i, X_ = p.out.x[j], Y_ = p.out.y[j], w_ = window_cell(X_, Y_, 0, 0);
         if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_ & 0xFFFFu], p.out.slot[j] + 1u);
+        if (FS) {                                           // (a crowd's stayers beyond the first two per thread)
+            const float fv = die_ld((const T*)food, food_at(X_, Y_));
+            p.out.fpre[j] = fv;
+            kgain += die_fix(die_consumed(p.rate_feed, fv));
+        }
     }
     if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, false);
     PIC_STAMP(10);
@@ -1850,6 +1293,18 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     };
 #pragma unroll
     for (int u = 0; u < 2 + NE; ++u) deposit(cw[u], cs[u], cd[u]);
+    if (FS) {
+        // the stayers' food stream entries and their consumption (core/env.py:224-225: every slot on a cell gets the cell's rate·food)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (threadIdx.x + u * BLOCK < nown) {
+                p.out.fpre[own0 + threadIdx.x + u * BLOCK] = fpv[u];
+                kgain += die_fix(die_consumed(p.rate_feed, fpv[u]));
+            }
+        }
+        kgain = die_wave_sum(kgain);
+        if ((threadIdx.x & (DIE_WAVE - 1)) == 0) s_kg[threadIdx.x / DIE_WAVE] = kgain;
+    }
     for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
         const uint32_t j = own0 + i;
         deposit(window_cell(p.out.x[j], p.out.y[j], 0, 0), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
@@ -1865,7 +1320,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             const bool occ[4] = {c[0] != 0u, c[1] != 0u, c[2] != 0u, c[3] != 0u};
             if (occ[0] || occ[1] || occ[2] || occ[3]) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
+                for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = die_food_after(p.rate_feed, fd[g][q]);
                 Vec4<T>::template st_sel<9>(a.nt_out != 0, food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
             }
         }
@@ -1873,6 +1328,13 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     __syncthreads();
     PIC_STAMP(12);
     PIC_SETPRIO(PIC_PRIO_KB, 2);
+    // FS: this tile's share of the reward — by the LAST thread: its wave has no item of the x pass below and would only wait at the
+    // next barrier
+    if (FS && a.result && threadIdx.x == BLOCK - 1) {
+        long long t = 0;
+        for (int w = 0; w < BLOCK / DIE_WAVE; ++w) t += s_kg[w];
+        kb_contribute(a, t);
+    }
     // 5. x pass (axis 0): column c of the window, RB output rows per item, the 2R + 1 rows of the stencil in registers
     constexpr int RB = TX >= 64 ? 16 : 8;
     for (int item = threadIdx.x; item < WC * (TX / RB); item += BLOCK) {
@@ -1935,6 +1397,8 @@ struct PicBinArgs {
     uint32_t* dead_cursor;
     const float *pgx, *pgy;         // GradientAgent with inertia: _prev_grad travels along (NULL: none)
     float *opgx, *opgy;
+    const void* food;               // out.fpre != NULL (food stream): the food under every alive agent, from this plane (f16: of halves)
+    int f16;
 };
 
 __global__ __launch_bounds__(DIE_BLOCK) void k_pic_hist(PicBinArgs a, uint32_t* hist) {
@@ -1996,6 +1460,26 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
         a.out.hhi[j] = a.hhi[n];
         a.out.hlo[j] = a.hlo[n];
         if (a.pgx) { a.opgx[j] = a.pgx[n]; a.opgy[j] = a.pgy[n]; }
+        if (a.out.fpre) {           // (single-tile worlds only: the plane cell is the world cell)
+            const int64_t c = (int64_t)die_cell_u(X, a.g.gW) * a.g.H + die_cell_u(Y, a.g.gH);
+            a.out.fpre[j] = !active ? 0.f : (a.f16 ? die_ld((const __half*)a.food, c) : die_ld((const float*)a.food, c));
+        }
+    }
+}
+
+// Food stream housekeeping between steps (die_pic_settle): entries [0, n) of a layout a step wrote.
+//   apply     agent_food += rate·fpre — the consumption of that step, which the NEXT step's agent kernel would have added
+//   regather  fpre ← the food under the agent as the plane holds it now (somebody may have written the plane); else, with `apply`,
+//             fpre ← what that consumption left on the cell (the same value, from arithmetic: no gather, no coordinates)
+template <typename T>
+__global__ __launch_bounds__(DIE_BLOCK) void k_pic_settle(die_geo g, uint32_t n, const uint32_t* x, const uint32_t* y, float* agent_food, float* fpre,
+                                                          const T* food, float rate, int food_infinite, int apply, int regather) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        const float fp = fpre[j];
+        if (apply) agent_food[j] = __fadd_rn(agent_food[j], die_consumed(rate, fp));
+        if (regather) fpre[j] = die_ld(food, (int64_t)die_cell_u(x[j], g.gW) * g.H + die_cell_u(y[j], g.gH));
+        else if (apply && !food_infinite) fpre[j] = die_as_stored<T>(die_food_after(rate, fp));
     }
 }
 
@@ -2032,6 +1516,8 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
         DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
     }
     DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
+    DIE_REQUIRE(!(p->rim && m->gW <= 0) || (p->layout[0].fpre && p->layout[1].fpre && p->layout[0].fpre != p->layout[1].fpre),
+                "%s: the two-launch form on a single-tile world needs the food stream arrays (die_pic_layout.fpre) of both layouts", who);
     DIE_REQUIRE(p->dep && p->part_gain && p->error && ((p->rim && p->rim_code && p->rim_cnt) || p->dep_plane), "%s: null workspace pointer", who);
     return DIE_OK;
 }
@@ -2040,6 +1526,7 @@ static PicLayout pic_layout(const die_pic_layout& L) {
     PicLayout o;
     o.x = L.x; o.y = L.y; o.agent_food = L.agent_food; o.slot = L.slot; o.hhi = L.heading_hi; o.hlo = L.heading_lo;
     o.off = L.off; o.n = L.n; o.s = L.s; o.inc = L.inc;
+    o.fpre = L.fpre;
     return o;
 }
 
@@ -2100,6 +1587,9 @@ static int pic_bin(const die_medium* m, const die_agents* a, const uint32_t* hea
     b.out = pic_layout(p->layout[into]); b.cursor = cursor;
     b.alive = dead ? a->alive : nullptr; b.n_alive = dead ? (uint32_t)p->n_alive : (uint32_t)p->N; b.dead_cursor = hist + 2 * NT;
     b.pgx = prev_gx; b.pgy = prev_gy; b.opgx = p->prev_grad[into][0]; b.opgy = p->prev_grad[into][1];
+    b.food = m->food; b.f16 = m->dtype != DIE_F32;
+    if (m->gW > 0) b.out.fpre = nullptr;                     // (a decomposed world's tile: no food stream)
+    DIE_REQUIRE(!b.out.fpre || m->food, "die_pic_bin: the food stream needs the food plane");
     DIE_REQUIRE((prev_gx != nullptr) == (prev_gy != nullptr) && (!prev_gx || (b.opgx && b.opgy && b.opgx != prev_gx)),
                 "die_pic_bin: _prev_grad given without die_pic.prev_grad[%d] to carry it into", into);
     int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
@@ -2119,14 +1609,19 @@ extern "C" int die_pic_bin_momentum(const die_medium* m, const die_agents* a, co
     return pic_bin(m, a, heading_hi, heading_lo, prev_gx, prev_gy, p, into, stream);
 }
 
-static int pa_cu_count() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 256;
-    }
-    return cus;
+extern "C" int die_pic_settle(const die_medium* m, const die_pic* p, int32_t lay, const die_dynamics* d, int32_t apply, int32_t regather, void* stream) {
+    DIE_REQUIRE(m && p && d && (lay == 0 || lay == 1) && m->food && m->gW <= 0, "die_pic_settle: null argument, or a decomposed world's tile (no food stream there)");
+    const die_pic_layout& L = p->layout[lay];
+    const int64_t n = p->n_alive > 0 && p->n_alive < p->N ? p->n_alive : p->N;
+    DIE_REQUIRE(L.fpre && L.agent_food && L.x && L.y && n > 0 && n < ((int64_t)1 << 32), "die_pic_settle: null array in layout %d", lay);
+    if (!apply && !regather) return DIE_OK;
+    const int64_t g = (n + DIE_BLOCK - 1) / DIE_BLOCK;
+    const int grid = (int)(g < 8192 ? g : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    if (m->dtype == DIE_F32) k_pic_settle<float><<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), (uint32_t)n, L.x, L.y, L.agent_food, L.fpre, (const float*)m->food, d->rate_feed, d->food_infinite, apply, regather);
+    else k_pic_settle<__half><<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), (uint32_t)n, L.x, L.y, L.agent_food, L.fpre, (const __half*)m->food, d->rate_feed, d->food_infinite, apply, regather);
+    DIE_CHECK_LAUNCH("die_pic_settle");
+    return DIE_OK;
 }
 
 template <int XS, int YS>
@@ -2140,28 +1635,12 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
     }
 }
 
-// PERSIST (two-launch form with staged windows): three workgroups per CU draw the tiles from k.queue
-template <typename T, bool TILED>
-static void launch_forward_move_queue(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s) {
-    const int g3 = 3 * pa_cu_count();
-    const dim3 grid(NT < g3 ? NT : g3);
-    if (getenv("DIE_PIC_DEBUG")) {
-        int nq = -1, np_ = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nq, (const void*)k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, TILED, true>, block, lds);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&np_, (const void*)k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, TILED, false>, block, lds);
-        fprintf(stderr, "die_pic: occupancy (workgroups per CU) queue form %d, plain form %d; block %d, dynamic LDS %zu, grid %u\n", nq, np_, block, lds, grid.x);
-    }
-    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, true, true, true, TILED, true><<<grid, block, lds, s>>>(f, k);
-    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, true, true, TILED, true><<<grid, block, lds, s>>>(f, k);
-    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, TILED, true><<<grid, block, lds, s>>>(f, k);
-}
-
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s, bool mom = false) {
     const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx);
     if constexpr (!TILED) {
         if (kind != DIE_AGENT_PHYSARUM && mom) {
-            k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, false, false, true><<<grid, block, lds, s>>>(f, k);
+            k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, false, true><<<grid, block, lds, s>>>(f, k);
             return;
         }
     }
@@ -2194,38 +1673,6 @@ static void launch_resolve_diffuse_shape(int xs, int ys, const PicArgs& k, const
     else if (xs == 5 && ys == 7) launch_resolve_diffuse<T, 5, 7, TILED>(k, a, R, s);
     else if (xs == 5 && ys == 6) launch_resolve_diffuse<T, 5, 6, TILED>(k, a, R, s);
     else launch_resolve_diffuse<T, 4, 5, TILED>(k, a, R, s);
-}
-
-static PaLds pa_lds_layout(int P, int FR, int FC, int esz) {
-    const int TX = 64, TY = 64;
-    PaLds L;
-    uint32_t at = 0;
-    auto take = [&](uint32_t bytes) { const uint32_t o = at; at += (bytes + 15u) & ~15u; return o; };
-    const uint32_t chem = (uint32_t)((TX + 2 * P) * (TY + 2 * P) * esz), food = (uint32_t)((TX + 2 * FR) * (TY + 2 * FC) * esz);
-    L.food_off = (chem + 15u) & ~15u;
-    for (int b = 0; b < 2; ++b) L.w[b] = take(L.food_off + food);
-    for (int b = 0; b < 2; ++b) L.s[b] = take(6 * PA_SCAP * 4);
-    for (int b = 0; b < 3; ++b) L.c[b] = take(3 * PA_CCAP * 4);
-    for (int b = 0; b < 2; ++b) L.a[b] = take(7 * PA_ACAP * 4);
-    L.mr = take(4 * PA_MWORDS * 4);
-    L.tin = take(3 * sizeof(PaTileIn));
-    L.tacc = take(2 * sizeof(PaTileAcc));
-    L.ranges = take(32 * 4);
-    L.total = at;
-    return L;
-}
-
-template <typename T, bool TILED>
-static int launch_agents(const FwdArgs& f, const PicArgs& k, const PaLds& L, int NT, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {          // (dynamic LDS beyond the default limit)
-        hipError_t e = hipFuncSetAttribute((const void*)k_pic_agents<T, TILED>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)L.total);
-        if (e != hipSuccess) { (void)hipGetLastError(); die_set_error("die_pic_forward_env_step: %u bytes of LDS refused: %s", L.total, hipGetErrorString(e)); return DIE_ERR_HIP; }
-        attr_set = true;
-    }
-    const int cus = pa_cu_count();
-    k_pic_agents<T, TILED><<<NT < cus ? NT : cus, PA_WAVES * DIE_WAVE, L.total, s>>>(f, k, L);
-    return DIE_OK;
 }
 
 extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g,
@@ -2279,7 +1726,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.adx = act ? act->dx : nullptr; k.ady = act ? act->dy : nullptr; k.adep = act ? act->deposit : nullptr;
     k.food = m->food; k.rate_feed = d->rate_feed; k.w_dep = d->cost_w_deposit; k.w_dist = d->cost_w_dist;
     k.boundary = d->boundary; k.cost = d->cost;
-    k.part_gain = (long long*)p->part_gain; k.error = p->error; k.queue = nullptr;
+    k.part_gain = (long long*)p->part_gain; k.error = p->error;
     k.sub_mode = p->sub_mode; k.sub_tx0 = p->sub_tx0; k.sub_ty0 = p->sub_ty0; k.sub_ntx = p->sub_ntx; k.sub_nty = p->sub_nty;
     const bool keep_pg = mom && g->inertia != 0.f;
     k.ipgx = keep_pg ? pg_in[0] : nullptr; k.ipgy = keep_pg ? pg_in[1] : nullptr; k.opgx = keep_pg ? pg_out[0] : nullptr; k.opgy = keep_pg ? pg_out[1] : nullptr;
@@ -2302,8 +1749,8 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     // the food block: the tile ± the cells an agent can walk onto in one step (floor(reach) + 1 by the move, one more across the
     // world's seam), columns in whole vectors
     k.fm_r = stage ? (int)floorf(reach) + 2 : 0;
-    // (columns: only for the persistent agent kernel, which has no path to global memory in its compute waves; PIC_FOOD_COLS = 1: always)
-    k.fm_c = (PIC_FOOD_COLS || p->k1_threads == -1) ? (k.fm_r + V - 1) / V * V : 0;
+    // (columns: PIC_FOOD_COLS = 1 only)
+    k.fm_c = PIC_FOOD_COLS ? (k.fm_r + V - 1) / V * V : 0;
     const int vpr_c = (TY + 2 * k.margin) / V, vpr_f = (TY + 2 * k.fm_c) / V;     // 16-byte vectors per staged row
     k.mg_c = ((1u << 20) + (uint32_t)vpr_c - 1u) / (uint32_t)vpr_c;
     k.mg_f = ((1u << 20) + (uint32_t)vpr_f - 1u) / (uint32_t)vpr_f;
@@ -2315,7 +1762,6 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     DIE_REQUIRE(!stage || (m->W < (1 << 23) && m->H < (1 << 23) && (int64_t)m->W * m->H < (1ll << 31)),
                 "die_pic_forward_env_step: plane too large for the 24-bit index arithmetic of the staging loop");
     DIE_REQUIRE(!stage || m->H % V == 0, "die_pic_forward_env_step: plane rows must be whole 16-byte vectors");
-    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (size_t)(TX + 2 * k.fm_r) * (TY + 2 * k.fm_c)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
     // two launches (one field kernel per tile, fed by the agent kernel's rim lists) when the caller gave the lists and every
     // agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
@@ -2324,6 +1770,12 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr &&
                      pic_two_launch_rule(worldmax, p->tile_xs, p->tile_ys, step_scale, d->diffuse_sigma, d->diffuse_mode);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
+    // food stream (two-launch form on a single-tile world; k_pic_forward_move): the agent kernel stages no food block
+    const bool fs = two && !tiled;
+    DIE_REQUIRE(fs ? (p->food_state == DIE_PIC_FOOD_PENDING || p->food_state == DIE_PIC_FOOD_FRESH) : p->food_state != DIE_PIC_FOOD_PENDING,
+                "die_pic_forward_env_step: food_state %d does not fit this step (%s): die_pic_settle first", p->food_state, fs ? "food stream" : "food plane");
+    k.fs_fresh = p->food_state == DIE_PIC_FOOD_FRESH; k.food_infinite = d->food_infinite;
+    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (fs ? 0 : (size_t)(TX + 2 * k.fm_r) * (TY + 2 * k.fm_c))) * esz : 0;
     DIE_REQUIRE(two || !p->sub_mode, "die_pic_forward_env_step: subsets of the tiles exist in the two-launch form only");
     DIE_REQUIRE(!(dead && p->sub_mode), "die_pic_forward_env_step: subsets of the tiles and dead slots do not combine");
     if (tiled && !(two && stage)) {
@@ -2351,28 +1803,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             k_turn_bits<<<(int)(blocks < 1024 ? blocks : 1024), DIE_BLOCK, 0, s>>>(p->turn_bits, turn_words, g->seed, g->step);
         }
     }
-    // the persistent agent kernel (k_pic_agents) when the caller asks for it (k1_threads = −1) and it applies: two-launch form,
-    // 64×64 tiles, staged windows, PhysarumAgent.  Not the default: at 4096² it takes 101 µs against 81 µs
-    bool persistent = false;
-    PaLds PL = {};
-    if (two && stage && physarum && p->tile_xs == 6 && p->tile_ys == 6 && p->k1_threads == -1 && !p->sub_mode) {
-        PL = pa_lds_layout(k.margin, k.fm_r, k.fm_c, esz);
-        const int nvc = (TX + 2 * k.margin) * vpr_c, nvf = (TX + 2 * k.fm_r) * vpr_f;
-        bool ok = PL.total <= 160u * 1024u && nvc < 4096 && nvf < 4096;
-        for (int i = 0; ok && i < nvc; ++i) ok = (int)(((uint32_t)i * k.mg_c) >> 20) == i / vpr_c;
-        for (int i = 0; ok && i < nvf; ++i) ok = (int)(((uint32_t)i * k.mg_f) >> 20) == i / vpr_f;
-        persistent = ok;
-    }
-    if ((stages & 1) && persistent) {
-        int rc2;
-        if (tiled) rc2 = m->dtype == DIE_F32 ? launch_agents<float, true>(f, k, PL, NT, s) : launch_agents<__half, true>(f, k, PL, NT, s);
-        else rc2 = m->dtype == DIE_F32 ? launch_agents<float, false>(f, k, PL, NT, s) : launch_agents<__half, false>(f, k, PL, NT, s);
-        if (rc2 != DIE_OK) return rc2;
-    } else if ((stages & 1) && two && stage && p->queue && PIC_QUEUE && !p->sub_mode && !mom) {
-        k.queue = p->queue;
-        if (tiled) { if (m->dtype == DIE_F32) launch_forward_move_queue<float, true>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, true>(g->kind, f, k, NT, block, lds, s); }
-        else { if (m->dtype == DIE_F32) launch_forward_move_queue<float, false>(g->kind, f, k, NT, block, lds, s); else launch_forward_move_queue<__half, false>(g->kind, f, k, NT, block, lds, s); }
-    } else if (stages & 1) {
+    if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s, mom); \
                                        else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s, mom); } while (0)
         if (tiled) {
@@ -2431,6 +1862,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
             a.result = result; a.alive_const = dead ? p->n_alive : p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
             a.n_part = NT + (dead ? dead_blocks : 0);
+            a.acc = (unsigned long long*)p->part_gain + 2 * (size_t)NT; a.done = (uint32_t*)(a.acc + 1); a.tickets = (uint32_t)NT + 1u;
             // cache policy of the field kernel's two plane stores.  Measured (profiles/r04_nt_stores_by_size.txt): with the planes and
             // agent arrays beyond the 256 MiB Infinity Cache (4096² fp32: 342 MB, 8192²) non-temporal stores make the step 3.5 % / 2 %
             // faster — the lines would be evicted before the next kernel reads them anyway and only displace the windows' shared

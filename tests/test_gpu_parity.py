@@ -490,81 +490,6 @@ def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile, fo
         assert np.array_equal(a, b), name
 
 
-@pytest.mark.parametrize('W,H,boundary,f16,N,crowd', [(320, 256, 'wrap', False, 40000, False), (256, 320, 'limit', True, 30000, False),
-                                                       (256, 256, 'wrap', False, 20000, True)])
-def test_persistent_agent_kernel_equals_the_default(die, W, H, boundary, f16, N, crowd):
-    """die_pic.k1_threads = -1: the agent kernel as one persistent 16-wave workgroup per CU (k_pic_agents: loader waves stage a
-    tile's windows, stayers and arrivals by LDS-DMA one to three tiles ahead of the compute waves) against the default agent
-    kernel (k_pic_forward_move), bit for bit over steps in which agents cross tile borders — incl. a crowd: more stayers,
-    candidate arrivals and arrivals on one tile than the staged capacities (640 / 768 / 128), which the compute waves then
-    finish with direct passes."""
-    rs = np.random.RandomState(W * 7 + H)
-    medium, agents = random_state(W, H, N, N, rs, collide=0.3)
-    if crowd:                                                  # 9 000 agents on and around one tile border, heading across it
-        n = 9000
-        agents[0, :n] = q32((63.0 + rs.uniform(-2.5, 2.5, n)) / (W - 1))
-        agents[1, :n] = q32(rs.uniform(70, 120, n) / (H - 1))
-    turn = np.radians(30)
-    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
-    if crowd:
-        dir0[:9000] = 0.0
-    outs = []
-    for threads in (-1, 0):
-        env = die.Env.from_numpy(medium, agents, die.Dynamics(boundary=die.BoundaryCondition(boundary)), pic=True,
-                                 field_dtype=torch.float16 if f16 else torch.float32)
-        env._pic_tile = (6, 6)
-        env._pic_k1_threads = threads
-        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
-        ag.set_state(dir0)
-        obs = env._get_current_obs
-        acts, rewards = [], []
-        for i in range(7):
-            action = ag.forward(obs)
-            obs, rew, _, _, info = env.step(action)
-            if i in (2, 6):
-                acts.append(action.to_numpy())
-            rewards.append((rew, info['num_agents']))
-            assert env._pic is not None and env._pic.held[0] is env.agents.x and env._pic.k1_threads == threads
-        env.check()
-        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), env.medium.owner_slots().cpu().numpy(),
-                     np.stack(acts), np.array(rewards)))
-    for name, a, b in zip(('medium', 'agents', 'heading', 'owners', 'actions', 'rewards'), outs[0], outs[1]):
-        assert np.array_equal(a, b), name
-
-
-def test_agent_kernel_tile_queue_form_equals_the_default(die):
-    """die_pic.queue: the agent kernel as a fixed grid of workgroups (three per CU) that draw tiles from a queue and prefetch the
-    next tile's segment words, first stayers and candidate arrivals while they work on the current one (k_pic_forward_move
-    <…, PERSIST>) against the default one-workgroup-per-tile launch, bit for bit — on a world of 1 600 tiles, so that a workgroup
-    takes several tiles in a row (768 workgroups on an MI355X)."""
-    W = H = 1280
-    xs = ys = 5                                               # 32x32 tiles: 40 x 40 = 1 600 of them
-    N = 250000
-    rs = np.random.RandomState(77)
-    medium, agents = random_state(W, H, N, N, rs, collide=0.2)
-    turn = np.radians(30)
-    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
-    outs = []
-    for queue in (True, False):
-        env = die.Env.from_numpy(medium, agents, pic=True)
-        env._pic_tile = (5, 6)
-        env._pic_queue = queue
-        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1))
-        ag.set_state(dir0)
-        obs = env._get_current_obs
-        rewards = []
-        for i in range(6):
-            action = ag.forward(obs)
-            obs, rew, _, _, info = env.step(action)
-            rewards.append((rew, info['num_agents']))
-            assert env._pic is not None and env._pic.held[0] is env.agents.x and (env._pic.queue is not None) == queue
-        env.check()
-        assert env._pic.queue is None or int(env._pic.queue.abs().sum().item()) == 0, 'the queue words are left at zero'
-        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), action.to_numpy(), np.array(rewards)))
-    for name, a, b in zip(('medium', 'agents', 'heading', 'last action', 'rewards'), outs[0], outs[1]):
-        assert np.array_equal(a, b), name
-
-
 def applied(action):
     """The action as the device applies it: displacements rounded to the Q0.32 grid of the coordinates (at most 2^-33 away
     from the float the agent computed — enough to put ≈ 1e-6 of the agents of a 4096-cell axis on the other side of a cell
