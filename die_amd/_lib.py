@@ -66,7 +66,7 @@ DIE_FIELD_CONST, DIE_FIELD_NOISE, DIE_FIELD_AGENTS, DIE_FIELD_PERLIN = 0, 1, 2, 
 class PicLayout(C.Structure):
     _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('agent_food', C.c_void_p), ('slot', C.c_void_p), ('heading_hi', C.c_void_p),
                 ('heading_lo', C.c_void_p),
-                ('off', C.c_void_p), ('n', C.c_void_p), ('s', C.c_void_p), ('inc', C.c_void_p), ('fpre', C.c_void_p)]
+                ('off', C.c_void_p), ('n', C.c_void_p), ('s', C.c_void_p), ('inc', C.c_void_p)]
 
 
 class Pic(C.Structure):
@@ -74,13 +74,10 @@ class Pic(C.Structure):
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
-                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('food_state', C.c_int32),
+                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32),
                 ('reserved5', C.c_void_p), ('sub_mode', C.c_int32), ('sub_tx0', C.c_int32), ('sub_ty0', C.c_int32), ('sub_ntx', C.c_int32),
                 ('sub_nty', C.c_int32), ('reserved4', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p),
                 ('prev_grad', (C.c_void_p * 2) * 2)]
-
-
-PIC_FOOD_NONE, PIC_FOOD_PENDING, PIC_FOOD_FRESH = 0, 1, 2         # die_pic.food_state
 
 
 class PicSide(C.Structure):          # die_pic_side: one neighbour of the ghost refresh by tiles
@@ -191,7 +188,6 @@ _SIGNATURES = {
     'die_pic_rim_cap': (C.c_int64, [C.c_int32, C.c_int32]),
     'die_pic_bin': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
     'die_pic_bin_momentum': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
-    'die_pic_settle': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(Dynamics), C.c_int32, C.c_int32, C.c_void_p]),
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),

@@ -117,18 +117,6 @@ __device__ __forceinline__ long long die_fix(float g) {
     return __double2ll_rn((double)g * DIE_FIX_ONE);
 }
 
-// ---- _agent_feed (core/env.py:220-243) for one slot -------------------------------------------------------------------
-// consumed = rate_feed · (food under the slot BEFORE this step's consumption); an occupied cell keeps food − rate_feed·food;
-// agent_food += consumed − burned; reward = Σ (consumed − burned) over the slots.  The association is fixed HERE for every step
-// implementation — agent_food ← (agent_food − burned) + consumed, reward ← Σ fix(consumed) − Σ fix(burned) — so that the two
-// halves can be applied by different kernels (tile-binned step: the agent kernel knows the cost, the field kernel holds the food
-// under the agents that stay on its tile; the reference's own order differs from this one by an ulp of float64 it never pins) and
-// every implementation still gives the same bits.  Explicit roundings: nothing here may fuse with its caller's arithmetic.
-__device__ __forceinline__ float die_consumed(float rate, float food) { return __fmul_rn(rate, food); }
-__device__ __forceinline__ float die_food_after(float rate, float food) { return fmaf(-rate, food, food); }
-__device__ __forceinline__ float die_feed(float agent_food, float cost, float consumed) { return __fadd_rn(__fsub_rn(agent_food, cost), consumed); }
-__device__ __forceinline__ long long die_feed_fix(float cost, float consumed) { return die_fix(consumed) - die_fix(cost); }
-
 // "no agent on this cell" in the deposit plane of the tile-binned step (a NaN no deposit can carry)
 #define DIE_DEP_EMPTY 0xFFFFFFFFu
 

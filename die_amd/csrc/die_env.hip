@@ -73,9 +73,9 @@ __device__ __forceinline__ void block_sum_store(long long g, long long c, long l
     }
 }
 
-// One slot of _agent_move + claim + _agent_feed (alive slots); returns its `gained` in fixed point (die_feed_fix; 0 for dead slots).
+// One slot of _agent_move + claim + _agent_feed (alive slots); returns its `gained` (0 for dead slots).
 template <typename T, bool EXT = true>
-__device__ __forceinline__ long long move_claim_one(const StepArgs& a, const int64_t n, uint32_t X, uint32_t Y, const float dx,
+__device__ __forceinline__ float move_claim_one(const StepArgs& a, const int64_t n, uint32_t X, uint32_t Y, const float dx,
                                                 const float dy, const float dep, const uint32_t sid, long long& owned_alive) {
     const T* food = (const T*)a.food;
     const die_geo g = a.g;
@@ -93,22 +93,22 @@ __device__ __forceinline__ long long move_claim_one(const StepArgs& a, const int
     }
     const int cx = die_cell((int64_t)X, g.gW), cy = die_cell((int64_t)Y, g.gH);
     if (a.tile_of) a.tile_of[n] = (cx / a.tile_w) * a.tiles_y + cy / a.tile_h;
-    if (!a.do_claim) return 0;
+    if (!a.do_claim) return 0.f;
     const int64_t c = die_local(g, cx, cy);
-    const float consumed = die_consumed(a.rate_feed, die_ld(food, c));
+    const float consumed = a.rate_feed * die_ld(food, c);
     if (a.alive[n]) {
         // Claim: one 64-bit atomicMax (a plain store + a repair pass was measured: 70 + 38 µs against 105 µs, no gain)
         atomicMax(&a.owner[c], die_claim(a.epoch, (int64_t)sid, dep));
-        const float cost = action_cost(a, dx, dy, dep);
-        a.agent_food[n] = die_feed(a.agent_food[n], cost, consumed);
+        const float gained = consumed - action_cost(a, dx, dy, dep);
+        a.agent_food[n] += gained;
         if (EXT) {                                     // ghost-agent tiles (compiled out of the single-tile kernel)
-            if (!die_owned(g, cx, cy)) return 0;       // a ghost: the rank that owns this cell accounts for it
+            if (!die_owned(g, cx, cy)) return 0.f;     // a ghost: the rank that owns this cell accounts for it
             ++owned_alive;
         }
-        return die_feed_fix(cost, consumed);
+        return gained;
     }
     if (a.has_dead) a.stash[n] = consumed;
-    return 0;
+    return 0.f;
 }
 
 template <typename T>
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) void k_move_claim(StepArgs a) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; n < a.N; n += stride) {
         const uint32_t sid = a.slot ? a.slot[n] : (uint32_t)n;
-        gsum += move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid, cnt);
+        gsum += die_fix(move_claim_one<T>(a, n, a.x[n], a.y[n], a.dx[n], a.dy[n], a.do_claim ? a.dep[n] : 0.f, sid, cnt));
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
@@ -137,7 +137,7 @@ __device__ __forceinline__ void forward_move_claim_body(FwdArgs& f, StepArgs& a)
         const FwdOut o = die_forward_agent<T, KIND, EXT>(f, X, Y, die_heading_ld(f.heading_hi, f.heading_lo, n), sid, n);
         die_heading_st(f.heading_hi, f.heading_lo, n, o.heading);
         if (f.dx) { f.dx[n] = o.dx; f.dy[n] = o.dy; f.dep[n] = o.dep; }
-        gsum += move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt);
+        gsum += die_fix(move_claim_one<T, EXT>(a, n, X, Y, o.dx, o.dy, o.dep, sid, cnt));
     }
     if (a.do_claim) block_sum_store(gsum, cnt, a.part_gain, a.part_alive);
 }
@@ -208,14 +208,14 @@ __global__ __launch_bounds__(DIE_STEP_BLOCK) void k_resolve(StepArgs a) {
                 die_st(chem, c, die_ld(chem, c) + a.dep[n]);
                 if (!a.food_infinite) {
                     const float f = die_ld(food, c);
-                    die_st(food, c, die_food_after(a.rate_feed, f));
+                    die_st(food, c, f - a.rate_feed * f);
                 }
             }
         } else if (!alive && a.has_dead) {
             const float consumed = die_claim_occupied(a.owner[c], a.epoch) ? a.stash[n] : 0.f;
-            const float cost = action_cost(a, a.dx[n], a.dy[n], a.dep[n]);
-            a.agent_food[n] = die_feed(a.agent_food[n], cost, consumed);
-            if (owned) gsum += die_feed_fix(cost, consumed);
+            const float gained = consumed - action_cost(a, a.dx[n], a.dy[n], a.dep[n]);
+            a.agent_food[n] += gained;
+            if (owned) gsum += die_fix(gained);
         }
         if (a.agents_die && !(a.agent_food[n] > 1e-4f)) {         // where(have_food, 0): every channel
             a.x[n] = 0; a.y[n] = 0; a.alive[n] = 0; a.agent_food[n] = 0.f;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool mine = col + j >= hy && col + j < H - hy;
-                    if (occ[j] && mine) f[j] = die_food_after(a.rate_feed, f[j]);
+                    if (occ[j] && mine) f[j] = f[j] - a.rate_feed * f[j];
                 }
                 Vec4<T>::st(food + off, f);
             }

@@ -140,12 +140,11 @@ struct FwdGlobalMem {
     __device__ __forceinline__ explicit FwdGlobalMem(const FwdArgs& a) : chem((const T*)a.chem), food((const T*)a.food), mask(a.mask), g(a.g) {}
     // the agent sees medium.where(sense_mask, 0) (core/env.py:292-295): a hidden cell reads as 0
     __device__ __forceinline__ float seen(const T* p, const int64_t i) const { return (EXT && mask && !mask[i]) ? 0.f : die_ld(p, i); }
-    template <bool FOOD = true>
     __device__ __forceinline__ FwdTaps taps(int px, int py, int xm, int xp, int ym, int yp, int cx, int cy) const {
         FwdTaps t;
         t.cxm = seen(chem, die_local(g, xm, py)); t.cxp = seen(chem, die_local(g, xp, py));
         t.cym = seen(chem, die_local(g, px, ym)); t.cyp = seen(chem, die_local(g, px, yp));
-        t.f_own = FOOD ? seen(food, die_local(g, cx, cy)) : 0.f;
+        t.f_own = seen(food, die_local(g, cx, cy));
         return t;
     }
 };
@@ -162,7 +161,6 @@ struct FwdTileMem {
     // die_plane_coord(gx) == clamp(die_plane_coord(cx) + (gx − cx), 0, W − 1) for every tap within the staged margin — provided
     // the world is larger than the planes by more than twice that margin, or the planes span it (checked on the host,
     // die_pic_forward_env_step).  Ten mappings per agent were 8 % of the agent kernel's instructions.
-    template <bool FOOD = true>
     __device__ __forceinline__ FwdTaps taps(int px, int py, int xm, int xp, int ym, int yp, int cx, int cy) const {
         FwdTaps t;
         if (TILED) {
@@ -172,13 +170,13 @@ struct FwdTileMem {
             const int rp = lx(px) * pitch, cp = ly(py);
             t.cxm = die_ld(chem, (int64_t)(lx(xm) * pitch + cp)); t.cxp = die_ld(chem, (int64_t)(lx(xp) * pitch + cp));
             t.cym = die_ld(chem, (int64_t)(rp + ly(ym))); t.cyp = die_ld(chem, (int64_t)(rp + ly(yp)));
-            t.f_own = FOOD ? die_ld(food, (int64_t)((cx + hx - fx0) * fpitch + (cy + hy - fy0))) : 0.f;
+            t.f_own = die_ld(food, (int64_t)((cx + hx - fx0) * fpitch + (cy + hy - fy0)));
         } else {
             // one multiply for the probe cell, the four taps by their distance from it (0 where the world ends)
             const int c = (px - cx0) * pitch + (py - cy0);
             t.cxm = die_ld(chem, (int64_t)(c - (px - xm) * pitch)); t.cxp = die_ld(chem, (int64_t)(c + (xp - px) * pitch));
             t.cym = die_ld(chem, (int64_t)(c - (py - ym))); t.cyp = die_ld(chem, (int64_t)(c + (yp - py)));
-            t.f_own = FOOD ? die_ld(food, (int64_t)((cx - fx0) * fpitch + (cy - fy0))) : 0.f;
+            t.f_own = die_ld(food, (int64_t)((cx - fx0) * fpitch + (cy - fy0)));
         }
         return t;
     }
@@ -206,11 +204,9 @@ __device__ __forceinline__ void die_normalize2(float gx, float gy, float* ux, fl
 // evaluation per agent — the same bits (die_rng.h).
 // PGSTORE = false: _prev_grad is read at index n but NOT updated in place — the caller stores FwdOut.ux / uy where the agent
 // goes (the tile-binned step: the agent's index changes with the step).
-// FOWN: the food under the agent (gradient.py:114-116) is the caller's `f_own` — the tile-binned step's food stream — and no
-// food plane is read here.
-template <typename T, int KIND, bool EXT, class MEM, bool TB = false, bool PGSTORE = true, bool FOWN = false>
+template <typename T, int KIND, bool EXT, class MEM, bool TB = false, bool PGSTORE = true>
 __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const MEM& mem, const uint32_t X, const uint32_t Y, const double d64,
-                                                       const uint32_t sid, const int64_t n, const float f_own = 0.f) {
+                                                       const uint32_t sid, const int64_t n) {
     const float d = (float)d64;             // trigonometry in fp32 (1e-7 of a cell on the probe), decisions in float64
     const die_geo g = a.g;
     const int W = g.gW, H = g.gH;           // world size: probes clamp at the world's edge
@@ -229,8 +225,7 @@ __device__ __forceinline__ FwdOut die_forward_agent_mem(const FwdArgs& a, const 
     const int ym = py > 0 ? py - 1 : 0, yp = py < H - 1 ? py + 1 : H - 1;
     const int cx = die_cell_u(X, W), cy = die_cell_u(Y, H);
     // the taps, and the food under the agent (gradient.py:114-116)
-    FwdTaps t = mem.template taps<!FOWN>(px, py, xm, xp, ym, yp, cx, cy);
-    if (FOWN) t.f_own = f_own;
+    const FwdTaps t = mem.taps(px, py, xm, xp, ym, yp, cx, cy);
     const float gx = (t.cxp - t.cxm) * ((xp - xm) == 2 ? 0.5f : 1.0f);
     const float gy = (t.cyp - t.cym) * ((yp - ym) == 2 ? 0.5f : 1.0f);
     float nx, ny, norm;

@@ -142,8 +142,7 @@ struct PicLayout {
     uint32_t* slot;
     uint32_t *hhi, *hlo;            // heading, float64 halves
     uint32_t *off, *n, *s, *inc;    // per tile
-    float* fpre;                    // food stream (two-launch form, single-tile worlds): the food under the agent BEFORE the consumption
-};                                  // of the step that wrote this layout — see "Food stream" below
+};
 
 struct PicArgs {
     die_geo g;
@@ -157,8 +156,6 @@ struct PicArgs {
     const void* food;
     float rate_feed, w_dep, w_dist;
     int boundary, cost;
-    int fs_fresh, food_infinite;    // food stream: in.fpre holds the food under the agent as it is NOW and agent_food is complete (after
-                                    // die_pic_bin / die_pic_settle); Dynamics.food_infinite
     long long* part_gain;           // one fixed-point partial per tile
     uint32_t* error;                // device word, sticky: bit 0 segment bookkeeping broken, bit 1 an agent jumped further than a
                                     // tile, bit 2 a rim record left the 3×3 neighbourhood
@@ -407,22 +404,17 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #define PIC_TB true             // the agent kernel reads a PhysarumAgent's random turn bit from the step's table (false: one Philox block per agent whose turn is random)
 #endif
 #define PIC_AT(base, type, idx) (*(type*)((char*)(base) + (size_t)(uint32_t)((uint32_t)(idx) << 2)))
-// Food stream (FS = two-launch form on a single-tile world).  The forward needs the food under the agent (deposit =
-// deposit·food·mask, gradient.py:114-117), feeding the food under its NEW cell before this step's consumption (core/env.py:224-225).
-// Reading both from the plane made this kernel stage the whole food tile — 67 MB per step at 4096² for two 4-byte values per agent,
-// and 18 KB of LDS per workgroup.  Instead the value travels with the agent: layout.fpre[j] = the food under agent j BEFORE the
-// consumption of the step that wrote the layout — written by the field kernel for the agents that stay on its tile (it holds the
-// tile's food anyway), by this kernel for the ≈ 13 % that walk onto another tile (one gather from the plane, which the field kernel
-// of this step has not touched yet).  The next step's agent kernel completes the feeding — agent_food ← (agent_food − cost) + rate·fpre
-// (die_feed: the association every implementation uses) — and takes fpre − rate·fpre, the cell's food after that consumption, as the
-// food under the agent: no food plane here.  The reward's two halves meet in the field kernel (Σ fix(consumed) of its stayers added
-// to this kernel's per-tile partial: integers).  Between steps agent_food lacks the last consumption; die_pic_settle adds it when
-// somebody reads the array (fs_fresh then tells the next step that fpre already holds the food under the agent as it is NOW).
 // (Two persistent forms of this kernel — a tile queue with the next tile's agents prefetched, and one 16-wave workgroup per CU with
 // LDS-DMA loader waves — were built, bit-equal, and measured slower in round 4 (96 / 101 µs against 75–81): DESIGN.md §3.1,
 // scratch/refuted_r04/.)
 template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool MOM = false>
-__global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(FwdArgs f, PicArgs p) {
+// (waves per SIMD the compiler must leave room for: with fp16 planes the staged windows are 25 KB per workgroup, FOUR workgroups fit a
+// CU's LDS and the registers have to fit 8 waves per SIMD too — 78 scalar registers + 29 spilled instead of 106 + 17; with fp32
+// planes, 49 KB, only three fit whatever the registers)
+#ifndef PIC_K1_MINW_F16
+#define PIC_K1_MINW_F16 8
+#endif
+__global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : PIC_K1_MINW)) void k_pic_forward_move(FwdArgs f, PicArgs p) {
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
     // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)
@@ -445,9 +437,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
 #else
 #define PIC_KP(field, type) (p.field)
 #endif
-    constexpr bool FS = RIM && !TILED;                             // food stream: no food plane in this kernel (above)
-    constexpr bool SFOOD = STAGE && !FS;                           // the food block is staged
-    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then (SFOOD) food of the tile ± its margin
+    extern __shared__ __align__(16) unsigned char pic_smem[];     // STAGE: chem of the tile ± margin, then food of the tile ± its margin
     __shared__ uint32_t s_base[9], s_pre[10];                     // ranges of the current tile
     __shared__ unsigned long long s_cnt;                           // stayers | leavers << 21 | rim entries << 42: one LDS atomic per wave and chunk
     __shared__ uint32_t s_next, s_nlist;
@@ -477,7 +467,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     // this wave's first chunk of stayers
     uint32_t cj = 0, cX = 0, cY = 0, pX = 0, pY = 0, pS = 0, pHh = 0, pHl = 0;
     float pA = 0.f;
-    [[maybe_unused]] float pF = 0.f;
     bool chas = false;
     auto prefetch_agents = [&]() {
         const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
@@ -499,7 +488,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             pX = PIC_LDN(p.in.x, const uint32_t, j); pY = PIC_LDN(p.in.y, const uint32_t, j); pS = PIC_LDN(p.in.slot, const uint32_t, j);
             pHh = PIC_LDN(p.in.hhi, const uint32_t, j); pHl = PIC_LDN(p.in.hlo, const uint32_t, j);
             pA = PIC_LDN(p.in.agent_food, const float, j);
-            if (FS) pF = PIC_LDN(p.in.fpre, const float, j);
         }
     };
     const int x0 = tx << p.xs, y0 = ty << p.ys;
@@ -511,10 +499,11 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     // the tiles to stage depend on nothing but the tile index: their loads go out next and overlap both round trips
     const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, (int)blockDim.x / (pitch / SV)};
     const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, (int)blockDim.x / (fpitch / SV)};
-    uint4 sc[4];                          // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
-    [[maybe_unused]] uint4 sf[3];
-    if (STAGE) st_c.issue(sc);
-    if (SFOOD) st_f.issue(sf);
+    uint4 sc[4], sf[3];                   // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
+    if (STAGE) {
+        st_c.issue(sc);
+        st_f.issue(sf);
+    }
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
     pic_ranges_finish(mt, s_base, s_pre);
     prefetch_agents();
@@ -526,11 +515,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
     T* s_food = nullptr;
     if (STAGE) {
         T* s_chem = (T*)pic_smem;
+        s_food = s_chem + rows * pitch;
         st_c.commit(s_chem, sc);
-        if (SFOOD) {
-            s_food = s_chem + rows * pitch;
-            st_f.commit(s_food, sf);
-        }
+        st_f.commit(s_food, sf);
         tm.food = s_food; tm.fx0 = x0 - FR; tm.fy0 = y0 - FC; tm.fpitch = fpitch;
         tm.chem = s_chem; tm.cx0 = x0 - P; tm.cy0 = y0 - P; tm.pitch = pitch;
     }
@@ -584,16 +571,14 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
             bool stay = false;
             uint32_t X = 0, Y = 0, sid = 0, hh = 0, hl = 0;
             float af = 0.f, dep = 0.f;
-            [[maybe_unused]] float pux = 0.f, puy = 0.f, fnew = 0.f;
+            [[maybe_unused]] float pux = 0.f, puy = 0.f;
             double hd = 0.0;
             uint32_t code = 0;
             bool listed = false;
             if (act) {
                 const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
-                [[maybe_unused]] float fp = 0.f;
                 if (first && idx < n_own) {                      // (this wave's prefetched chunk: idx = wave·64 + lane < own)
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
-                    if (FS) fp = pF;
                 } else {
                     // (the pointers first — their scalar loads go out together —, then all six streams in flight together)
                     const uint32_t *ix_ = PIC_KP(in.x, const uint32_t*), *iy_ = PIC_KP(in.y, const uint32_t*), *is_ = PIC_KP(in.slot, const uint32_t*);
@@ -602,21 +587,10 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     X = PIC_LDN(ix_, const uint32_t, j); Y = PIC_LDN(iy_, const uint32_t, j); sid = PIC_LDN(is_, const uint32_t, j);
                     hh = PIC_LDN(ihh_, const uint32_t, j); hl = PIC_LDN(ihl_, const uint32_t, j);
                     af = PIC_LDN(ia_, const float, j);
-                    if (FS) fp = PIC_LDN(PIC_KP(in.fpre, const float*), const float, j);
                 }
                 hd = __hiloint2double((int)hh, (int)hl);
-                // FS: the previous step's consumption completes agent_food, and what that consumption left on the cell is the food
-                // under the agent (fs_fresh: both done already — a layout fresh from die_pic_bin / die_pic_settle)
-                float f_own = 0.f;
-                if (FS) {
-                    const bool fresh = p.fs_fresh != 0;
-                    const float done = __fadd_rn(af, die_consumed(p.rate_feed, fp));
-                    const float left = p.food_infinite ? fp : die_as_stored<T>(die_food_after(p.rate_feed, fp));
-                    af = fresh ? af : done;
-                    f_own = fresh ? fp : left;
-                }
-                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, PIC_TB, false, FS>(f, tm, X, Y, hd, sid, (int64_t)j, f_own)
-                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, PIC_TB, false, FS>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j, f_own);
+                const FwdOut o = STAGE ? die_forward_agent_mem<T, KIND, false, FwdTileMem<T, TILED>, PIC_TB, false>(f, tm, X, Y, hd, sid, (int64_t)j)
+                                       : die_forward_agent_mem<T, KIND, false, FwdGlobalMem<T, false>, PIC_TB, false>(f, FwdGlobalMem<T, false>(f), X, Y, hd, sid, (int64_t)j);
                 if (MOM) { pux = o.ux; puy = o.uy; }
                 if (ACT && p.adx) { PIC_AT(p.adx, float, j) = o.dx; PIC_AT(p.ady, float, j) = o.dy; PIC_AT(p.adep, float, j) = o.dep; }   // ACT = false: the caller passed no action arrays
                 // _agent_move (core/env.py:163-172)
@@ -634,38 +608,30 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                 const int cy = TILED ? die_plane_coord(gcy, p.g.oy, p.g.H, p.g.gH) : gcy;
                 const int ntx_ = cx >> p.xs, nty_ = cy >> p.ys;
                 stay = ntx_ == tx && nty_ == ty;
-                // _agent_feed for this (alive) agent (core/env.py:220-243)
-                const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
-                if (FS) {
-                    // the cost now; the consumption when the food under the new cell is known: the field kernel writes fpre for the
-                    // agents that stay on this tile, the others read their cell here — from the plane, which still holds the food
-                    // BEFORE this step's consumption — and count their consumption into this tile's partial
-                    af = __fsub_rn(af, cost);
-                    gsum -= die_fix(cost);
-                    if (!stay) fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
+                // _agent_feed for this (alive) agent (core/env.py:220-243): the food under it BEFORE this step's consumption —
+                // from the staged food block, whose margin holds every cell an agent of the tile can reach in one step (a flat
+                // load from "LDS or global memory" here made every wave drain its outstanding stores before each chunk)
+                float fnew;
+                if (STAGE) {
+                    int rx = cx - x0, ry = cy - y0;                                    // relative to the tile, periodic
+                    rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
+                    ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
+                    rx = min(max(rx + FR, 0), frows - 1);                              // (a longer jump is an error, flagged below: never out of the block)
+                    // the block has a margin of ROWS only by default (fm_c = 0): a row of the plane starts on a 256-byte boundary of
+                    // the tile, so whole rows cost no partial cache lines, while ± 4 columns made every row touch two more 128-byte
+                    // lines (70 rows × 4 lines instead of 64 × 2: + 65 MB of fetches per step at 4096²).  The few agents that leave
+                    // the tile's columns (≈ 1 % per step at the benchmark's step length) read their cell from global memory
+                    if (ry >= -FC && ry < TY + FC) fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry + FC));
+                    else fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
                 } else {
-                    // the food under it BEFORE this step's consumption — from the staged food block, whose margin holds every cell
-                    // an agent of the tile can reach in one step (a flat load from "LDS or global memory" here made every wave
-                    // drain its outstanding stores before each chunk)
-                    if (SFOOD) {
-                        int rx = cx - x0, ry = cy - y0;                                    // relative to the tile, periodic
-                        rx += rx < -FR ? p.g.W : 0; rx -= rx >= TX + FR ? p.g.W : 0;
-                        ry += ry < -FC ? p.g.H : 0; ry -= ry >= TY + FC ? p.g.H : 0;
-                        rx = min(max(rx + FR, 0), frows - 1);                              // (a longer jump is an error, flagged below: never out of the block)
-                        // the block has a margin of ROWS only by default (fm_c = 0): a row of the plane starts on a 256-byte boundary of
-                        // the tile, so whole rows cost no partial cache lines, while ± 4 columns made every row touch two more 128-byte
-                        // lines (70 rows × 4 lines instead of 64 × 2: + 65 MB of fetches per step at 4096²).  The few agents that leave
-                        // the tile's columns (≈ 1 % per step at the benchmark's step length) read their cell from global memory
-                        if (ry >= -FC && ry < TY + FC) fnew = die_ld(s_food, (int64_t)(rx * fpitch + ry + FC));
-                        else fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
-                    } else {
-                        fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
-                    }
-                    const float consumed = die_consumed(p.rate_feed, fnew);
-                    af = die_feed(af, cost, consumed);
-                    // (a ghost is its owner's to count; die_owned on the plane element: a cell beyond the planes maps to an edge element, never owned)
-                    if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_feed_fix(cost, consumed); ++nowned; }
+                    fnew = die_ld(food, (int64_t)cx * p.g.H + cy);
                 }
+                const float consumed = p.rate_feed * fnew;
+                const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
+                const float gained = consumed - cost;
+                af += gained;
+                // (a ghost is its owner's to count; die_owned on the plane element: a cell beyond the planes maps to an edge element, never owned)
+                if (!TILED || p.g.own_x1 == 0 || (cx >= p.g.own_x0 && cx < p.g.own_x1 && cy >= p.g.own_y0 && cy < p.g.own_y1)) { gsum += die_fix(gained); ++nowned; }
                 hd = o.heading;
                 dep = o.dep;
                 int ddx = 0, ddy = 0;
@@ -721,8 +687,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, PIC_K1_MINW) void k_pic_forward_move(
                     PIC_ST(1, ohl_, uint32_t, q, (uint32_t)__double2loint(hd));
                     PIC_ST(0, od_, float, q, dep);
                     if (MOM && p.opgx) { PIC_AT(p.opgx, float, q) = pux; PIC_AT(p.opgy, float, q) = puy; }
-                    // FS: a leaver's food stream entry and its consumption (the gather was issued before the position atomics)
-                    if (FS && !stay) { PIC_AT(PIC_KP(out.fpre, float*), float, q) = fnew; gsum += die_fix(die_consumed(p.rate_feed, fnew)); }
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
@@ -817,10 +781,11 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_dead(FwdArgs f, PicArgs p, ui
         const uint32_t c = (uint32_t)cx * (uint32_t)p.g.H + (uint32_t)cy;
         // _agent_feed (core/env.py:224-233): a dead slot "consumes" iff somebody alive stands on its cell
         const bool occupied = occ[c] != 0;
-        const float consumed = occupied ? die_consumed(p.rate_feed, die_ld(food, (int64_t)c)) : 0.f;
+        const float consumed = occupied ? p.rate_feed * die_ld(food, (int64_t)c) : 0.f;
         const float cost = p.cost == DIE_COST_LINEAR ? p.w_dep * fabsf(o.dep) + p.w_dist * die_sqrt1(o.dx * o.dx + o.dy * o.dy) : 0.f;
-        gsum += die_feed_fix(cost, consumed);
-        p.out.x[j] = X; p.out.y[j] = Y; p.out.agent_food[j] = die_feed(p.in.agent_food[j], cost, consumed); p.out.slot[j] = sid;
+        const float gained = consumed - cost;
+        gsum += die_fix(gained);
+        p.out.x[j] = X; p.out.y[j] = Y; p.out.agent_food[j] = p.in.agent_food[j] + gained; p.out.slot[j] = sid;
         p.out.hhi[j] = (uint32_t)__double2hiint(o.heading); p.out.hlo[j] = (uint32_t)__double2loint(o.heading);
         p.dep[j] = o.dep;
     }
@@ -944,7 +909,7 @@ __global__ __launch_bounds__(PIC_K2_BLOCK) void k_pic_resolve(PicArgs p, float* 
         *(uint4*)(dep_plane + off) = make_uint4(o[0], o[1], o[2], o[3]);
         if (FEED && (c[0] | c[1] | c[2] | c[3])) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (c[q]) fd[g][q] = die_food_after(p.rate_feed, fd[g][q]);
+            for (int q = 0; q < 4; ++q) if (c[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
             Vec4<T>::st((T*)p.food + off, fd[g]);
         }
     }
@@ -987,27 +952,7 @@ struct KbArgs {
     int64_t turn_words;
     uint64_t turn_seed;
     uint32_t turn_step;
-    // food stream (single-tile worlds): the step's reward = the agent kernel's per-tile partials (costs, leavers' consumption) + the
-    // consumption of every tile's stayers, known to that tile's workgroup here.  Every workgroup adds its share to *acc and draws a
-    // ticket from *done; the one that draws the last of `tickets` writes the result and leaves both words 0 for the next step.
-    unsigned long long* acc;
-    uint32_t* done;
-    uint32_t tickets;
 };
-
-// One workgroup's share of the step's reward (thread-level: ONE thread calls this).  Integers: any order.
-__device__ __forceinline__ void kb_contribute(const KbArgs& a, long long share) {
-    atomicAdd(a.acc, (unsigned long long)share);
-    __threadfence();                                            // the share is in before the ticket is drawn
-    const uint32_t t = atomicAdd(a.done, 1u);
-    if (t + 1u != a.tickets) return;
-    __threadfence();
-    const long long total = (long long)atomicAdd(a.acc, 0ull);  // every other workgroup's share went in before its ticket
-    a.result->reward = (double)total / DIE_FIX_ONE; a.result->num_alive = a.alive_const;
-    if (a.status_out) *a.status_out = (long long)*a.error;      // (set by the agent kernel: a kernel boundary lies in between)
-    atomicExch(a.acc, 0ull);
-    atomicExch(a.done, 0u);
-}
 
 template <int XS, int YS> struct KbShape {
     static constexpr int BLOCK = ((1 << XS) * (1 << YS) >= 4096) ? 512 : 256;
@@ -1026,9 +971,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     constexpr int WR = TX + 2 * R, WC = TY + 2 * R;        // the window
     constexpr int CP = TY + 2 * A, NV = CP / A;            // staged columns [y0 − A, y0 + TY + A): whole vectors; vectors per row
     static_assert(R >= 1 && R <= 4 && R <= A, "the rim lies inside one vector beside the tile");
-    constexpr bool FS = !TILED;                             // food stream (see k_pic_forward_move): this kernel writes fpre of its stayers
     extern __shared__ __align__(16) unsigned char kb_smem[];
-    __shared__ long long s_kg[FS ? BLOCK / DIE_WAVE : 1];   // FS: the waves' sums of their stayers' consumption
     float* s_chem = (float*)kb_smem;                        // WR × CP, window cell (r, c) at r·CP + c − R + A
     uint32_t* s_claim = (uint32_t*)(s_chem + WR * CP);      // WR × WC; after the deposits: s_tmp, TX × CP (the x pass)
     float* s_tmp = (float*)s_claim;
@@ -1095,12 +1038,8 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                if (FS) {
-                    kb_contribute(a, s_g[0]);
-                } else {
-                    a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
-                    if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
-                }
+                a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
+                if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
             }
         } else if (blockIdx.x >= 2 && a.turn_bits) {        // the rest of the row: the next step's turn bits (this step's agent kernel is done with the table)
             pic_turn_bits_fill(a.turn_bits, a.turn_words, a.turn_seed, a.turn_step, (int64_t)(blockIdx.x - 2) * BLOCK + threadIdx.x,
@@ -1188,9 +1127,6 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     if constexpr (NCV > 2) window_commit(2, cv2);
     const uint32_t own0 = s_own[0], nown = s_own[1];
     // window cell of an agent standing on the tile at (ux, uy) tiles from d; 0xFFFFFFFF: outside the window
-    [[maybe_unused]] long long kgain = 0;
-    // FS, a stayer: its cell of the food plane (it stands on this tile: the element is this workgroup's to read and to feed)
-    auto food_at = [&](uint32_t X, uint32_t Y) { return (int64_t)pic_row<TILED>(p.g, X) * H + pic_col<TILED>(p.g, Y); };
     auto window_cell = [&](uint32_t X, uint32_t Y, int ux, int uy) {
         const int cx = pic_row<TILED>(p.g, X), cy = pic_col<TILED>(p.g, Y);
         const int r = ux * TX + (cx & (TX - 1)) + R, c = uy * TY + (cy & (TY - 1)) + R;
@@ -1232,7 +1168,6 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     constexpr int FG = (TX * TY / 4 + BLOCK - 1) / BLOCK;
     float fd[FG][4];
     uint32_t cw[2 + NE], cs[2 + NE], cd[2 + NE];
-    [[maybe_unused]] float fpv[2] = {0.f, 0.f};             // FS: the food under this thread's two stayers, before this step's consumption
     {
         uint32_t X[2 + NE], Y[2 + NE], uc[NE];
         const uint32_t rj[NE] = {rim_decode(0, uc[0]), rim_decode(1, uc[1]), rim_decode(2, uc[2]), rim_decode(3, uc[3])};
@@ -1258,12 +1193,6 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 if (i < TX * TY) { const int row = i / TY, col = i - row * TY; Vec4<T>::template ld<4>(food + (int64_t)(x0 + row) * H + y0 + col, fd[q]); }
             }
         }
-        // FS: the food under the stayers — one 4-byte gather each, behind the tile's own 16-byte loads of the same lines, ahead of the
-        // barrier that separates every read of the tile's food from its consumption below
-        if (FS) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u) if (cw[u] != 0xFFFFFFFFu) fpv[u] = die_ld((const T*)food, food_at(X[u], Y[u]));
-        }
 #pragma unroll
         for (int u = 0; u < 2 + NE; ++u) {
             if (cw[u] == 0xFFFFFFFFu) continue;
@@ -1272,13 +1201,8 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         }
     }
     for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
-        const uint32_t j = own0 + i, X_ = p.out.x[j], Y_ = p.out.y[j], w_ = window_cell(X_, Y_, 0, 0);
+        const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
         if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_ & 0xFFFFu], p.out.slot[j] + 1u);
-        if (FS) {                                           // (a crowd's stayers beyond the first two per thread)
-            const float fv = die_ld((const T*)food, food_at(X_, Y_));
-            p.out.fpre[j] = fv;
-            kgain += die_fix(die_consumed(p.rate_feed, fv));
-        }
     }
     if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, false);
     PIC_STAMP(10);
@@ -1293,18 +1217,6 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     };
 #pragma unroll
     for (int u = 0; u < 2 + NE; ++u) deposit(cw[u], cs[u], cd[u]);
-    if (FS) {
-        // the stayers' food stream entries and their consumption (core/env.py:224-225: every slot on a cell gets the cell's rate·food)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (threadIdx.x + u * BLOCK < nown) {
-                p.out.fpre[own0 + threadIdx.x + u * BLOCK] = fpv[u];
-                kgain += die_fix(die_consumed(p.rate_feed, fpv[u]));
-            }
-        }
-        kgain = die_wave_sum(kgain);
-        if ((threadIdx.x & (DIE_WAVE - 1)) == 0) s_kg[threadIdx.x / DIE_WAVE] = kgain;
-    }
     for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
         const uint32_t j = own0 + i;
         deposit(window_cell(p.out.x[j], p.out.y[j], 0, 0), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
@@ -1320,7 +1232,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             const bool occ[4] = {c[0] != 0u, c[1] != 0u, c[2] != 0u, c[3] != 0u};
             if (occ[0] || occ[1] || occ[2] || occ[3]) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = die_food_after(p.rate_feed, fd[g][q]);
+                for (int q = 0; q < 4; ++q) if (occ[q]) fd[g][q] = fd[g][q] - p.rate_feed * fd[g][q];
                 Vec4<T>::template st_sel<9>(a.nt_out != 0, food + (int64_t)(x0 + row) * H + y0 + col, fd[g]);
             }
         }
@@ -1328,13 +1240,6 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     __syncthreads();
     PIC_STAMP(12);
     PIC_SETPRIO(PIC_PRIO_KB, 2);
-    // FS: this tile's share of the reward — by the LAST thread: its wave has no item of the x pass below and would only wait at the
-    // next barrier
-    if (FS && a.result && threadIdx.x == BLOCK - 1) {
-        long long t = 0;
-        for (int w = 0; w < BLOCK / DIE_WAVE; ++w) t += s_kg[w];
-        kb_contribute(a, t);
-    }
     // 5. x pass (axis 0): column c of the window, RB output rows per item, the 2R + 1 rows of the stencil in registers
     constexpr int RB = TX >= 64 ? 16 : 8;
     for (int item = threadIdx.x; item < WC * (TX / RB); item += BLOCK) {
@@ -1397,8 +1302,6 @@ struct PicBinArgs {
     uint32_t* dead_cursor;
     const float *pgx, *pgy;         // GradientAgent with inertia: _prev_grad travels along (NULL: none)
     float *opgx, *opgy;
-    const void* food;               // out.fpre != NULL (food stream): the food under every alive agent, from this plane (f16: of halves)
-    int f16;
 };
 
 __global__ __launch_bounds__(DIE_BLOCK) void k_pic_hist(PicBinArgs a, uint32_t* hist) {
@@ -1460,26 +1363,6 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_pic_scatter(PicBinArgs a) {
         a.out.hhi[j] = a.hhi[n];
         a.out.hlo[j] = a.hlo[n];
         if (a.pgx) { a.opgx[j] = a.pgx[n]; a.opgy[j] = a.pgy[n]; }
-        if (a.out.fpre) {           // (single-tile worlds only: the plane cell is the world cell)
-            const int64_t c = (int64_t)die_cell_u(X, a.g.gW) * a.g.H + die_cell_u(Y, a.g.gH);
-            a.out.fpre[j] = !active ? 0.f : (a.f16 ? die_ld((const __half*)a.food, c) : die_ld((const float*)a.food, c));
-        }
-    }
-}
-
-// Food stream housekeeping between steps (die_pic_settle): entries [0, n) of a layout a step wrote.
-//   apply     agent_food += rate·fpre — the consumption of that step, which the NEXT step's agent kernel would have added
-//   regather  fpre ← the food under the agent as the plane holds it now (somebody may have written the plane); else, with `apply`,
-//             fpre ← what that consumption left on the cell (the same value, from arithmetic: no gather, no coordinates)
-template <typename T>
-__global__ __launch_bounds__(DIE_BLOCK) void k_pic_settle(die_geo g, uint32_t n, const uint32_t* x, const uint32_t* y, float* agent_food, float* fpre,
-                                                          const T* food, float rate, int food_infinite, int apply, int regather) {
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
-        const float fp = fpre[j];
-        if (apply) agent_food[j] = __fadd_rn(agent_food[j], die_consumed(rate, fp));
-        if (regather) fpre[j] = die_ld(food, (int64_t)die_cell_u(x[j], g.gW) * g.H + die_cell_u(y[j], g.gH));
-        else if (apply && !food_infinite) fpre[j] = die_as_stored<T>(die_food_after(rate, fp));
     }
 }
 
@@ -1516,8 +1399,6 @@ static int pic_check(const die_medium* m, const die_pic* p, const char* who) {
         DIE_REQUIRE(L.x && L.y && L.agent_food && L.slot && L.heading_hi && L.heading_lo && L.off && L.n && L.s && L.inc, "%s: null pointer in layout %d", who, l);
     }
     DIE_REQUIRE(p->layout[0].x != p->layout[1].x && p->layout[0].off != p->layout[1].off, "%s: the two layouts must be different arrays", who);
-    DIE_REQUIRE(!(p->rim && m->gW <= 0) || (p->layout[0].fpre && p->layout[1].fpre && p->layout[0].fpre != p->layout[1].fpre),
-                "%s: the two-launch form on a single-tile world needs the food stream arrays (die_pic_layout.fpre) of both layouts", who);
     DIE_REQUIRE(p->dep && p->part_gain && p->error && ((p->rim && p->rim_code && p->rim_cnt) || p->dep_plane), "%s: null workspace pointer", who);
     return DIE_OK;
 }
@@ -1526,7 +1407,6 @@ static PicLayout pic_layout(const die_pic_layout& L) {
     PicLayout o;
     o.x = L.x; o.y = L.y; o.agent_food = L.agent_food; o.slot = L.slot; o.hhi = L.heading_hi; o.hlo = L.heading_lo;
     o.off = L.off; o.n = L.n; o.s = L.s; o.inc = L.inc;
-    o.fpre = L.fpre;
     return o;
 }
 
@@ -1587,9 +1467,6 @@ static int pic_bin(const die_medium* m, const die_agents* a, const uint32_t* hea
     b.out = pic_layout(p->layout[into]); b.cursor = cursor;
     b.alive = dead ? a->alive : nullptr; b.n_alive = dead ? (uint32_t)p->n_alive : (uint32_t)p->N; b.dead_cursor = hist + 2 * NT;
     b.pgx = prev_gx; b.pgy = prev_gy; b.opgx = p->prev_grad[into][0]; b.opgy = p->prev_grad[into][1];
-    b.food = m->food; b.f16 = m->dtype != DIE_F32;
-    if (m->gW > 0) b.out.fpre = nullptr;                     // (a decomposed world's tile: no food stream)
-    DIE_REQUIRE(!b.out.fpre || m->food, "die_pic_bin: the food stream needs the food plane");
     DIE_REQUIRE((prev_gx != nullptr) == (prev_gy != nullptr) && (!prev_gx || (b.opgx && b.opgy && b.opgx != prev_gx)),
                 "die_pic_bin: _prev_grad given without die_pic.prev_grad[%d] to carry it into", into);
     int64_t g = (a->N + DIE_BLOCK - 1) / DIE_BLOCK;
@@ -1607,21 +1484,6 @@ extern "C" int die_pic_bin(const die_medium* m, const die_agents* a, const uint3
 extern "C" int die_pic_bin_momentum(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo,
                                     const float* prev_gx, const float* prev_gy, const die_pic* p, int32_t into, void* stream) {
     return pic_bin(m, a, heading_hi, heading_lo, prev_gx, prev_gy, p, into, stream);
-}
-
-extern "C" int die_pic_settle(const die_medium* m, const die_pic* p, int32_t lay, const die_dynamics* d, int32_t apply, int32_t regather, void* stream) {
-    DIE_REQUIRE(m && p && d && (lay == 0 || lay == 1) && m->food && m->gW <= 0, "die_pic_settle: null argument, or a decomposed world's tile (no food stream there)");
-    const die_pic_layout& L = p->layout[lay];
-    const int64_t n = p->n_alive > 0 && p->n_alive < p->N ? p->n_alive : p->N;
-    DIE_REQUIRE(L.fpre && L.agent_food && L.x && L.y && n > 0 && n < ((int64_t)1 << 32), "die_pic_settle: null array in layout %d", lay);
-    if (!apply && !regather) return DIE_OK;
-    const int64_t g = (n + DIE_BLOCK - 1) / DIE_BLOCK;
-    const int grid = (int)(g < 8192 ? g : 8192);
-    hipStream_t s = (hipStream_t)stream;
-    if (m->dtype == DIE_F32) k_pic_settle<float><<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), (uint32_t)n, L.x, L.y, L.agent_food, L.fpre, (const float*)m->food, d->rate_feed, d->food_infinite, apply, regather);
-    else k_pic_settle<__half><<<grid, DIE_BLOCK, 0, s>>>(die_geo_of(m), (uint32_t)n, L.x, L.y, L.agent_food, L.fpre, (const __half*)m->food, d->rate_feed, d->food_infinite, apply, regather);
-    DIE_CHECK_LAUNCH("die_pic_settle");
-    return DIE_OK;
 }
 
 template <int XS, int YS>
@@ -1762,6 +1624,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     DIE_REQUIRE(!stage || (m->W < (1 << 23) && m->H < (1 << 23) && (int64_t)m->W * m->H < (1ll << 31)),
                 "die_pic_forward_env_step: plane too large for the 24-bit index arithmetic of the staging loop");
     DIE_REQUIRE(!stage || m->H % V == 0, "die_pic_forward_env_step: plane rows must be whole 16-byte vectors");
+    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (size_t)(TX + 2 * k.fm_r) * (TY + 2 * k.fm_c)) * esz : 0;
     const int stages = p->stages ? p->stages : 7;          // bit 0: agent kernel, bit 1: resolve + scan, bit 2: field sweep
     // two launches (one field kernel per tile, fed by the agent kernel's rim lists) when the caller gave the lists and every
     // agent that matters to a tile sits in one of the 9 segments around it: an agent changes cell by at most floor(reach) + 1 per axis and must not come within R cells of the
@@ -1770,12 +1633,6 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const bool two = p->rim != nullptr && p->rim_code != nullptr && p->rim_cnt != nullptr &&
                      pic_two_launch_rule(worldmax, p->tile_xs, p->tile_ys, step_scale, d->diffuse_sigma, d->diffuse_mode);
     if (!two) DIE_REQUIRE(p->dep_plane, "die_pic_forward_env_step: this step needs the three-launch form: dep_plane is null");
-    // food stream (two-launch form on a single-tile world; k_pic_forward_move): the agent kernel stages no food block
-    const bool fs = two && !tiled;
-    DIE_REQUIRE(fs ? (p->food_state == DIE_PIC_FOOD_PENDING || p->food_state == DIE_PIC_FOOD_FRESH) : p->food_state != DIE_PIC_FOOD_PENDING,
-                "die_pic_forward_env_step: food_state %d does not fit this step (%s): die_pic_settle first", p->food_state, fs ? "food stream" : "food plane");
-    k.fs_fresh = p->food_state == DIE_PIC_FOOD_FRESH; k.food_infinite = d->food_infinite;
-    const size_t lds = stage ? ((size_t)(TX + 2 * P) * (TY + 2 * P) + (fs ? 0 : (size_t)(TX + 2 * k.fm_r) * (TY + 2 * k.fm_c))) * esz : 0;
     DIE_REQUIRE(two || !p->sub_mode, "die_pic_forward_env_step: subsets of the tiles exist in the two-launch form only");
     DIE_REQUIRE(!(dead && p->sub_mode), "die_pic_forward_env_step: subsets of the tiles and dead slots do not combine");
     if (tiled && !(two && stage)) {
@@ -1862,7 +1719,6 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             for (int q = 0; q <= 2 * R; ++q) a.w[q] = (float)wd[q];
             a.result = result; a.alive_const = dead ? p->n_alive : p->N; a.status_out = (long long*)p->status_out; a.error = p->error;
             a.n_part = NT + (dead ? dead_blocks : 0);
-            a.acc = (unsigned long long*)p->part_gain + 2 * (size_t)NT; a.done = (uint32_t*)(a.acc + 1); a.tickets = (uint32_t)NT + 1u;
             // cache policy of the field kernel's two plane stores.  Measured (profiles/r04_nt_stores_by_size.txt): with the planes and
             // agent arrays beyond the 256 MiB Infinity Cache (4096² fp32: 342 MB, 8192²) non-temporal stores make the step 3.5 % / 2 %
             // faster — the lines would be evicted before the next kernel reads them anyway and only displace the windows' shared

@@ -61,29 +61,6 @@ class DeviceMedium:
         self.epoch = 1
         self.world = None        # (gW, gH, ox, oy) when these planes are one tile of a decomposed world
         self.owner_stale = None  # callable that rebuilds `owner` (the tile-binned step does not maintain the claim plane)
-        self.food_taken = None   # callable: somebody took the food plane and may write it (the tile-binned step's food stream, pic.py)
-
-    @property
-    def food(self) -> torch.Tensor:
-        """The env_food plane.  Taking it tells the tile-binned step that the plane may change under it (its agents carry the food
-        under them from step to step instead of reading the plane: die_amd/pic.py); a caller that KEEPS the tensor and writes it
-        later calls `touch_food()` after writing."""
-        taken = self.__dict__.get('food_taken')
-        if taken is not None:
-            taken()
-        return self._food
-
-    @food.setter
-    def food(self, t: torch.Tensor):
-        taken = self.__dict__.get('food_taken')
-        if taken is not None:
-            taken()
-        self._food = t
-
-    def touch_food(self):
-        """The food plane was written through a retained tensor."""
-        if self.food_taken is not None:
-            self.food_taken()
 
     @property
     def shape(self):
@@ -99,7 +76,7 @@ class DeviceMedium:
         if need_owner:
             self._ensure_owner()
         return _lib.Medium(self.W, self.H, _lib.DIE_F32 if self.dtype == torch.float32 else _lib.DIE_F16, self.epoch,
-                           _ptr(self.owner), _ptr(self._food), _ptr(self.chem), _ptr(self.chem_next),
+                           _ptr(self.owner), _ptr(self.food), _ptr(self.chem), _ptr(self.chem_next),
                            *(self.world or (0, 0, 0, 0)), *(getattr(self, 'own', None) or (0, 0, 0, 0)),
                            _ptr(self.sense_mask) if getattr(self, 'sense_mask', None) is not None else None)
 
@@ -184,23 +161,9 @@ class DeviceAgents:
         self.y = torch.zeros(N, dtype=torch.int32, device=device)
         self.alive = torch.zeros(N, dtype=torch.uint8, device=device)
         self.agent_food = torch.zeros(N, dtype=torch.float32, device=device)
-        self.food_pending = None     # callable: completes agent_food (the tile-binned step's food stream adds a step's consumption late)
         self.slot: Optional[torch.Tensor] = None
         self.global_slots = False    # decomposed world: `slot` holds world slot ids, N <= capacity of the arrays
         self._attached = []          # weak references to objects holding per-slot state (Agent objects)
-
-    @property
-    def agent_food(self) -> torch.Tensor:
-        """The agent_food channel.  After a tile-binned step the array lacks that step's consumption until the next step's agent
-        kernel — or this access — adds it (die_pic_settle; die_amd/pic.py)."""
-        pending = self.__dict__.get('food_pending')
-        if pending is not None:
-            pending()
-        return self._agent_food
-
-    @agent_food.setter
-    def agent_food(self, t: torch.Tensor):
-        self._agent_food = t
 
     @property
     def shape(self):

@@ -682,7 +682,8 @@ class Env(_EnvBase):
     def _agents_changed(self):
         """The agent arrays were modified in place by something other than the tile-binned step: its tile order is void."""
         if self._pic is not None:
-            self._pic.release(self)
+            self._pic.flush_lazy()
+            self._pic.held = None
 
     def _stage(self, fn_name, action):
         self._agents_changed()

@@ -79,19 +79,10 @@ class PicState:
         # the dead slots behind them (include/die_hip.h `die_pic.n_alive`); `occ`: this step's occupancy map (a byte per cell) for their feeding
         self.n_alive = int(getattr(env, '_pic_n_alive', 0) or 0)
         self.occ = torch.zeros(W * H, dtype=torch.uint8, device=dev) if 0 < self.n_alive < N else None
-        self.part = torch.zeros(2 * self.NT + 2, dtype=torch.int64, device=dev)   # reward partials | owned agents (decomposed tiles) | food stream: accumulator, tickets
+        self.part = torch.zeros(2 * self.NT, dtype=torch.int64, device=dev)       # reward partials | owned agents (decomposed tiles)
         self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
         self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
-        # food stream (include/die_hip.h `die_pic.food_state`; two-launch form, single-tile worlds): the food under every agent travels
-        # with it — one array per layout, index 7 of the tensor tuples below — and a step's consumption reaches agent_food one agent
-        # kernel later, or when somebody takes env.agents.agent_food (`settle`)
-        self.fs = self.fused and env.medium.world is None
-        self.fpre = torch.empty(N, dtype=torch.float32, device=dev) if self.fs else None          # of layout[cur] (valid per food_state)
-        self.spare_fpre = torch.empty(N, dtype=torch.float32, device=dev) if self.fs else None
-        self.food_state = _lib.PIC_FOOD_NONE
-        self.food_touched = False    # somebody took env.medium.food since the stream was last read from the plane
-        self._env_ref = weakref.ref(env)
         self.spare_pg = None         # GradientAgent with inertia: the (2, N) _prev_grad array of the layout that is not current (die_pic.prev_grad)
         self.k1_threads = int(os.environ.get('DIE_PIC_THREADS', '0'))   # die_pic.k1_threads: 0 = library default, > 0: workgroup size of the agent kernel
         self.cur = 0                 # layout index that holds the agents
@@ -107,8 +98,7 @@ class PicState:
     # ------------------------------------------------------------------
     def _layout(self, tensors, meta) -> _lib.PicLayout:
         x, y, af, slot, hh, hl = tensors[:6]
-        return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hh), _ptr(hl), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]),
-                              _ptr(tensors[7]) if len(tensors) > 7 else None)
+        return _lib.PicLayout(_ptr(x), _ptr(y), _ptr(af), _ptr(slot), _ptr(hh), _ptr(hl), _ptr(meta[0]), _ptr(meta[1]), _ptr(meta[2]), _ptr(meta[3]))
 
     def _struct(self, cur_tensors, other_tensors, stages: int = 0, status_out=None) -> _lib.Pic:
         """The die_pic of a call: layout[cur] = `cur_tensors`, layout[1 - cur] = `other_tensors`.  The arrays ping-pong between
@@ -120,8 +110,7 @@ class PicState:
         key = (cur, ct[0].data_ptr(), ct[1].data_ptr(), ct[2].data_ptr(), ct[4].data_ptr(), ct[5].data_ptr(),
                ot[0].data_ptr(), ot[1].data_ptr(), ot[2].data_ptr(), ot[4].data_ptr(), ot[5].data_ptr(),
                0 if self._dep_plane is None else self._dep_plane.data_ptr(),
-               0 if ct[6] is None else ct[6].data_ptr(), 0 if ot[6] is None else ot[6].data_ptr(),
-               0 if ct[7] is None else ct[7].data_ptr(), 0 if ot[7] is None else ot[7].data_ptr())
+               0 if ct[6] is None else ct[6].data_ptr(), 0 if ot[6] is None else ot[6].data_ptr())
         p = self._structs.get(key)
         if p is None:
             if len(self._structs) >= 8:
@@ -139,7 +128,6 @@ class PicState:
         L = p.layout
         L[cur].slot, L[1 - cur].slot = ct[3].data_ptr(), ot[3].data_ptr()
         p.N, p.k1_threads, p.stages, p.status_out = self._n_agents, self.k1_threads, stages, status_out
-        p.food_state = self.food_state
         return p
 
     def two_launch(self, env, agent) -> bool:
@@ -161,17 +149,15 @@ class PicState:
 
     def is_current(self, env, agent) -> bool:
         A, h = env.agents, self.held
-        return h is not None and self.agent is agent and A.x is h[0] and A.y is h[1] and A._agent_food is h[2] and A.slot is h[3] and \
+        return h is not None and self.agent is agent and A.x is h[0] and A.y is h[1] and A.agent_food is h[2] and A.slot is h[3] and \
             agent._hd_hi is h[4] and agent._hd_lo is h[5] and agent._order is A.slot and getattr(agent, '_prev_grad', None) is h[6]
 
     def _adopt(self, env, agent, new):
         """The agents now live in `new` = (x, y, agent_food, slot, heading hi, lo): hand the arrays to their owners and keep the
         old ones as the next step's output buffers (the slot array is never reused: actions may still refer to it)."""
         A = env.agents
-        self.spare = [A.x, A.y, A._agent_food, agent._hd_hi, agent._hd_lo]
+        self.spare = [A.x, A.y, A.agent_food, agent._hd_hi, agent._hd_lo]
         A.x, A.y, A.agent_food, A.slot = new[0], new[1], new[2], new[3]
-        if self.fs:
-            self.spare_fpre, self.fpre = self.fpre, new[7]
         agent._hd_hi, agent._hd_lo = new[4], new[5]
         if new[6] is not None:
             self.spare_pg, agent._prev_grad = agent._prev_grad, new[6]
@@ -185,7 +171,7 @@ class PicState:
             if self.spare_pg is None or self.spare_pg.shape != (2, self.cap):
                 self.spare_pg = torch.empty((2, self.cap), dtype=torch.float32, device=env.device)
             pg = self.spare_pg
-        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4], pg, self.spare_fpre)
+        return (self.spare[0], self.spare[1], self.spare[2], slot, self.spare[3], self.spare[4], pg)
 
     def bin(self, env, agent):
         """Agents in any order → layout[1 - cur]; both layouts' per-tile words are reset.  (The sticky error word is read first
@@ -194,8 +180,6 @@ class PicState:
         if self.steps_since_check:
             self.check()
         A = env.agents
-        _ = A.agent_food                         # (a pending consumption of the layout that is being left: into agent_food first)
-        self._food_state(env, _lib.PIC_FOOD_NONE)
         self._n_agents = int(A.N)
         self.agent_for_out = agent
         pg = getattr(agent, '_prev_grad', None)
@@ -204,7 +188,7 @@ class PicState:
         if pg is not None and self.spare_pg is pg:
             self.spare_pg = None                 # (never bin an array into itself)
         out = self._out_tensors(env)
-        cur_t = (A.x, A.y, A._agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo, pg, self.fpre)
+        cur_t = (A.x, A.y, A.agent_food, A.slot if A.slot is not None else out[3], agent._hd_hi, agent._hd_lo, pg)
         p = self._struct(cur_t, out)
         m, a = env.medium.c_struct(need_owner=False), A.c_struct()
         if pg is None:
@@ -215,9 +199,6 @@ class PicState:
                                                      C.byref(p), 1 - self.cur, stream_ptr(env.device)), 'die_pic_bin_momentum')
         self.cur = 1 - self.cur
         self._adopt(env, agent, out)
-        if self.fs:                              # die_pic_bin has read the food under every agent from the plane
-            self._food_state(env, _lib.PIC_FOOD_FRESH)
-            self.food_touched = False
         if self.occ is not None:                 # the array order is now: alive agents (tile by tile), then the dead slots
             A.alive = torch.cat([torch.ones(self.n_alive, dtype=A.alive.dtype, device=env.device),
                                  torch.zeros(self._n_agents - self.n_alive, dtype=A.alive.dtype, device=env.device)])
@@ -272,15 +253,6 @@ class PicState:
         m = env.medium.c_struct(need_owner=False)
         u = None if lazy else C.byref(action.raw_struct())
         two = self.two_launch(env, agent)
-        # food stream: the two-launch step takes the food under the agents from layout[cur].fpre — re-read from the plane first if
-        # somebody took the plane since (or a three-launch step ran) —, a three-launch step reads the plane and needs agent_food complete
-        fs_step = self.fs and two
-        if fs_step and (self.food_touched or self.food_state == _lib.PIC_FOOD_NONE):
-            self.settle(env, regather=True, dyn=dyn)
-        elif not fs_step and self.food_state == _lib.PIC_FOOD_PENDING:
-            self.settle(env, dyn=dyn)
-        if not fs_step:
-            self._food_state(env, _lib.PIC_FOOD_NONE)
         g = action.g_struct
         turn_key = (int(g.seed), int(g.step))
         if plan is not None:
@@ -317,61 +289,10 @@ class PicState:
         self.cur = 1 - self.cur
         self.steps_since_check += 1
         self._adopt(env, agent, out)
-        if fs_step:
-            self._food_state(env, _lib.PIC_FOOD_PENDING)
         if lazy:
             action._rebuild = self._rebuilder(env, agent, out)
             self._lazy_ref = agent._lazy_action = weakref.ref(action)
         return 0
-
-    # ------------------------------------------------------------------ food stream
-    def _food_state(self, env, state: int):
-        """Set the state of layout[cur]'s food stream and the hooks that go with it: PENDING — env.agents.agent_food lacks the last
-        step's consumption until `settle`; any state but NONE — taking env.medium.food marks the stream stale."""
-        self.food_state = state
-        A, M = env.agents, env.medium
-        ref = weakref.ref(self)
-
-        def pending():
-            me, e = ref(), self._env_ref()
-            A.food_pending = None
-            if me is not None and e is not None and me.food_state == _lib.PIC_FOOD_PENDING and A._agent_food is (me.held[2] if me.held else None):
-                me.settle(e)
-
-        def taken():
-            me = ref()
-            if me is not None:
-                me.food_touched = True
-
-        A.food_pending = pending if state == _lib.PIC_FOOD_PENDING else None
-        if state != _lib.PIC_FOOD_NONE and M.food_taken is None:
-            M.food_taken = taken
-
-    def settle(self, env, regather: bool = False, dyn=None):
-        """die_pic_settle on layout[cur]: a pending consumption goes into agent_food; `regather`: the stream is read from the food
-        plane again.  FRESH afterwards."""
-        if not self.fs or self.held is None:
-            return
-        apply = self.food_state == _lib.PIC_FOOD_PENDING
-        if apply or regather:
-            self._n_agents = int(env.agents.N)
-            p = self._struct(self.held, self._out_tensors(env))
-            m = env.medium.c_struct(need_owner=False)
-            d = dyn if dyn is not None else env._c_dynamics()
-            _lib.check(_lib.lib.die_pic_settle(C.byref(m), C.byref(p), self.cur, C.byref(d), int(apply), int(regather), stream_ptr(env.device)),
-                       'die_pic_settle')
-        if regather:
-            self.food_touched = False
-        self._food_state(env, _lib.PIC_FOOD_FRESH)
-
-    def release(self, env):
-        """The agent arrays are about to be modified by something other than the tile-binned step: complete agent_food, then the
-        tile order is void."""
-        self.flush_lazy()
-        if self.food_state == _lib.PIC_FOOD_PENDING and self.held is not None and env.agents._agent_food is self.held[2]:
-            self.settle(env)
-        self._food_state(env, _lib.PIC_FOOD_NONE)
-        self.held = None
 
     def check(self):
         """After a synchronisation: did every agent stay within its tile's neighbourhood?"""

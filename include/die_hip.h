@@ -384,8 +384,6 @@ typedef struct die_pic_layout {
     uint32_t* heading_hi;    /* N, the agent object's _direction_rads (float64 halves, die_gradient_agent) in this order */
     uint32_t* heading_lo;
     uint32_t *off, *n, *s, *inc;   /* die_pic_tiles() words each */
-    float* fpre;             /* N, the food stream (two-launch form on a single-tile world; NULL elsewhere): the food under every agent
-                                BEFORE the consumption of the step that wrote this layout — see die_pic.food_state */
 } die_pic_layout;
 
 typedef struct die_pic {
@@ -395,10 +393,8 @@ typedef struct die_pic {
     float* dep;                  /* N floats of scratch */
     float* dep_plane;            /* three-launch form only (may be NULL when rim is given and the step qualifies), W*H: per cell the deposit of the highest slot standing
                                     on it, or 0xFFFFFFFF */
-    void* part_gain;             /* 2 * die_pic_tiles() + 2 64-bit words: reward partials per tile, then (tiles of a decomposed world:
-                                    die_medium.gW > 0) the owned agents per tile; also the binning scratch.  The last two words (the
-                                    food stream's reward accumulator and ticket counter) must be 0 before the first step; every
-                                    completed step leaves them 0 */
+    void* part_gain;             /* 2 * die_pic_tiles() 64-bit words: reward partials per tile, then (tiles of a decomposed world:
+                                    die_medium.gW > 0) the owned agents per tile; also the binning scratch */
     uint32_t* error;             /* device word, 0 = fine; sticky bits after a step: 1 segment bookkeeping broken, 2 an agent moved
                                     further than a tile.  Never cleared by the library */
     int32_t k1_threads;          /* tuning: workgroup size of the agent kernel (multiple of 64, <= 512); 0 = default */
@@ -424,16 +420,8 @@ typedef struct die_pic {
     uint32_t* turn_bits;         /* 4 * ceil(turn_slots / 128) words */
     int64_t turn_slots;          /* slot ids are < turn_slots (>= N; a decomposed world: the world's slot count) */
     int32_t turn_ready;          /* the table already holds the bits of (g->seed, g->step) */
-    /* Food stream (two-launch form, single-tile worlds).  The agent kernel reads no food plane: the food under an agent
-     * (core/agent/gradient.py:114-117) and the food it consumes (core/env.py:224-225) travel with it in layout.fpre, written by the
-     * field kernel of the step for the agents that stay on its tile and by the agent kernel for those that walk onto another.  The
-     * consumption of step k is added to agent_food by the agent kernel of step k + 1, so between two steps layout[written].agent_food
-     * lacks it: state DIE_PIC_FOOD_PENDING, which the caller passes to the next step — or clears with die_pic_settle before anything
-     * else reads agent_food.  DIE_PIC_FOOD_FRESH: agent_food is complete and fpre holds the food under every agent as the plane
-     * holds it now (after die_pic_bin, after die_pic_settle).  Three-launch steps and decomposed tiles read the food plane and
-     * ignore fpre: they must not be entered in state PENDING. */
-    int32_t food_state;
-    void* reserved5;             /* (round 4: the tile queue of a persistent form of the agent kernel — measured slower, removed) */
+    int32_t reserved3;
+    void* reserved5;             /* (ABI 20: the tile queue of a persistent form of the agent kernel — measured slower, removed) */
     /* ONE launch (stages = 1 or 2) over a subset of the tiles: sub_mode 0 all tiles; 1 only the rectangle [sub_tx0, sub_tx0 +
      * sub_ntx) x [sub_ty0, sub_ty0 + sub_nty) of tiles; 2 all tiles but that rectangle — and, for stages = 2, the workgroups that
      * complete a step (next offsets, reward, turn bits).  A decomposed rank steps the tiles that need nothing from its neighbours
@@ -455,14 +443,6 @@ typedef struct die_pic {
     float* prev_grad[2][2];
 } die_pic;
 
-#define DIE_PIC_FOOD_NONE 0
-#define DIE_PIC_FOOD_PENDING 1
-#define DIE_PIC_FOOD_FRESH 2
-/* Food stream housekeeping on layout[lay] as a step wrote it (single-tile worlds): apply != 0 adds the pending consumption
- * rate_feed * fpre to agent_food (PENDING -> complete); regather != 0 reloads fpre from the food plane under every agent (after
- * somebody wrote the plane; after a three-launch step), else with apply fpre becomes what the consumption left on the cell — the
- * same value without a gather.  Either way the layout is DIE_PIC_FOOD_FRESH afterwards. */
-int die_pic_settle(const die_medium* m, const die_pic* p, int32_t lay, const die_dynamics* d, int32_t apply, int32_t regather, void* stream);
 /* entries per tile of die_pic.rim for a tile shape, or -1 if the shape is not compiled in */
 int64_t die_pic_rim_cap(int32_t tile_xs, int32_t tile_ys);
 /* 1 if die_pic_forward_env_step takes the two-launch form for these parameters when rim lists are given (world_max = the longer
@@ -478,7 +458,7 @@ int32_t die_pic_two_launch(int32_t world_max, int32_t tile_xs, int32_t tile_ys, 
 /* number of tiles (words per per-tile array), or -1 if the shape is not compiled in */
 int64_t die_pic_tiles(int32_t W, int32_t H, int32_t tile_xs, int32_t tile_ys);
 /* Bin agents held in any order (die_agents; `heading` in the same order) into layout[into]; both layouts' per-tile words
- * are initialised; layout[into].fpre (when given, single-tile worlds) receives the food under every agent (DIE_PIC_FOOD_FRESH).  DIE_ERR_UNSUPPORTED unless the world splits into at least 3×3 whole tiles. */
+ * are initialised.  DIE_ERR_UNSUPPORTED unless the world splits into at least 3×3 whole tiles. */
 int die_pic_bin(const die_medium* m, const die_agents* a, const uint32_t* heading_hi, const uint32_t* heading_lo, const die_pic* p,
                 int32_t into, void* stream);
 /* … and a GradientAgent's _prev_grad (core/agent/gradient.py:42,89), same order, into p->prev_grad[into] (both NULL: die_pic_bin) */

@@ -46,12 +46,12 @@ def test_struct_layouts_match_header(built_lib):
     assert C.sizeof(_lib.Dynamics) == 12 * 4
     assert C.sizeof(_lib.GradientAgent) == 8 * 4 + 3 * 8 + 5 * 8 + 8 + 4 + 4 + 8
     assert C.sizeof(_lib.FoodSpec) == 16 + 4 * 8 * 8
-    assert C.sizeof(_lib.PicLayout) == 11 * 8
+    assert C.sizeof(_lib.PicLayout) == 10 * 8
     assert C.sizeof(_lib.PicSide) == 6 * 4 + 8 + 4 * 8
     # die_pic: tile shape 2 x i32, N i64, two layouts, dep / dep_plane / part_gain / error, k1_threads + stages, rim / rim_code /
-    # rim_cnt / status_out, turn_bits / turn_slots / turn_ready + food_state / reserved pointer / sub_mode + rectangle + reserved / n_alive / occ /
+    # rim_cnt / status_out, turn_bits / turn_slots / turn_ready + reserved / reserved pointer / sub_mode + rectangle + reserved / n_alive / occ /
     # prev_grad[2][2]
-    assert C.sizeof(_lib.Pic) == 8 + 8 + 2 * 11 * 8 + 4 * 8 + 8 + 4 * 8 + 8 + 8 + 8 + 8 + 6 * 4 + 8 + 8 + 4 * 8
+    assert C.sizeof(_lib.Pic) == 8 + 8 + 2 * 10 * 8 + 4 * 8 + 8 + 4 * 8 + 8 + 8 + 8 + 8 + 6 * 4 + 8 + 8 + 4 * 8
     assert C.sizeof(_lib.Batch) == 8 + 8 + 8 + 8 + 64 * 8
 
 
