@@ -36,7 +36,8 @@ class TorchAgent(Agent, nn.Module):
 
     @classmethod
     def load(cls, file: Union[str, os.PathLike, io.IOBase]):
-        ctor_args, weights = (th.load(file)[k] for k in _CHECKPOINT_KEYS)
+        loaded = th.load(file)                                         # ONE read: `file` may be a stream
+        ctor_args, weights = (loaded[k] for k in _CHECKPOINT_KEYS)
         ctor_args = dict(ctor_args)
         ctor_args.update(ctor_args.pop('model_kwargs', {}))            # **model_kwargs of NeuralAutomataAgent are stored nested
         restored = cls(**ctor_args)
@@ -134,6 +135,7 @@ class NeuralAutomataAgent(TorchAgent):
 
     def sense(self, medium) -> th.Tensor:
         """ConvolutionModel.forward over the medium on the device → (3, W, H) float32 tensor."""
+        medium.sensed()
         dev, W, H = medium.device, medium.W, medium.H
         weights = self._device_weights(dev)
         sp = stream_ptr(dev)

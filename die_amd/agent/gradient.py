@@ -178,6 +178,9 @@ class GradientAgent(Agent):
         if self._pending is action:
             self._pending = None
         agents, medium = action.agents, action.medium
+        if medium.sensed():                         # (a decomposed rank: a ghost refresh that was left for the next step happens now …
+            action.rebind(agents)                   #  … and re-seats the agents: the action follows — array order, headings, count)
+            action.N = agents.N
         m, a, u = medium.c_struct(), agents.c_struct(), action.raw_struct()
         _lib.check(_lib.lib.die_gradient_forward(C.byref(m), C.byref(a), C.byref(action.g_struct), C.byref(u),
                                                  stream_ptr(agents.device)), 'die_gradient_forward')

@@ -61,6 +61,10 @@ class DeviceMedium:
         self.epoch = 1
         self.world = None        # (gW, gH, ox, oy) when these planes are one tile of a decomposed world
         self.owner_stale = None  # callable that rebuilds `owner` (the tile-binned step does not maintain the claim plane)
+        # callable run before anything SENSES these planes outside a fused step — a stand-alone forward, a host read: a decomposed
+        # rank whose ghost refresh was left to travel under the next step (die_amd/dist.py) does it now instead.  The fused step
+        # itself takes the planes through c_struct() and never triggers it
+        self.before_sense = None
 
     @property
     def shape(self):
@@ -110,7 +114,16 @@ class DeviceMedium:
         return torch.where((w >> _lib.OWNER_EPOCH_SHIFT) == self.epoch, (w & _lib.OWNER_SLOT_MASK) - 1,
                            torch.full_like(w, -1))
 
+    def sensed(self):
+        """Somebody is about to read these planes as an observation (see `before_sense`)."""
+        hook = self.before_sense
+        if hook is not None:
+            hook()
+            return True                  # (the caller's view of the agents may be stale now: arrays re-seated, another count)
+        return False
+
     def sel(self, channel: str) -> torch.Tensor:
+        self.sensed()
         if channel == 'agents':
             return self.occupied().to(torch.float32)
         if channel == 'env_food':

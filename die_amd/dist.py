@@ -630,7 +630,8 @@ class DistEnv:
         result = torch.empty(2, dtype=torch.float64, device=self.device)
         if self._refresh_due:
             # the refresh that the previous step left for this one: the messages travel under this step's interior tiles
-            self._refresh_due = False
+            self._refresh_due, self._refresh_action = False, None
+            self.medium.before_sense = None
             self._send_action = False
             if self._pic_applies(action) and self._tile_refresh_applies():
                 self._check_reach(action)
@@ -696,7 +697,11 @@ class DistEnv:
         self._steps += 1
         if self._steps % self.migrate_every == 0:
             if self._overlap and self.geo.DIRS and self._tile_refresh_could_apply():
-                self._refresh_due, self._refresh_action = True, action      # … with the NEXT step (_step_ghost); observers flush it
+                # … with the NEXT step (_step_ghost), as long as that step's forward runs fused: anything that senses the planes
+                # before — a stand-alone forward (agent.lazy = False, an action read before the step), NCA sensing, a host read —
+                # finds `before_sense` and the refresh happens first (collective: the ranks run the same program).  ADVICE r4.
+                self._refresh_due = True            # (the consumed action is not kept: a reference would make flush_lazy() rebuild it)
+                self.medium.before_sense = self.flush_refresh
             else:
                 self._refresh_ghosts(action, after_step=True)
         self.last_result = result
@@ -709,10 +714,10 @@ class DistEnv:
     def flush_refresh(self):
         """A ghost refresh that was left for the next step (to travel under its interior tiles) is done NOW.  COLLECTIVE: every rank
         must call it (gather_world does; the rank-local observers — owned_mask, check, read_result — need no refresh)."""
+        self.medium.before_sense = None
         if self._refresh_due:
             self._refresh_due = False
-            self._refresh_ghosts(self._refresh_action, after_step=True)
-        self._refresh_action = None
+            self._refresh_ghosts(None, after_step=True)
 
     # -- tile-binned step on the padded tile (die_amd/pic.py, csrc/die_pic.hip TILED): a rank's step is the N = 1 step ------
     def _pic_applies(self, action) -> bool:
@@ -899,10 +904,13 @@ class DistEnv:
             cells = (rs.stop - rs.start) * (cs.stop - cs.start)
             cap = int(min(self.capacity, np.ceil(cells * dens * self._ghost_headroom) + 1024))
             ntx, nty = (rs.stop - rs.start) // TX, (cs.stop - cs.start) // TY
-            blk = (cells * esz + 7) & ~7
+            # (every block on a 16-byte boundary, cap a multiple of 4: the vector pack / unpack of csrc/die_pack.hip k_rects_vec takes
+            # 16-byte offsets only and would otherwise fall back to the scalar kernel depending on the parity of cap — ADVICE r4)
+            cap = (cap + 3) & ~3
+            blk = (cells * esz + 15) & ~15
             cnt = 16
-            rec = (cnt + ntx * nty * 4 + 7) & ~7
-            chem = (rec + 6 * cap * 4 + 7) & ~7
+            rec = (cnt + ntx * nty * 4 + 15) & ~15
+            chem = (rec + 6 * cap * 4 + 15) & ~15
             food = chem + blk
             P.caps.append(cap); rel.append((cnt, rec, chem, food)); sizes.append(food + blk)
             geo.append((rs.start // TX, cs.start // TY, ntx, nty, hr.start // TX, hc.start // TY))
@@ -1046,7 +1054,8 @@ class DistEnv:
         if nd:
             self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))
         A.N = n_new
-        action.N = n_new
+        if action is not None:
+            action.N = n_new
         self.tile_refreshes = getattr(self, 'tile_refreshes', 0) + 1
         self._ghosts_fresh = True
 

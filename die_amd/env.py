@@ -461,8 +461,8 @@ class Env(_EnvBase):
         momentum = ag._inertia != 0 or ag._noise_scale != 0
         if momentum and (ag._kind != _lib.DIE_AGENT_GRADIENT or not self._all_alive):
             return False                                         # (a PhysarumAgent with momentum, momentum with dead slots: the classic step)
-        if not momentum and ag._prev_grad is not None:
-            return False
+        if ag._prev_grad is not None and ag._inertia == 0:
+            return False                                         # (_prev_grad is kept up to date by the classic step only when nothing reads it: inertia 0 — ADVICE r4)
         W, H = self._field_size
         from .pic import step_scale
         eff_scale = step_scale(ag)                               # |scale| · the bound of the vector it multiplies (momentum: die_pic_step_bound)

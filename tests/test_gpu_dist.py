@@ -39,7 +39,7 @@ def _wave_dynamics(die_amd, W, H, kind=True):
 
 
 def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
-            wave=False, f16=False, read_actions=False):
+            wave=False, f16=False, read_actions=False, materialise_at=()):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -73,8 +73,10 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         agent.set_state_local(env.agents, local)
         obs = env._get_current_obs
         rewards = []
-        for _ in range(steps):
+        for i in range(steps):
             act = agent.forward(obs)
+            if i in materialise_at:          # the stand-alone forward runs NOW, on what the rank holds now (a ghost refresh
+                act.to_numpy()               # that was left for this step has to happen first — the halos are past their window)
             obs, res = env.step(act)
             rewards.append(env.read_result(res))
             if read_actions:                 # the binned step kept it in registers: re-derived from what the step left behind
@@ -226,6 +228,27 @@ def test_action_read_after_a_step_that_ran_inside_a_ghost_refresh(tmp_path, grid
              nprocs=size, join=True)
     got = np.load(out)
     assert int(got['pic_steps']) == steps and int(got['overlapped']) == (steps - 1) // refresh_every
+    m, a, r = _single_device_run(W, H, N, N, steps, False, False)
+    assert np.array_equal(got['agents'], a)
+    for c in range(3):
+        assert np.array_equal(got['medium'][c], m[c])
+    assert np.array_equal(got['rewards'], r)
+
+
+@pytest.mark.parametrize('grid,refresh_every,at', [((1, 2), 2, (2, 5)), ((2, 2), 1, (1, 2, 4)), ((2, 1), 3, (3,))])
+def test_action_materialised_before_the_step_that_follows_a_deferred_refresh(tmp_path, grid, refresh_every, at):
+    """With the refresh left for the next step (overlap), a forward that does NOT run fused into that step — here: the action is read
+    between forward() and step() — must not sense the stale halos: DeviceMedium.before_sense makes the deferred refresh happen first
+    (collectively: every rank runs the same program).  ADVICE r4: before the fix such a run silently left the single-device run."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    W, H, N, steps = 384, 256, 12000, 7
+    out = str(tmp_path / 'dist.npz')
+    size = grid[0] * grid[1]
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, True, refresh_every, out, 'gloo', True, False, False, False, at),
+             nprocs=size, join=True)
+    got = np.load(out)
     m, a, r = _single_device_run(W, H, N, N, steps, False, False)
     assert np.array_equal(got['agents'], a)
     for c in range(3):

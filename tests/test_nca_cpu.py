@@ -76,4 +76,12 @@ def test_model_and_agent_interface_like_the_reference_tests():
     finally:
         if os.path.exists(path):
             os.remove(path)
+    # an already-open stream (allowed by the signature, as by the reference's single th.load): ONE read
+    import io
+    buf = io.BytesIO()
+    agent.save(buf)
+    buf.seek(0)
+    agent3 = die_amd.NeuralAutomataAgent.load(buf)
+    assert agent.init_params == agent3.init_params
+    assert th.allclose(agent.model.forward(x), agent3.model.forward(x))
     assert agent.render()[0].shape == (2, 2, 3)
