@@ -399,10 +399,14 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
             a.result += blockIdx.z;
         }
     }
-    if (FUSED && a.result && blockIdx.y == gridDim.y - 1) {
-        // an extra row of workgroups past the field: (0, last) reduces, the others have nothing to do.  (Doing it as a
-        // prologue of workgroup (0, 0) made the whole sweep 10 µs longer: all its workgroups are resident at once, so
-        // the kernel ends when its slowest workgroup does.)
+    const int row0 = FUSED && a.result ? 1 : 0;             // grid rows ahead of the field's
+    if (row0 && blockIdx.y == 0) {
+        // an extra row of workgroups ahead of the field: (0, 0) reduces, the others have nothing to do.  (Doing it as a
+        // prologue of a field workgroup made the whole sweep 10 µs longer: all its workgroups are resident at once, so
+        // the kernel ends when its slowest workgroup does.)  The FIRST row since round 5: the reduction depends on the claim
+        // pass only, and dispatched first it hands the step's result to an Env(sync=True) caller (pinned host memory) while
+        // the field is still being swept — the caller's next launches are queued before this kernel ends (die_pic.hip's field
+        // kernel does the same).
         if (blockIdx.x != 0) return;
         __shared__ long long s_g[DIF_BLOCK];
         // 8 loads in flight per thread: this workgroup must not outlast the sweep (one load at a time it took ≈ 45 µs per
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
     const int hx = wx ? 0 : a.halo, hy = wy ? 0 : a.halo;
     const int col = wy ? wrap_idx(yb + 4 * (lane - 1), H)    // 16-byte aligned since H % 4 == 0
                        : min(max(yb + 4 * (lane - 1), 0), H - 4);     // tile: clamp, border ring is don't-care
-    const int x0 = blockIdx.y * a.rpw;
+    const int x0 = ((int)blockIdx.y - row0) * a.rpw;
     const int rows = min(a.rpw, W - x0);
 
     float win[2 * R + 1][4];

@@ -191,10 +191,10 @@ struct PicArgs {
 #define PIC_XCD_MAP 2
 #endif
 template <bool REVERSE = false>
-__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx) {      // ntx: rows of tiles (the grid may have one row more)
+__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t row0 = 0) {      // ntx: rows of tiles; row0: grid rows ahead of the tiles' (the field kernel's extra row)
 #if PIC_XCD_MAP == 1
     if (((gridDim.x * (uint32_t)ntx) & 7u) == 0) {
-        const uint32_t L = blockIdx.y * gridDim.x + blockIdx.x, G8 = (gridDim.x * (uint32_t)ntx) >> 3;
+        const uint32_t L = (blockIdx.y - row0) * gridDim.x + blockIdx.x, G8 = (gridDim.x * (uint32_t)ntx) >> 3;
         const uint32_t nl = (L & 7u) * G8 + (L >> 3);
         tx = (int)(nl / gridDim.x); ty = (int)(nl - (uint32_t)tx * gridDim.x);
     }
@@ -202,7 +202,7 @@ __device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx) {      /
     // (gridDim.x = tiles per row.  Bands of wb = floor(nty / 8) columns; the nty mod 8 columns left over — a decomposed rank's planes:
     // 68 tiles per row — come last, in the plain order)
     const uint32_t nty = gridDim.x, wb = nty >> 3, banded = (wb << 3) * (uint32_t)ntx;
-    const uint32_t L = blockIdx.y * nty + blockIdx.x;
+    const uint32_t L = (blockIdx.y - row0) * nty + blockIdx.x;
     if (wb == 0) return;
     if (L < banded) {
         const uint32_t k = REVERSE ? wb * (uint32_t)ntx - 1u - (L >> 3) : L >> 3;      // (REVERSE: the band walked from its far end — A/B only)
@@ -983,7 +983,12 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     __shared__ unsigned char s_lut[9 * 81 + 3];             // (list, code) → (ux + 1)·3 + uy + 1 of an agent that matters here, else 0xFF
     constexpr int CAPR = KbShape<XS, YS>::RIM_CAP, NE = KbShape<XS, YS>::NE;
     const int NT = p.ntx * p.nty;
-    if ((int)blockIdx.y == p.ntx) {                         // the extra grid row
+    // The extra grid row — next offsets, reward, turn bits: work that depends on the agent kernel only — is the FIRST row of the grid:
+    // its workgroups are dispatched ahead of the tiles', so the step's result reaches an Env(sync=True) caller (pinned host memory)
+    // while the tiles are still being swept, and that caller's next launches are queued before this kernel ends.  (As the last row,
+    // round 4, the result arrived with the kernel's end and every sync=True step paid a launch latency: 6 300 against 7 300 steps/s.)
+    const uint32_t row0 = p.sub_mode == 1 ? 0u : 1u;        // (a launch over a rectangle of tiles has no extra row)
+    if (row0 && blockIdx.y == 0) {
         if (blockIdx.x == 0) {                              // sizes and offsets of the layout the NEXT step writes
             uint32_t* s_sum = (uint32_t*)kb_smem;           // BLOCK words (the window arrays are not used by this workgroup)
             const int per = (NT + BLOCK - 1) / BLOCK;
@@ -1049,11 +1054,11 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         }
         return;
     }
-    int tx = blockIdx.y, ty = blockIdx.x;
+    int tx = (int)(blockIdx.y - row0), ty = blockIdx.x;
 #ifndef PIC_XCD_MAP_KB
 #define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx);
+    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
