@@ -499,12 +499,13 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
             if (any && outl && own_row && !a.food_infinite) {
                 float f[4];
                 Vec4<T>::ld(food + off, f);
+                bool changed = false;                           // (an occupied cell without food stays as it is: a group in which nothing changes is not written)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool mine = col + j >= hy && col + j < H - hy;
-                    if (occ[j] && mine) f[j] = f[j] - a.rate_feed * f[j];
+                    if (occ[j] && mine && f[j] != 0.f) { f[j] = f[j] - a.rate_feed * f[j]; changed = true; }
                 }
-                Vec4<T>::st(food + off, f);
+                if (changed) Vec4<T>::st(food + off, f);
             }
         }
     };
