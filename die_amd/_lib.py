@@ -76,7 +76,7 @@ class Pic(C.Structure):
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
                 ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32),
                 ('reserved5', C.c_void_p), ('sub_mode', C.c_int32), ('sub_tx0', C.c_int32), ('sub_ty0', C.c_int32), ('sub_ntx', C.c_int32),
-                ('sub_nty', C.c_int32), ('reserved4', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p),
+                ('sub_nty', C.c_int32), ('halo_fresh', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p),
                 ('prev_grad', (C.c_void_p * 2) * 2)]
 
 
@@ -195,6 +195,7 @@ _SIGNATURES = {
     'die_pic_ghost_pack': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_void_p, C.c_void_p]),
     'die_pic_ghost_merge': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_int64, C.c_void_p, C.c_void_p]),
     'die_pic_ghost_merge_phase': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p]),
+    'die_pic_ghost_inplace': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     'die_conv2d_circular': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,
                                       C.c_void_p, C.c_int32, C.c_void_p]),
     'die_conv2d': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P(ConvPlane), C.c_int32, C.c_int32, _P(C.c_void_p), C.c_int32,

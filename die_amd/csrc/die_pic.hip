@@ -173,6 +173,7 @@ struct PicArgs {
     // while the ghost refresh's messages are in flight, the others afterwards): 0 all tiles; 1 the rectangle only (the grid is the
     // rectangle); 2 all but the rectangle (full grid, the rectangle's workgroups return at once)
     int sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty;
+    int halo_fresh;                 // die_pic.halo_fresh
     // GradientAgent with momentum (inertia ≠ 0: die_pic.prev_grad): _prev_grad in `in` order / where the step leaves it, `out` order
     const float *ipgx, *ipgy;
     float *opgx, *opgy;
@@ -262,12 +263,12 @@ __device__ __forceinline__ PicMeta pic_meta_load(const PicLayout& L, int tx, int
     return mt;
 }
 
-__device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* base, uint32_t* pre) {
+__device__ __forceinline__ void pic_ranges_finish(const PicMeta& mt, uint32_t* base, uint32_t* pre, bool no_arrivals = false) {
     __shared__ uint32_t s_len[9];
     if (threadIdx.x < 9) {
         const bool own = threadIdx.x == 0;
         base[threadIdx.x] = own ? mt.o : mt.o + mt.s;
-        s_len[threadIdx.x] = mt.s > mt.n ? 0u : (own ? mt.s : mt.n - mt.s);     // (s > n: broken bookkeeping — never loop over garbage)
+        s_len[threadIdx.x] = mt.s > mt.n ? 0u : (own ? mt.s : (no_arrivals ? 0u : mt.n - mt.s));     // (s > n: broken bookkeeping — never loop over garbage)
     }
     PA_BARRIER();
     if (threadIdx.x == 0) {
@@ -505,7 +506,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
         st_f.issue(sf);
     }
     const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
-    pic_ranges_finish(mt, s_base, s_pre);
+    // (TILED, the step behind a refresh in place — die_pic_ghost_inplace: a halo tile holds exactly what arrived for it; the neighbours'
+    // leavers that stand on it are stale copies of agents that came with the message)
+    pic_ranges_finish(mt, s_base, s_pre, TILED && p.halo_fresh && p.g.own_x1 > 0 && (x0 < p.g.own_x0 || x0 >= p.g.own_x1 || y0 < p.g.own_y0 || y0 >= p.g.own_y1));
     prefetch_agents();
     PIC_STAMP(1);
     const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
@@ -1604,6 +1607,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.boundary = d->boundary; k.cost = d->cost;
     k.part_gain = (long long*)p->part_gain; k.error = p->error;
     k.sub_mode = p->sub_mode; k.sub_tx0 = p->sub_tx0; k.sub_ty0 = p->sub_ty0; k.sub_ntx = p->sub_ntx; k.sub_nty = p->sub_nty;
+    k.halo_fresh = m->gW > 0 ? p->halo_fresh : 0;
     const bool keep_pg = mom && g->inertia != 0.f;
     k.ipgx = keep_pg ? pg_in[0] : nullptr; k.ipgy = keep_pg ? pg_in[1] : nullptr; k.opgx = keep_pg ? pg_out[0] : nullptr; k.opgy = keep_pg ? pg_out[1] : nullptr;
     DIE_REQUIRE(p->sub_mode >= 0 && p->sub_mode <= 2, "die_pic_forward_env_step: sub_mode %d", p->sub_mode);

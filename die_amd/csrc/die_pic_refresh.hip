@@ -43,6 +43,11 @@ struct RfArgs {
     long long* summary;
     uint32_t capacity;
     int phase;                  // die_pic_ghost_merge_phase: 0 the whole new layout; 1 its interior tiles (needs nothing that arrives); 2 its halo tiles
+    // die_pic_ghost_inplace: the interior tiles' segments stay where the step left them (layout `src` remains the layout the next step
+    // READS); only the halo tiles get new segments, behind everything the arrays hold.  tail[t]: where halo tile t's new segment
+    // begins (scratch, one word per tile)
+    int inplace;
+    uint32_t* tail;
 };
 
 __device__ __forceinline__ int rf_wrap(int v, int n) { return v < 0 ? v + n : (v >= n ? v - n : v); }
@@ -242,6 +247,119 @@ __global__ __launch_bounds__(1024) void k_pic_ghost_scan(RfArgs a) {
         for (int i = 0; i < S.ntx * S.nty; ++i) t += (long long)S.recv_counts[i];
         a.summary[RF_SUM_ARRIVED + threadIdx.x] = t;
     }
+    if (a.inplace && a.phase == 2) {
+        // in place: the halo tiles' NEW segments of the layout the step reads (src) go behind everything the arrays hold.  A halo
+        // tile's segment = what arrived for it (stayers) + those of its OLD leavers that stand on an interior tile (a ghost that
+        // walked into the interior in the last step is owned now and lives nowhere else) — room for all its old leavers is set
+        // aside, so the places follow from the per-tile words alone.
+        __syncthreads();
+        uint32_t end = 0, sum = 0;
+        for (int t = lo; t < hi; ++t) {
+            end = max(end, a.src.off[t] + a.src.n[t]);
+            bool in;
+            const uint32_t c = count(t, in);
+            if (!in) { const uint32_t s_ = a.src.s[t], n_ = a.src.n[t]; sum += c + (s_ > n_ ? 0u : n_ - s_); }
+        }
+        s[threadIdx.x] = end;
+        __syncthreads();
+        for (int o = 512; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) s[threadIdx.x] = max(s[threadIdx.x], s[threadIdx.x + o]);
+            __syncthreads();
+        }
+        const uint32_t end_old = s[0];
+        __syncthreads();
+        s[threadIdx.x] = sum;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
+            __syncthreads();
+            s[threadIdx.x] += v;
+            __syncthreads();
+        }
+        uint32_t run = end_old + s[threadIdx.x] - sum;
+        for (int t = lo; t < hi; ++t) {
+            bool in;
+            const uint32_t c = count(t, in);
+            if (in) continue;
+            a.tail[t] = run;
+            const uint32_t s_ = a.src.s[t], n_ = a.src.n[t];
+            run += c + (s_ > n_ ? 0u : n_ - s_);
+        }
+        if (threadIdx.x == 1023 && (unsigned long long)end_old + s[1023] > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
+    }
+}
+
+// in place (die_pic_ghost_inplace, phase 2), one workgroup per HALO tile: its new segment of layout src, at tail[t] — what arrived
+// for it as stayers, then its old leavers that stand on an interior tile as leavers (the agent kernel of the interior tile next to it
+// picks them up as arrivals, as after any step) — and its three words.  The interior tiles' leavers that stand on a halo tile stay
+// where they are and are nobody's: the agent kernel of a halo tile takes no arrivals in the step behind a refresh (die_pic.halo_fresh)
+// — the copy that counts arrived with the message.
+__global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_halo(RfArgs a) {
+    const int tx = blockIdx.y, ty = blockIdx.x, t = tx * a.NTY + ty;
+    if (tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1) return;
+    const die_pic_layout& L = a.src;
+    __shared__ uint32_t s_keep;
+    if (threadIdx.x == 0) s_keep = 0;
+    uint32_t o_old = L.off[t], s_old = L.s[t], n_old = L.n[t];
+    if (s_old > n_old) { s_old = n_old = 0; if (threadIdx.x == 0) rf_flag(a, RF_FLAG_COUNT); }
+    const uint32_t base = a.tail[t], capacity = a.capacity;
+    int i;
+    const int k = rf_halo_side(a, tx, ty, i);
+    uint32_t c = 0;
+    if (k >= 0) {
+        const RfSide& S = a.side[k];
+        const uint32_t* counts = S.recv_counts;
+        c = counts[i];
+        if (c > S.cap) c = 0;                                   // (flagged by the scan)
+        const uint32_t before = rf_block_sum(i, [&](int q) { return counts[q]; }), cap = S.cap;
+        const uint32_t* rec = S.recv_rec;
+        constexpr int U = 3;                                    // (all loads of a round before its first store: see rf_gather)
+        for (uint32_t b = 0; b < c; b += U * RF_BLOCK) {
+            uint32_t v[U][6];
+            bool ok[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t q = b + (uint32_t)u * RF_BLOCK + threadIdx.x, from = before + q, at = base + q;
+                ok[u] = q < c;
+                if (ok[u] && (from >= cap || at >= capacity)) { rf_flag(a, from >= cap ? RF_FLAG_RECV : RF_FLAG_CAPACITY); ok[u] = false; }
+                if (ok[u]) for (int w = 0; w < 6; ++w) v[u][w] = rec[(uint32_t)w * cap + from];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t at = base + b + (uint32_t)u * RF_BLOCK + threadIdx.x;
+                if (!ok[u]) continue;
+                L.x[at] = v[u][0]; L.y[at] = v[u][1]; L.agent_food[at] = __uint_as_float(v[u][2]);
+                L.slot[at] = v[u][3]; L.heading_hi[at] = v[u][4]; L.heading_lo[at] = v[u][5];
+            }
+        }
+    }
+    __syncthreads();
+    // the old leavers that stand on an interior tile
+    const int lane = threadIdx.x & (DIE_WAVE - 1);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t b = s_old; b < n_old; b += RF_BLOCK) {                // wave-uniform trip count
+        const uint32_t j = o_old + b + threadIdx.x;
+        const bool in_range = b + threadIdx.x < n_old;
+        uint32_t X = 0, Y = 0, AF = 0, SL = 0, HH = 0, HL = 0;
+        if (in_range) { X = L.x[j]; Y = L.y[j]; AF = __float_as_uint(L.agent_food[j]); SL = L.slot[j]; HH = L.heading_hi[j]; HL = L.heading_lo[j]; }
+        bool keep = false;
+        if (in_range) {
+            const int tt = rf_tile_of(a, X, Y), ttx = tt / a.NTY, tty = tt - ttx * a.NTY;
+            keep = ttx >= a.ix0 && ttx < a.ix1 && tty >= a.iy0 && tty < a.iy1;
+        }
+        const unsigned long long m = __ballot(keep);
+        if (!m) continue;
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(&s_keep, (uint32_t)__popcll(m));
+        at = __shfl(at, 0, DIE_WAVE);
+        if (keep) {
+            const uint32_t q = base + c + at + (uint32_t)__popcll(m & below);
+            if (q < capacity) { L.x[q] = X; L.y[q] = Y; L.agent_food[q] = __uint_as_float(AF); L.slot[q] = SL; L.heading_hi[q] = HH; L.heading_lo[q] = HL; }
+            else rf_flag(a, RF_FLAG_CAPACITY);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { L.off[t] = base; L.s[t] = c; L.n[t] = c + s_keep; }
 }
 
 // one workgroup per tile of the planes: its segment of the new layout
@@ -337,6 +455,7 @@ static int rf_fill(RfArgs& a, const die_medium* m, const die_pic* p, int32_t fro
     a.summary = (long long*)summary;
     a.capacity = 0;
     a.phase = 0;
+    a.inplace = 0; a.tail = nullptr;
     return DIE_OK;
 }
 
@@ -372,5 +491,24 @@ extern "C" int die_pic_ghost_merge_phase(const die_medium* m, const die_pic* p, 
     k_pic_ghost_merge<<<dim3(a.NTY, a.NTX), RF_BLOCK, 0, s>>>(a);
     k_pic_ghost_words<<<(a.NTX * a.NTY + RF_BLOCK - 1) / RF_BLOCK, RF_BLOCK, 0, s>>>(a);
     DIE_CHECK_LAUNCH("die_pic_ghost_merge");
+    return DIE_OK;
+}
+
+extern "C" int die_pic_ghost_inplace(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                                     int64_t capacity, int64_t* summary, int32_t phase, uint32_t* tail, void* stream) {
+    RfArgs a;
+    const int rc = rf_fill(a, m, p, from, n_sides, sides, summary, "die_pic_ghost_inplace");
+    if (rc != DIE_OK) return rc;
+    DIE_REQUIRE(capacity > 0 && capacity < ((int64_t)1 << 31), "die_pic_ghost_inplace: capacity %lld", (long long)capacity);
+    DIE_REQUIRE((phase == 1 || phase == 2) && tail, "die_pic_ghost_inplace: phase %d / null scratch", phase);
+    a.capacity = (uint32_t)capacity;
+    a.phase = phase;
+    a.inplace = 1; a.tail = tail;
+    hipStream_t s = (hipStream_t)stream;
+    // phase 1: the places of the interior tiles' segments in the layout the step WRITES (dst) — the step can start on the interior;
+    // phase 2: those of the halo tiles behind them, and the halo tiles' new segments of the layout it reads (src), in place
+    k_pic_ghost_scan<<<1, 1024, 0, s>>>(a);
+    if (phase == 2) k_pic_ghost_halo<<<dim3(a.NTY, a.NTX), RF_BLOCK, 0, s>>>(a);
+    DIE_CHECK_LAUNCH("die_pic_ghost_inplace");
     return DIE_OK;
 }

@@ -415,6 +415,7 @@ class DistEnv:
             self.medium.own = (g.hx, g.hy, g.hx + g.Wi, g.hy + g.Hi)
         self._ghosts_fresh = False
         self._refresh_due, self._refresh_action = False, None     # a ghost refresh left for the next step (overlap)
+        self._refresh_in_place = os.environ.get('DIE_REFRESH_IN_PLACE', '1') != '0'      # … keeps the interior tiles' segments where they are (die_pic_ghost_inplace)
         self._pic = None                 # PicState (die_amd/pic.py), built at the first step that qualifies
         self._pic_off = False            # the library refused the binned step for this configuration once
         self.pic_steps = 0               # steps taken by the tile-binned path (tests, bench)
@@ -1019,6 +1020,29 @@ class DistEnv:
                       'die_pic_ghost_merge')
             self._tick('new layout (scan, merge, words)')
             adopt_new_layout()
+        elif self._refresh_in_place and n + sum(P.caps) + max(n - int(getattr(self, '_owned', 0) or 0), 0) <= self.capacity:
+            # (… when the halo tiles' new segments surely fit behind the arrays' old end: what can arrive + the old halo agents)
+            # IN PLACE (round 5): the step that follows reads the layout the step before left (interior tiles: stayers + leavers where
+            # they are — the agent kernel gathers a tile's agents from there anyway; nothing is copied, where the merge rewrote every
+            # tile's segment: 120 MB, ≈ 80 µs per refresh); only the halo tiles get new segments, behind the arrays' old end, once
+            # the messages are here.  The layout never outlives this call: the step writes the other one, compact, as always.
+            d, result = step
+            if getattr(P, 'tail', None) is None:
+                P.tail = torch.zeros(pic.NT, dtype=torch.int32, device=dev)
+            lib.check(lib.lib.die_pic_ghost_inplace(C.byref(m), C.byref(p), cur, nd, P.sides, self.capacity, _ptr(P.summary), 1, _ptr(P.tail), sp),
+                      'die_pic_ghost_inplace')
+            self._tick('places of the interior segments (scan)')
+
+            def second_half():
+                exchange_and_unpack()
+                lib.check(lib.lib.die_pic_ghost_inplace(C.byref(m), C.byref(p), cur, nd, P.sides, self.capacity, _ptr(P.summary), 2, _ptr(P.tail), sp),
+                          'die_pic_ghost_inplace')
+                self._tick('halo tiles: scan + new segments in place')
+            ia, if_ = P.inner_agents, P.inner_field
+            rc = pic.step(self, pic.agent, action, d, result,
+                          plan=[(1, (1,) + ia), (2, (1,) + if_), second_half, (1, (2,) + ia, 1), (2, (2,) + if_)])
+            lib.check(rc, 'die_pic_forward_env_step')
+            self.inplace_refreshes = getattr(self, 'inplace_refreshes', 0) + 1
         else:
             d, result = step
             # the interior tiles' segments of the new layout need nothing that arrives …

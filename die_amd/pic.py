@@ -237,7 +237,7 @@ class PicState:
         that bench.py times each kernel inside real steps.
 
         `plan` (two-launch form; a decomposed rank's step behind a ghost refresh, die_amd/dist.py): the step as a list of
-        launches over subsets of the tiles, `(stages, (sub_mode, tx0, ty0, ntx, nty))`, with callables in between (they run on
+        launches over subsets of the tiles, `(stages, (sub_mode, tx0, ty0, ntx, nty)[, halo_fresh])`, with callables in between (they run on
         the host between two launches: wait for the messages, unpack, second half of the merge).
 
         A normalised PhysarumAgent's action is a function of what the step leaves behind (heading', deposit array), so the
@@ -269,8 +269,9 @@ class PicState:
                 item()
                 m = env.medium.c_struct(need_owner=False)
                 continue
-            stages, sub = item
+            stages, sub = item[:2]
             p = self._struct(self.held, out, stages, status_out if two else None)
+            p.halo_fresh = int(item[2]) if len(item) > 2 else 0      # (the agent kernel behind a refresh in place: die_pic_ghost_inplace)
             p.turn_ready = int(self._turn_for == turn_key)
             p.sub_mode, p.sub_tx0, p.sub_ty0, p.sub_ntx, p.sub_nty = sub if sub is not None else (0, 0, 0, 0, 0)
             if events is not None:

@@ -427,7 +427,9 @@ typedef struct die_pic {
      * complete a step (next offsets, reward, turn bits).  A decomposed rank steps the tiles that need nothing from its neighbours
      * while its ghost refresh's messages are in flight, the others once they have arrived (die_amd/dist.py).  The caller issues
      * every tile exactly once per stage; two-launch form only. */
-    int32_t sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty, reserved4;
+    int32_t sub_mode, sub_tx0, sub_ty0, sub_ntx, sub_nty;
+    int32_t halo_fresh;          /* decomposed tiles, the step behind die_pic_ghost_inplace: the agent kernel takes no arrivals on tiles
+                                    outside the owned cells (die_medium.own_*) */
     /* The reference's default slot layout on this path (core/data_init.py:143-144: max_agents = W*H slots, most of which never
      * lived): the tiles' segments hold the n_alive alive agents, entries [0, n_alive) of the arrays, the dead slots lie behind them,
      * entries [n_alive, N), where die_pic_bin puts them.  A dead slot acts, moves, burns and "consumes" like the reference's
@@ -526,6 +528,17 @@ int die_pic_ghost_merge(const die_medium* m, const die_pic* p, int32_t from, int
  * (die_pic_ghost_merge).  Phase 1 before phase 2, die_pic_ghost_pack before both. */
 int die_pic_ghost_merge_phase(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
                               int64_t capacity, int64_t* summary, int32_t phase, void* stream);
+/* The refresh IN PLACE, for a step that follows at once and reads layout[from] (not layout[1 - from], as after die_pic_ghost_merge):
+ * the interior tiles' segments stay where the step before left them — stayers, then leavers, as the agent kernel reads them
+ * anyway — and nothing of them is copied.  phase 1: the places of the interior tiles' segments in the layout the coming step WRITES
+ * (layout[1 - from].off / .n; summary[1]); phase 2, once the messages are here: the halo tiles' places behind them (summary[0],
+ * arrived counts), and in layout[from] every halo tile gets a NEW segment behind everything the arrays hold — what arrived for it as
+ * stayers, then those of its old leavers that stand on an interior tile (a ghost that walked into the interior is owned now) — and
+ * its three words.  The coming step must run its agent kernel on the halo tiles with die_pic.halo_fresh = 1 (they take no arrivals:
+ * an interior tile's leaver that stands on a halo tile is the stale copy of an agent that arrived with the message).  Entries beyond
+ * the old end of the arrays are used: at most die_pic_tiles() words of `tail` scratch, `capacity` array entries. */
+int die_pic_ghost_inplace(const die_medium* m, const die_pic* p, int32_t from, int32_t n_sides, const die_pic_side* sides,
+                          int64_t capacity, int64_t* summary, int32_t phase, uint32_t* tail, void* stream);
 /* Rebuild the 'agents' channel from the agent arrays: atomicMax of (m->epoch, slot) claims (deposit bits 0) for every
  * alive agent.  The caller advances m->epoch (or zeroes the plane) first. */
 int die_agents_mark_owner(const die_medium* m, const die_agents* a, void* stream);

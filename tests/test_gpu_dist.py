@@ -39,7 +39,7 @@ def _wave_dynamics(die_amd, W, H, kind=True):
 
 
 def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
-            wave=False, f16=False, read_actions=False, materialise_at=()):
+            wave=False, f16=False, read_actions=False, materialise_at=(), capacity=None):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -65,7 +65,7 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H, wave) if wave else None, probe_reach=11,
                                         device=dev, sort_every=sort_every,
                                         overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
-                                        field_dtype=torch.float16 if f16 else torch.float32)
+                                        field_dtype=torch.float16 if f16 else torch.float32, **({'capacity': capacity} if capacity else {}))
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
         local = torch.zeros(cap, dtype=torch.float32, device=dev)
@@ -90,7 +90,7 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         if rank == 0:
             np.savez(out_path, medium=world[0], agents=world[1], rewards=np.array(rewards), pic_steps=getattr(env, 'pic_steps', 0),
                      plane=np.array([env.geo.W, env.geo.H]), tile_refreshes=getattr(env, 'tile_refreshes', 0),
-                     overlapped=getattr(env, 'overlapped_refreshes', 0))
+                     overlapped=getattr(env, 'overlapped_refreshes', 0), inplace=getattr(env, 'inplace_refreshes', 0))
     finally:
         dist.destroy_process_group()
 
@@ -174,7 +174,7 @@ def test_ghost_agent_mode_equals_single_device_run(tmp_path, grid, sort_every, r
     assert np.array_equal(got['rewards'][:, 0], r[:, 0])          # fixed-point accumulation: exact in any decomposition
 
 
-@pytest.mark.parametrize('overlap', [False, True])
+@pytest.mark.parametrize('overlap', [False, True, 'in place'])
 @pytest.mark.parametrize('grid,refresh_every,backend,wave,plane', [
     ((2, 2), 2, 'gloo', False, (320, 256)), ((1, 2), 3, 'gloo', True, (384, 256)), ((2, 1), 2, 'gloo-f16', False, (320, 256)),
     ((1, 1), 4, 'nccl', False, (384, 256)), ((1, 2), 2, 'gloo', 'limit', (384, 256))])
@@ -186,7 +186,11 @@ def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_ever
     run bit for bit; the worker reports how many of its steps took the binned path: all of them.
     `overlap`: a refresh is left for the step that follows it and its messages (one per peer) travel under that step's interior
     tiles — agent kernel and field kernel on the tiles that need nothing from a neighbour, then the halo tiles' segments, then
-    both kernels on the rest (DistEnv._refresh_ghosts_tiles(step=...)): the same bits."""
+    both kernels on the rest (DistEnv._refresh_ghosts_tiles(step=...)): the same bits.  'in place' (round 5; what a rank with the
+    benchmark's proportions takes — the small worlds here need their arrays enlarged for it): that step reads the layout the step before
+    left, the interior tiles' segments are not copied, only the halo tiles get new segments (die_pic_ghost_inplace)."""
+    in_place = overlap == 'in place'
+    overlap = bool(overlap)
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import torch.multiprocessing as mp
@@ -195,9 +199,11 @@ def test_ghost_agent_mode_with_the_tile_binned_step(tmp_path, grid, refresh_ever
     size = grid[0] * grid[1]
     f16 = backend.endswith('-f16')
     backend = backend.replace('-f16', '')
-    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, overlap, refresh_every, out, backend, True, wave, f16),
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, overlap, refresh_every, out, backend, True, wave, f16, False, (),
+                            8 * N if in_place else None),
              nprocs=size, join=True)
     got = np.load(out)
+    assert int(got['inplace']) == ((steps - 1) // refresh_every if size > 1 and in_place else 0)
     assert int(got['pic_steps']) == steps, 'the ranks did not take the tile-binned step'
     assert tuple(got['plane']) == plane                     # (halo rounded up so that the planes are whole tiles)
     # every refresh after a step went by tiles (csrc/die_pic_refresh.hip: no per-agent classification, no re-bin afterwards)
@@ -378,6 +384,8 @@ def _full_worker(rank, size, port, grid, W, H, steps, sort_every, refresh_every,
             obs, res = env.step(agent.forward(obs))
             rewards.append(env.read_result(res))
         assert env.overlapped_refreshes == (steps - 1) // refresh_every       # (the refresh travelled under the step that followed it)
+        # … in place: at the benchmark's proportions the halo tiles' new segments fit behind the arrays' old end by default
+        assert getattr(env, 'inplace_refreshes', 0) == (steps - 1) // refresh_every
         own = env.owned_mask()
         g, A, n = env.geo, env.agents, env.agents.N
         ri, ci = g.interior()
