@@ -247,46 +247,137 @@ __global__ __launch_bounds__(1024) void k_pic_ghost_scan(RfArgs a) {
         for (int i = 0; i < S.ntx * S.nty; ++i) t += (long long)S.recv_counts[i];
         a.summary[RF_SUM_ARRIVED + threadIdx.x] = t;
     }
-    if (a.inplace && a.phase == 2) {
-        // in place: the halo tiles' NEW segments of the layout the step reads (src) go behind everything the arrays hold.  A halo
-        // tile's segment = what arrived for it (stayers) + those of its OLD leavers that stand on an interior tile (a ghost that
-        // walked into the interior in the last step is owned now and lives nowhere else) — room for all its old leavers is set
-        // aside, so the places follow from the per-tile words alone.
-        __syncthreads();
-        uint32_t end = 0, sum = 0;
+}
+
+// The scan of the refresh in place (die_pic_ghost_inplace), one workgroup.  The generic scan above walks its tiles one dependent load
+// after the other (32 µs for the 4 624 tiles of a rank's planes: a chain of round trips, nothing else); here a thread requests the
+// words of all its tiles first.  phase 1: the interior tiles' places in the layout the step writes (dst), summary[1]; phase 2: the halo
+// tiles' places behind them (dst), the totals, the arrived counts per side, and tail[t] — where halo tile t's NEW segment of the
+// layout the step reads (src) begins: behind everything the arrays hold, room for what arrived + all its old leavers (so the places
+// follow from the per-tile words alone).
+#define RF_PER 8                // tiles per thread the unrolled loads cover (8 192 tiles; more: the plain loop)
+__global__ __launch_bounds__(1024) void k_pic_ghost_scan_inplace(RfArgs a) {
+    __shared__ uint32_t s[1024];
+    __shared__ unsigned long long s_arr[RF_SIDES];
+    const int NT = a.NTX * a.NTY, per = (NT + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(lo + per, NT);
+    if (threadIdx.x < RF_SIDES) s_arr[threadIdx.x] = 0ull;
+    __syncthreads();
+    // this thread's tiles: interior → the agents standing on it (s + inc); halo → what arrived for it, and its old leavers
+    uint32_t cnt[RF_PER], room[RF_PER], endv = 0;
+    int kind[RF_PER];                                           // 1 interior, 0 halo, −1 none
+    auto classify = [&](int t, uint32_t& c, uint32_t& r, uint32_t& e, int& side) {
+        const int tx = t / a.NTY, ty = t - tx * a.NTY;
+        const bool interior = tx >= a.ix0 && tx < a.ix1 && ty >= a.iy0 && ty < a.iy1;
+        c = r = e = 0; side = -1;
+        if (interior) { c = a.src.s[t] + a.src.inc[t]; return 1; }
+        if (a.phase == 1) return 0;
+        int i;
+        const int k = rf_halo_side(a, tx, ty, i);
+        if (k >= 0) {
+            c = a.side[k].recv_counts[i];
+            if (c > a.side[k].cap) { rf_flag(a, RF_FLAG_RECV); c = 0; }
+            side = k;
+        }
+        const uint32_t o_ = a.src.off[t], s_ = a.src.s[t], n_ = a.src.n[t];
+        r = c + (s_ > n_ ? 0u : n_ - s_);
+        e = o_ + n_;
+        return 0;
+    };
+    uint32_t own_sum = 0, halo_sum = 0, room_sum = 0;
+    if (per <= RF_PER) {
+#pragma unroll
+        for (int q = 0; q < RF_PER; ++q) {
+            const int t = lo + q;
+            kind[q] = -1; cnt[q] = room[q] = 0;
+            if (q < per && t < hi) {
+                uint32_t e; int side;
+                kind[q] = classify(t, cnt[q], room[q], e, side);
+                if (kind[q] == 1 && a.phase == 2) endv = max(endv, a.src.off[t] + a.src.n[t]);
+                endv = max(endv, e);
+                if (side >= 0) atomicAdd(&s_arr[side], (unsigned long long)cnt[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RF_PER; ++q) { if (kind[q] == 1) own_sum += cnt[q]; else if (kind[q] == 0) { halo_sum += cnt[q]; room_sum += room[q]; } }
+    } else {
         for (int t = lo; t < hi; ++t) {
-            end = max(end, a.src.off[t] + a.src.n[t]);
-            bool in;
-            const uint32_t c = count(t, in);
-            if (!in) { const uint32_t s_ = a.src.s[t], n_ = a.src.n[t]; sum += c + (s_ > n_ ? 0u : n_ - s_); }
+            uint32_t c, r, e; int side;
+            const int kd = classify(t, c, r, e, side);
+            if (kd == 1 && a.phase == 2) endv = max(endv, a.src.off[t] + a.src.n[t]);
+            endv = max(endv, e);
+            if (side >= 0) atomicAdd(&s_arr[side], (unsigned long long)c);
+            if (kd == 1) own_sum += c; else { halo_sum += c; room_sum += r; }
         }
-        s[threadIdx.x] = end;
-        __syncthreads();
-        for (int o = 512; o > 0; o >>= 1) {
-            if ((int)threadIdx.x < o) s[threadIdx.x] = max(s[threadIdx.x], s[threadIdx.x + o]);
-            __syncthreads();
-        }
-        const uint32_t end_old = s[0];
-        __syncthreads();
-        s[threadIdx.x] = sum;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
-            __syncthreads();
-            s[threadIdx.x] += v;
-            __syncthreads();
-        }
-        uint32_t run = end_old + s[threadIdx.x] - sum;
-        for (int t = lo; t < hi; ++t) {
-            bool in;
-            const uint32_t c = count(t, in);
-            if (in) continue;
-            a.tail[t] = run;
-            const uint32_t s_ = a.src.s[t], n_ = a.src.n[t];
-            run += c + (s_ > n_ ? 0u : n_ - s_);
-        }
-        if (threadIdx.x == 1023 && (unsigned long long)end_old + s[1023] > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
     }
+    // inclusive scan over the 1024 threads: shuffles inside a wave, the 16 waves' totals through LDS (two barriers; the textbook
+    // ten-step form with two barriers per step was most of this kernel's time)
+    const int lane = threadIdx.x & (DIE_WAVE - 1), wave = threadIdx.x / DIE_WAVE;
+    auto block_scan = [&](uint32_t v, uint32_t& total) {
+        uint32_t x = v;
+#pragma unroll
+        for (int o = 1; o < DIE_WAVE; o <<= 1) { const uint32_t u = __shfl_up(x, o, DIE_WAVE); if (lane >= o) x += u; }
+        __syncthreads();                                        // (s may still be read by the previous call's stragglers)
+        if (lane == DIE_WAVE - 1) s[wave] = x;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 1024 / DIE_WAVE; ++w) { const uint32_t t_ = s[w]; all += t_; if (w < wave) before += t_; }
+        total = all;
+        return x + before;
+    };
+    auto each = [&](auto f) {                                   // f(q-th tile of this thread, kind, count, room)
+        if (per <= RF_PER) {
+#pragma unroll
+            for (int q = 0; q < RF_PER; ++q) if (kind[q] >= 0) f(lo + q, kind[q], cnt[q], room[q]);
+        } else {
+            for (int t = lo; t < hi; ++t) { uint32_t c, r, e; int side; const int kd = classify(t, c, r, e, side); f(t, kd, c, r); }
+        }
+    };
+    if (a.phase == 1) {
+        uint32_t own_total;
+        uint32_t run = block_scan(own_sum, own_total) - own_sum;
+        each([&](int t, int kd, uint32_t c, uint32_t) {
+            if (kd != 1) return;
+            a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+            run += c;
+        });
+        if (threadIdx.x == 0) {
+            a.summary[1] = (long long)own_total;
+            if (own_total > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
+        }
+        return;
+    }
+    // phase 2
+    const uint32_t own_total = (uint32_t)a.summary[1];
+    uint32_t halo_total, room_total;
+    uint32_t run = own_total + block_scan(halo_sum, halo_total) - halo_sum;
+    each([&](int t, int kd, uint32_t c, uint32_t) {
+        if (kd != 0) return;
+        a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+        run += c;
+    });
+    const uint32_t room_incl = block_scan(room_sum, room_total);
+    uint32_t e_ = endv;
+#pragma unroll
+    for (int o = DIE_WAVE / 2; o > 0; o >>= 1) e_ = max(e_, (uint32_t)__shfl_xor((int)e_, o, DIE_WAVE));
+    __syncthreads();
+    if (lane == 0) s[wave] = e_;
+    __syncthreads();
+    uint32_t end_old = 0;
+#pragma unroll
+    for (int w = 0; w < 1024 / DIE_WAVE; ++w) end_old = max(end_old, s[w]);
+    uint32_t at = end_old + room_incl - room_sum;
+    each([&](int t, int kd, uint32_t, uint32_t r) {
+        if (kd != 0) return;
+        a.tail[t] = at;
+        at += r;
+    });
+    if (threadIdx.x == 0) {
+        a.summary[0] = (long long)own_total + (long long)halo_total;
+        if (own_total + halo_total > a.capacity || (unsigned long long)end_old + room_total > a.capacity) rf_flag(a, RF_FLAG_CAPACITY);
+    }
+    if ((int)threadIdx.x < a.n_sides) a.summary[RF_SUM_ARRIVED + threadIdx.x] = (long long)s_arr[threadIdx.x];
 }
 
 // in place (die_pic_ghost_inplace, phase 2), one workgroup per HALO tile: its new segment of layout src, at tail[t] — what arrived
@@ -507,7 +598,7 @@ extern "C" int die_pic_ghost_inplace(const die_medium* m, const die_pic* p, int3
     hipStream_t s = (hipStream_t)stream;
     // phase 1: the places of the interior tiles' segments in the layout the step WRITES (dst) — the step can start on the interior;
     // phase 2: those of the halo tiles behind them, and the halo tiles' new segments of the layout it reads (src), in place
-    k_pic_ghost_scan<<<1, 1024, 0, s>>>(a);
+    k_pic_ghost_scan_inplace<<<1, 1024, 0, s>>>(a);
     if (phase == 2) k_pic_ghost_halo<<<dim3(a.NTY, a.NTX), RF_BLOCK, 0, s>>>(a);
     DIE_CHECK_LAUNCH("die_pic_ghost_inplace");
     return DIE_OK;

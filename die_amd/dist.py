@@ -756,7 +756,14 @@ class DistEnv:
         if not self._pic.is_current(self, ag):
             self._pic.bin(self, ag)
             action.rebind(self.agents)
-        rc = self._pic.step(self, ag, action, d, result)
+        # the step after which a refresh falls due (and will be left for the next step): the band tiles' agents are final once the
+        # agent kernel has run, so they are packed on the second stream UNDER this step's field kernel, not in front of the refresh
+        plan = None
+        if self._overlap and self.geo.DIRS and self._comm_stream is not None and (self._steps + 1) % self.migrate_every == 0 \
+                and os.environ.get('DIE_REFRESH_EARLY_PACK', '1') != '0' and self._pic.two_launch(self, ag) and self._early_pack_ok():
+            plan = [(1, None), self._pack_bands_early, (2, None)]
+        self._packed_early = None
+        rc = self._pic.step(self, ag, action, d, result, plan=plan)
         if rc == -3:                         # DIE_ERR_UNSUPPORTED: nothing was launched; the classic step takes over for good
             self._pic_off = True
             self._pic_void()
@@ -766,6 +773,32 @@ class DistEnv:
         self.medium.owner_stale = self._mark_owner
         self.pic_steps += 1
         return True
+
+    def _early_pack_ok(self) -> bool:
+        """Will the refresh that falls due after this step go by tiles?  (What _tile_refresh_applies asks, for the layout the step
+        is about to write: the geometry, not the arrays.)"""
+        g, pic = self.geo, self._pic
+        TX, TY = 1 << pic.xs, 1 << pic.ys
+        if os.environ.get('DIE_GHOST_REFRESH', 'native') in ('torch', 'agents') or self.device.type != 'cuda' or not self.ghosts:
+            return False
+        return not (g.hx % TX or g.hy % TY or g.Wi % TX or g.Hi % TY or (g.hx and g.Wi < 2 * g.hx) or (g.hy and g.Hi < 2 * g.hy))
+
+    def _pack_bands_early(self):
+        """Between the agent kernel and the field kernel of a step (PicState.step(plan=…)): die_pic_ghost_pack of the layout the agent
+        kernel has just written, on the second stream.  The field kernel reads those arrays too and writes none of them."""
+        from .device_array import _ptr
+        lib, pic = self._lib, self._pic
+        P = self.__dict__.get('_tplan')
+        if P is None:
+            P = self._tplan = self._build_tile_plan()
+        main = torch.cuda.current_stream(self.device)
+        m = self.medium.c_struct(need_owner=False)
+        p = pic._struct(pic.held, pic.step_out)
+        self._comm_stream.wait_stream(main)
+        with torch.cuda.stream(self._comm_stream):
+            lib.check(lib.lib.die_pic_ghost_pack(C.byref(m), C.byref(p), 1 - pic.cur, P.nd, P.sides, _ptr(P.summary), self._comm_stream.cuda_stream),
+                      'die_pic_ghost_pack')
+        self._packed_early = pic.step_out[0]             # (the x array of the packed layout: the refresh checks that it is the one it refreshes)
 
     def _mark_owner(self):
         """Rebuild the claim plane ('agents' channel) of the padded tile from the local agents after tile-binned steps."""
@@ -978,7 +1011,12 @@ class DistEnv:
         p = pic._struct(pic.held, out)
         cur = pic.cur
         # everything below is enqueued without looking at a count; the host reads the summary once, at the end
-        lib.check(lib.lib.die_pic_ghost_pack(C.byref(m), C.byref(p), cur, nd, P.sides, _ptr(P.summary), sp), 'die_pic_ghost_pack')
+        early, self._packed_early = getattr(self, '_packed_early', None), None
+        if early is not None and early is pic.held[0] and self._comm_stream is not None:
+            torch.cuda.current_stream(dev).wait_stream(self._comm_stream)      # packed under the previous step's field kernel (_pack_bands_early)
+            self.early_packs = getattr(self, 'early_packs', 0) + 1
+        else:
+            lib.check(lib.lib.die_pic_ghost_pack(C.byref(m), C.byref(p), cur, nd, P.sides, _ptr(P.summary), sp), 'die_pic_ghost_pack')
         self._tick('band tiles packed')
         send_r, recv_r, _ = self._tile_field_rects(P)
         sb, rb = C.c_void_p(P.sbuf.data_ptr()), C.c_void_p(P.rbuf.data_ptr())
@@ -1042,6 +1080,7 @@ class DistEnv:
             rc = pic.step(self, pic.agent, action, d, result,
                           plan=[(1, (1,) + ia), (2, (1,) + if_), second_half, (1, (2,) + ia, 1), (2, (2,) + if_)])
             lib.check(rc, 'die_pic_forward_env_step')
+            self._tick('agent + field kernel on the remaining tiles')
             self.inplace_refreshes = getattr(self, 'inplace_refreshes', 0) + 1
         else:
             d, result = step
@@ -1059,6 +1098,7 @@ class DistEnv:
             rc = pic.step(self, pic.agent, action, d, result,
                           plan=[(1, (1,) + ia), (2, (1,) + if_), second_half, (1, (2,) + ia), (2, (2,) + if_)])
             lib.check(rc, 'die_pic_forward_env_step')
+            self._tick('agent + field kernel on the remaining tiles')
         t = P.summary.cpu().tolist()                                   # the one host read
         self._tick('counts to host')
         n_new, kept, sent, arrived, flags = t[0], t[1], t[2:2 + nd], t[10:10 + nd], int(t[18])

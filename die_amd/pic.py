@@ -264,6 +264,7 @@ class PicState:
         else:
             items = [(st, None) for st in ((1, 2) if two else (1, 2, 4))]
         i = 0
+        self.step_out = out                                    # (for callables of `plan`: the layout this step writes)
         for item in items:
             if callable(item):
                 item()
