@@ -320,6 +320,21 @@ def side_measurements(args, device, agent_kw, torch, die_amd):
             torch.cuda.empty_cache()
         except Exception as e:               # a side measurement never takes the headline down
             out[name] = f'failed: {type(e).__name__}: {e}'
+    # (e) Env.run: the same steps as ONE library call (die_pic_run: a C loop over the step — no Python between two steps)
+    try:
+        env = die_amd.Env((W, H), die_amd.Dynamics(init_agent_ratio=args.ratio), seed=args.seed, device=device, field_dtype=dt_f, max_agents='alive', sync=False)
+        agent = die_amd.PhysarumAgent(max_agents=env.agents.N, seed=args.seed, **agent_kw)
+        env.run(agent, 40)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        env.run(agent, 100)
+        torch.cuda.synchronize()
+        out['env_run_library_loop_steps_per_s'] = round(100 / (time.perf_counter() - t0), 1)
+        out['env_run_library_loop'] = 'die_pic_run' if getattr(env, 'library_runs', 0) else 'Python step loop (this world does not take the tile-binned two-launch step)'
+        del env, agent
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out['env_run_library_loop_steps_per_s'] = f'failed: {type(e).__name__}: {e}'
     return out
 
 

@@ -190,6 +190,7 @@ _SIGNATURES = {
     'die_pic_bin_momentum': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _P(Pic), C.c_int32, C.c_void_p]),
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),
+    'die_pic_run': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Dynamics), C.c_int32, C.c_void_p, C.c_void_p]),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),
     'die_pic_action_physarum': (C.c_int, [_P(Pic), C.c_int32, _P(GradientAgent), _P(Action), C.c_void_p]),
     'die_pic_ghost_pack': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_void_p, C.c_void_p]),

@@ -1770,6 +1770,27 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     return die_sweep_dep_plane(m, &dsweep, p->dep_plane, (const long long*)p->part_gain, NT, result, p->N, stream);
 }
 
+// n_steps × (forward + step) without the host in between (include/die_hip.h die_pic_run): the loop of examples/minimal_run.py:23-25 for a
+// caller that reads nothing back on the way.  Every step is die_pic_forward_env_step with the roles of the two layouts and of the
+// two chem planes exchanged and the Philox step counter advanced — the same launches, the same bits.
+extern "C" int die_pic_run(const die_medium* m, const die_pic* p, int32_t from, const die_gradient_agent* g, const die_dynamics* d,
+                           int32_t n_steps, die_step_result* results, void* stream) {
+    DIE_REQUIRE(m && p && g && d && results && n_steps >= 0 && (from == 0 || from == 1), "die_pic_run: null argument");
+    DIE_REQUIRE(p->stages == 0 && p->sub_mode == 0, "die_pic_run: whole steps only (stages = 0, all tiles)");
+    die_medium mm = *m;
+    die_pic pp = *p;
+    die_gradient_agent gg = *g;
+    for (int32_t i = 0; i < n_steps; ++i) {
+        const int rc = die_pic_forward_env_step(&mm, &pp, (from + i) & 1, &gg, nullptr, d, results + i, stream);
+        if (rc != DIE_OK) return rc;
+        void* t = mm.chem; mm.chem = mm.chem_next; mm.chem_next = t;                    // Env.step: swap_chem
+        gg.step += 1u;                                                                   // the agent object's call counter
+        // (the two-launch form's field kernel has left the next step's turn bits in the table; the three-launch form fills it itself)
+        pp.turn_ready = 1;
+    }
+    return DIE_OK;
+}
+
 // The action of the step that WROTE layout `lay`, re-derived from what that step left behind: a normalised PhysarumAgent
 // without momentum moves by scale·polar2xy(1, heading') (die_forward.h: ux += 0 after polar2xy, dx = ux·scale) and its
 // deposit went to p->dep — the same arithmetic on the same inputs, so the same bits as the action K1 would have stored.

@@ -563,6 +563,8 @@ class Env(_EnvBase):
                     agent._calls += K
                     done += K
                 self.last_result = out[done - 1] if done else self.last_result
+            if ok and not graph:
+                done += self._run_binned(agent, n_steps - done, out[done:])
             obs = self._get_current_obs
             for i in range(done, n_steps):
                 obs, res, *_ = self.step(agent.forward(obs))
@@ -572,6 +574,48 @@ class Env(_EnvBase):
         if sync:                        # (an env built with sync=True reads results back anyway: report a broken layout now)
             self.check()
         return out
+
+    def _run_binned(self, agent, n: int, results: torch.Tensor) -> int:
+        """The tile-binned two-launch steps of `run` as ONE library call (die_pic_run: a C loop over die_pic_forward_env_step — no
+        Python, no ctypes marshalling between two steps; SURVEY §8b's `die_step_fused(handle, n_steps)`).  Returns the number of steps
+        it took: 0 when this world / agent does not take the binned two-launch step (the caller's step loop does everything)."""
+        from types import SimpleNamespace
+        from .pic import PicState
+        if n <= 0 or self.dynamics.op_action_cost not in (linear_action_cost, zero_cost) or getattr(self, '_pic_events', None) is not None \
+                or getattr(self, '_pic_plan', None) is not None or (self.dynamics.agents_die and self.dynamics.compat == 'reference'):
+            return 0
+        if not self._pic_applies(SimpleNamespace(agent=agent)):
+            return 0
+        if _lib.lib.die_pic_two_launch(max(self._field_size), self._pic_tile[0], self._pic_tile[1], __import__('die_amd.pic', fromlist=['step_scale']).step_scale(agent),
+                                       float(self.dynamics.diffuse_sigma), 0) != 1 or not getattr(self, '_pic_fused', True):
+            return 0
+        if self._pic is not None:
+            self._pic.flush_lazy()
+        action = agent.forward(self._get_current_obs)                   # the first step's pending action: seed, step counter, state pointers
+        if not (isinstance(action, PendingAction) and action.pending):
+            return 0
+        if self._pic is None:
+            self._pic_n_alive = 0 if self._all_alive else int(self.agents.alive.sum().item())
+            if not self._all_alive and self._pic_n_alive == 0:
+                action.ensure()
+                return 0
+            self._pic = PicState(self, self._pic_tile)
+            if getattr(self, '_pic_k1_threads', 0):
+                self._pic.k1_threads = int(self._pic_k1_threads)
+            self._pic.lazy_actions = bool(getattr(self, '_pic_lazy_actions', True))
+        if not self._pic.is_current(self, agent):
+            self._pic.bin(self, agent)
+            action.rebind(self.agents)
+        _lib.check(self._pic.run(self, agent, action, self._c_dynamics(), results, n), 'die_pic_run')
+        agent._forward_consumed(action)
+        agent._calls += n - 1
+        if n & 1:
+            self.medium.swap_chem()
+        self.medium.owner_stale = self._mark_owner
+        self._steps += n
+        self.last_result = results[n - 1]
+        self.library_runs = getattr(self, 'library_runs', 0) + 1
+        return n
 
     @staticmethod
     def read_results(results: torch.Tensor) -> Tuple[np.ndarray, np.ndarray]:

@@ -296,6 +296,38 @@ class PicState:
             self._lazy_ref = agent._lazy_action = weakref.ref(action)
         return 0
 
+    def run(self, env, agent, action, dyn, results, n: int) -> int:
+        """`n` whole steps in ONE library call (die_pic_run): the loop of examples/minimal_run.py:23-25 without the host between two
+        steps.  `action`: the pending action of the first step (its g_struct carries seed and step counter); `results`: (n, 2) float64
+        on the device, one die_step_result per step.  No action is handed out, so the two layouts' slot arrays simply ping-pong —
+        in fresh arrays: actions handed out earlier keep referring to theirs."""
+        self.flush_lazy()
+        self._n_agents = int(env.agents.N)
+        self.agent_for_out = agent
+        out = self._out_tensors(env)
+        held = self.held[:3] + (self.held[3].clone(),) + self.held[4:]
+        g = action.g_struct
+        turn_key = (int(g.seed), int(g.step))
+        two = self.two_launch(env, agent)
+        p = self._struct(held, out, 0, None)
+        p.turn_ready = int(self._turn_for == turn_key)
+        p.sub_mode, p.sub_tx0, p.sub_ty0, p.sub_ntx, p.sub_nty, p.halo_fresh = 0, 0, 0, 0, 0, 0
+        m = env.medium.c_struct(need_owner=False)
+        rc = _lib.lib.die_pic_run(C.byref(m), C.byref(p), self.cur, C.byref(g), C.byref(dyn), int(n), _ptr(results), stream_ptr(env.device))
+        if rc != 0:
+            return rc
+        self._turn_for = (turn_key[0], (turn_key[1] + n) & 0xFFFFFFFF) if two and lazy_ok(agent) else None
+        self.steps_since_check += n
+        if n & 1:
+            self.held = held                                   # (what _adopt recycles as the next output buffers)
+            env.agents.slot = held[3]
+            self.cur = 1 - self.cur
+            self._adopt(env, agent, out)
+        else:                                                  # the agents are back in the arrays they started from (new slot array)
+            env.agents.slot = agent._order = held[3]
+            self.held = held
+        return 0
+
     def check(self):
         """After a synchronisation: did every agent stay within its tile's neighbourhood?"""
         e = int(self.error[0].item())

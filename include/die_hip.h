@@ -481,6 +481,13 @@ int die_pic_bin_momentum(const die_medium* m, const die_agents* a, const uint32_
  * mapped from one mapping of its own cell; else DIE_ERR_UNSUPPORTED). */
 int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from, die_gradient_agent* g, const die_action* act,
                              const die_dynamics* d, die_step_result* result, void* stream);
+/* n_steps x die_pic_forward_env_step(act = NULL) without the host in between — `for i in range(n): obs, ... = env.step(agent.forward(obs))`
+ * (examples/minimal_run.py:23-25) for a caller that reads nothing back on the way: step i reads layout[(from + i) & 1] and writes the
+ * other one, reads the chem plane step i - 1 wrote (m->chem and m->chem_next exchange roles every step: after an odd n_steps the
+ * current plane is m->chem_next), draws from (g->seed, g->step + i), and leaves its result in results[i].  p->stages = 0, no
+ * subset of the tiles; p->turn_ready as for the first step.  Same launches, same bits as n_steps separate calls. */
+int die_pic_run(const die_medium* m, const die_pic* p, int32_t from, const die_gradient_agent* g, const die_dynamics* d,
+                int32_t n_steps, die_step_result* results, void* stream);
 /* `act` of die_pic_forward_env_step may be NULL: the action then stays in registers.  For a normalised PhysarumAgent it can
  * still be produced afterwards — until the next step overwrites p->dep — from what the step left in layout[lay] (the layout it
  * WROTE): (dx, dy) = scale * polar2xy(1, heading'), deposit = p->dep; same bits as the action the step would have stored, in

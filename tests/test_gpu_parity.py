@@ -1644,6 +1644,66 @@ def test_graph_run_equals_step_loop(die, kind, sort_every):
     assert a_env._steps == b_env._steps and a_ag._calls == b_ag._calls
 
 
+@pytest.mark.parametrize('kind', ['physarum', 'gradient'])
+def test_run_of_tile_binned_steps_is_one_library_call(die, kind):
+    """Env.run on a world that takes the tile-binned two-launch step: the steps are ONE call of die_pic_run (a C loop over
+    die_pic_forward_env_step: layouts and chem planes exchange roles, the Philox step counter advances — SURVEY §8b's
+    `die_step_fused(handle, n_steps)`) and leave exactly what the step-by-step loop leaves — odd and even counts, plain steps in
+    between, an action handed out before a run and read after it, a GradientAgent's momentum state."""
+    W, H, N = 192, 256, 9000
+    rs = np.random.RandomState(33)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.3)
+    if kind == 'physarum':
+        mk = lambda: die.PhysarumAgent(max_agents=N, seed=3, scale=1.53 / (H - 1), sense_offset=10.2 / (H - 1))
+    else:
+        mk = lambda: die.GradientAgent(max_agents=N, seed=3, scale=0.6 / (H - 1), sense_offset=10.2 / (H - 1), inertia=0.9, noise_scale=0.025)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    prev = f32(rs.normal(0, .4, (2, N)))
+    envs, agts = [], []
+    for _ in range(2):
+        env = die.Env.from_numpy(medium, agents, sort_every=0, sync=False, pic=True)
+        env._pic_tile = (6, 6)
+        ag = mk()
+        ag.set_state(dir0, prev if kind == 'gradient' else None)
+        envs.append(env)
+        agts.append(ag)
+    a_env, a_ag = envs[0], agts[0]
+    obs = a_env._get_current_obs
+    act0 = a_ag.forward(obs)                                   # handed out before the runs, read after them
+    obs, res0, *_ = a_env.step(act0)
+    r1 = a_env.run(a_ag, 7)
+    assert a_env._pic is not None and a_env._pic.held[0] is a_env.agents.x and a_env._pic.steps_since_check >= 8
+    obs = a_env._get_current_obs
+    plain = []
+    for _ in range(3):
+        obs, res, *_ = a_env.step(a_ag.forward(obs))
+        plain.append(res.clone())
+    r3 = a_env.run(a_ag, 4)
+    r4 = a_env.run(a_ag, 1)
+    a_env.check()
+    got_rew, got_alive = die.Env.read_results(torch.cat([res0[None], r1, torch.stack(plain), r3, r4]))
+    b_env, b_ag = envs[1], agts[1]
+    obs = b_env._get_current_obs
+    want, b_act0 = [], None
+    for i in range(1 + 7 + 3 + 4 + 1):
+        act = b_ag.forward(obs)
+        obs, res, *_ = b_env.step(act)
+        if i == 0:
+            b_act0 = act.to_numpy()
+        want.append(b_env.read_result(res))
+    want = np.array(want)
+    assert np.array_equal(got_alive, want[:, 1].astype(np.int64)) and np.array_equal(got_rew, want[:, 0])
+    assert np.array_equal(act0.to_numpy(), b_act0)
+    assert np.array_equal(a_env.medium.to_numpy(), b_env.medium.to_numpy())
+    assert np.array_equal(a_env.agents.to_numpy(), b_env.agents.to_numpy())
+    assert np.array_equal(a_ag.direction_rads_numpy(), b_ag.direction_rads_numpy())
+    if kind == 'gradient':
+        assert np.array_equal(a_ag.prev_grad_numpy(), b_ag.prev_grad_numpy())
+    assert a_env._steps == b_env._steps and a_ag._calls == b_ag._calls
+    assert a_env.library_runs == 3                             # (every run was one die_pic_run call)
+
+
 def test_minimal_run_example(die):
     """The port of the reference's examples/minimal_run.py runs end to end (both agents)."""
     import importlib.util
