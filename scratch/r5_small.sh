@@ -1,0 +1,18 @@
+#!/bin/bash
+# small worlds: kernel averages of the classic step at 1024^2 and 256^2 with variant libraries
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+for v in "$@"; do
+  lib=$R/scratch/libs/libdie_$v.so; [ $v = hip ] && lib=$R/die_amd/libdie_hip.so
+  for size in 1024 256; do
+    d=$R/gpurun_out/sm_${v}_$size; rm -rf $d
+    DIE_AMD_LIB=$lib timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $R/bench.py --size $size --steps 300 --warmup 50 --no-cpu-baseline --no-extras --kernel-reps 1 > $d.json 2> $d.err || { echo "== $v $size FAILED"; tail -3 $d.err; continue; }
+    f=$(find $d -name "*kernel_stats.csv" | head -1)
+    echo "== $v $size: $(python3 -c "import json;d=json.load(open('$d.json'));print(d['value'], d['step_ms']['median'])")"
+    python3 - $f <<'PY'
+import csv,sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if any(k in r['Name'] for k in ('k_forward_move_claim','k_diffuse_rows')): print('    %-70s %6s calls %8.1f us' % (r['Name'][:70], r['Calls'], float(r['AverageNs'])/1e3))
+PY
+  done
+done
