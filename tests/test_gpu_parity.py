@@ -1644,7 +1644,7 @@ def test_graph_run_equals_step_loop(die, kind, sort_every):
     assert a_env._steps == b_env._steps and a_ag._calls == b_ag._calls
 
 
-@pytest.mark.parametrize('kind', ['physarum', 'gradient'])
+@pytest.mark.parametrize('kind', ['physarum', 'gradient', 'physarum with dead slots'])
 def test_run_of_tile_binned_steps_is_one_library_call(die, kind):
     """Env.run on a world that takes the tile-binned two-launch step: the steps are ONE call of die_pic_run (a C loop over
     die_pic_forward_env_step: layouts and chem planes exchange roles, the Philox step counter advances — SURVEY §8b's
@@ -1652,8 +1652,8 @@ def test_run_of_tile_binned_steps_is_one_library_call(die, kind):
     between, an action handed out before a run and read after it, a GradientAgent's momentum state."""
     W, H, N = 192, 256, 9000
     rs = np.random.RandomState(33)
-    medium, agents = random_state(W, H, N, N, rs, collide=0.3)
-    if kind == 'physarum':
+    medium, agents = random_state(W, H, N, N if 'dead' not in kind else 6000, rs, collide=0.3)      # (dead slots: the reference's default slot layout)
+    if kind.startswith('physarum'):
         mk = lambda: die.PhysarumAgent(max_agents=N, seed=3, scale=1.53 / (H - 1), sense_offset=10.2 / (H - 1))
     else:
         mk = lambda: die.GradientAgent(max_agents=N, seed=3, scale=0.6 / (H - 1), sense_offset=10.2 / (H - 1), inertia=0.9, noise_scale=0.025)
