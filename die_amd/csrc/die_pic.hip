@@ -131,9 +131,7 @@ template <> struct Vec4<__half> {
 #ifndef PIC_K2_BLOCK
 #define PIC_K2_BLOCK 512
 #endif
-#ifndef PIC_MAX_MARGIN
-#define PIC_MAX_MARGIN 24      // probe reach (cells) up to which K1 stages the chem tile in LDS (A/B: 0 = never: every tap a gather from L2)
-#endif
+#define PIC_MAX_MARGIN 24      // probe reach (cells) up to which K1 stages the chem tile in LDS
 #ifndef PIC_STAGE_FOOD
 #define PIC_STAGE_FOOD 1
 #endif
