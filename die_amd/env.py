@@ -586,23 +586,23 @@ class Env(_EnvBase):
             return 0
         if not self._pic_applies(SimpleNamespace(agent=agent)):
             return 0
-        if _lib.lib.die_pic_two_launch(max(self._field_size), self._pic_tile[0], self._pic_tile[1], __import__('die_amd.pic', fromlist=['step_scale']).step_scale(agent),
+        from .pic import step_scale
+        if _lib.lib.die_pic_two_launch(max(self._field_size), self._pic_tile[0], self._pic_tile[1], step_scale(agent),
                                        float(self.dynamics.diffuse_sigma), 0) != 1 or not getattr(self, '_pic_fused', True):
             return 0
-        if self._pic is not None:
-            self._pic.flush_lazy()
-        action = agent.forward(self._get_current_obs)                   # the first step's pending action: seed, step counter, state pointers
-        if not (isinstance(action, PendingAction) and action.pending):
-            return 0
+        if not (getattr(agent, 'lazy', False) and agent._turn_sign is None):
+            return 0                                                    # (forward() must hand out a PENDING action: nothing may run before the library call)
         if self._pic is None:
             self._pic_n_alive = 0 if self._all_alive else int(self.agents.alive.sum().item())
             if not self._all_alive and self._pic_n_alive == 0:
-                action.ensure()
-                return 0
+                return 0                                                # (nobody alive: nothing to bin)
             self._pic = PicState(self, self._pic_tile)
             if getattr(self, '_pic_k1_threads', 0):
                 self._pic.k1_threads = int(self._pic_k1_threads)
             self._pic.lazy_actions = bool(getattr(self, '_pic_lazy_actions', True))
+        self._pic.flush_lazy()
+        action = agent.forward(self._get_current_obs)                   # the first step's pending action: seed, step counter, state pointers
+        assert isinstance(action, PendingAction) and action.pending
         if not self._pic.is_current(self, agent):
             self._pic.bin(self, agent)
             action.rebind(self.agents)

@@ -319,8 +319,6 @@ class PicState:
         self._turn_for = (turn_key[0], (turn_key[1] + n) & 0xFFFFFFFF) if two and lazy_ok(agent) else None
         self.steps_since_check += n
         if n & 1:
-            self.held = held                                   # (what _adopt recycles as the next output buffers)
-            env.agents.slot = held[3]
             self.cur = 1 - self.cur
             self._adopt(env, agent, out)
         else:                                                  # the agents are back in the arrays they started from (new slot array)
