@@ -29,8 +29,13 @@ __global__ __attribute__((amdgpu_waves_per_eu(1, WAVES_MAX))) void k_turn(unsign
         const size_t base = (size_t)blockIdx.x * vec_per_wg;
         uint4 acc = make_uint4(0, 0, 0, 0);
         for (int i = threadIdx.x; i < vec_per_wg; i += blockDim.x) { const uint4 v = src[base + i]; acc.x ^= v.x; acc.y += v.y; acc.z ^= v.z; acc.w += v.w; }
+#ifdef STORES_FIRST           // the stores go out BEFORE the spin: nothing is outstanding when the workgroup ends
+        for (int i = threadIdx.x; i < vec_per_wg; i += blockDim.x) dst[base + i] = acc;
+        while ((long long)(rt() - t0) < ticks) __builtin_amdgcn_s_sleep(4);
+#else
         while ((long long)(rt() - t0) < ticks) __builtin_amdgcn_s_sleep(4);
         for (int i = threadIdx.x; i < vec_per_wg; i += blockDim.x) dst[base + i] = acc;
+#endif
     } else {
         while ((long long)(rt() - t0) < ticks) __builtin_amdgcn_s_sleep(4);
     }
