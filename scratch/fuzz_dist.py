@@ -77,7 +77,8 @@ def worker(rank, size, port, case, out):
         from die_amd.dist import DistEnv
         medium, agents, dir0, prev, dyn = build(case, die_amd)
         env = DistEnv.from_global_numpy(medium, agents, case['grid'], dyn, probe_reach=int(np.ceil(max(6.2 / (case['W'] - 1), 0.03) * (max(case['W'], case['H']) - 1))), device='cuda:0', sort_every=case['sort_every'],
-                                        capacity=case['N'] * int(os.environ.get('FUZZ_CAP_MULT', '1')) + 64,      # (FUZZ_CAP_MULT=8: room for the refresh in place) migrate_every=case['migrate_every'], ghosts=case.get('ghosts', False),
+                                        capacity=case['N'] * int(os.environ.get('FUZZ_CAP_MULT', '1')) + 64,      # (FUZZ_CAP_MULT=8: room for the refresh in place)
+                                        migrate_every=case['migrate_every'], ghosts=case.get('ghosts', False),
                                         max_step_cells=max(1.53 / (case['W'] - 1), 0.01 * 1.5) * (max(case['W'], case['H']) - 1) + 0.5)
         ag = make_agent(case, die_amd, env.capacity)
         if case['agent'] != 'brownian':
@@ -88,12 +89,19 @@ def worker(rank, size, port, case, out):
                 p = torch.zeros((2, env.capacity), dtype=torch.float32, device='cuda:0'); p[:, :env.agents.N] = torch.from_numpy(prev.astype(np.float32)).cuda()[:, sl]
             ag.set_state_local(env.agents, d, p)
         obs = env._get_current_obs
-        for _ in range(case['steps']):
-            obs, res = env.step(ag.forward(obs))
+        mat = np.random.RandomState(case['seed'] + 77).rand(case['steps']) < float(os.environ.get('FUZZ_MATERIALISE', '0'))
+        for i in range(case['steps']):
+            act = ag.forward(obs)
+            if mat[i] and case['agent'] != 'brownian':      # (FUZZ_MATERIALISE=p: the caller reads the action before the step, with probability p)
+                act.to_numpy()
+            obs, res = env.step(act)
         world = env.gather_world()
+        if hasattr(env, 'check'):
+            env.check()
         if rank == 0:
             np.savez(out, medium=world[0], agents=world[1], pic_steps=getattr(env, 'pic_steps', 0), plane=np.array([env.geo.W, env.geo.H]),
-                     inplace=getattr(env, 'inplace_refreshes', 0), tile_refreshes=getattr(env, 'tile_refreshes', 0))
+                     inplace=getattr(env, 'inplace_refreshes', 0), tile_refreshes=getattr(env, 'tile_refreshes', 0), early=getattr(env, 'early_packs', 0),
+                     overlapped=getattr(env, 'overlapped_refreshes', 0))
     finally:
         dist.destroy_process_group()
 
@@ -121,7 +129,7 @@ if __name__ == '__main__':
                 assert np.abs(got['agents'][:2] - a[:2]).max() == 0
             assert np.array_equal(got['agents'], a), 'agents'
             assert np.array_equal(got['medium'], m), 'medium'
-            print('ok  ', case, 'binned steps', int(got['pic_steps']), 'plane', got['plane'].tolist(), 'refreshes by tiles', int(got['tile_refreshes']), 'in place', int(got['inplace']), flush=True)
+            print('ok  ', case, 'binned steps', int(got['pic_steps']), 'plane', got['plane'].tolist(), 'refreshes by tiles', int(got['tile_refreshes']), 'in place', int(got['inplace']), 'packed early', int(got['early']), 'overlapped', int(got['overlapped']), flush=True)
         except Exception as e:
             fails += 1; print('FAIL', case, type(e).__name__, str(e)[-400:].replace(chr(10), ' | '), flush=True)
     print(f'fuzz dist: {fails} failures', flush=True)
