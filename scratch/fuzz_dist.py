@@ -14,8 +14,13 @@ def make_case(seed):
     if PIC:
         grid = [(1, 2), (2, 1), (2, 2), (1, 3), (1, 1)][rs.randint(5)]
         Wi = int(rs.choice([128, 192, 256])); Hi = int(rs.choice([128, 192, 256]))
+        if os.environ.get('FUZZ_BIG') == '1':             # planes that take the 64x64 tiles of the headline world
+            grid = [(1, 2), (2, 1), (2, 2)][rs.randint(3)]
+            Wi = int(rs.choice([512, 640, 768])); Hi = int(rs.choice([512, 640, 1024]))
         W, H = Wi * grid[0], Hi * grid[1]
         N = int(rs.choice([4000, 20000, 60000]))
+        if os.environ.get('FUZZ_BIG') == '1':
+            N = int(W * H * rs.choice([0.02, 0.15]))
         me = int(rs.choice([1, 2, 3]))
         reach = int(np.ceil(max(6.2 / (W - 1), 0.03) * (max(W, H) - 1)))
         loss = reach + 1 + int(np.ceil(max(1.53 / (W - 1), 0.01 * 1.5) * (max(W, H) - 1) + 0.5)) + 2
@@ -100,7 +105,7 @@ def worker(rank, size, port, case, out):
             env.check()
         if rank == 0:
             np.savez(out, medium=world[0], agents=world[1], pic_steps=getattr(env, 'pic_steps', 0), plane=np.array([env.geo.W, env.geo.H]),
-                     inplace=getattr(env, 'inplace_refreshes', 0), tile_refreshes=getattr(env, 'tile_refreshes', 0), early=getattr(env, 'early_packs', 0),
+                     inplace=getattr(env, 'inplace_refreshes', 0), tile_refreshes=getattr(env, 'tile_refreshes', 0), early=getattr(env, 'early_packs', 0), tile=np.array(env._pic_tile if getattr(env, '_pic_tile', None) else [0, 0]),
                      overlapped=getattr(env, 'overlapped_refreshes', 0))
     finally:
         dist.destroy_process_group()
@@ -129,7 +134,7 @@ if __name__ == '__main__':
                 assert np.abs(got['agents'][:2] - a[:2]).max() == 0
             assert np.array_equal(got['agents'], a), 'agents'
             assert np.array_equal(got['medium'], m), 'medium'
-            print('ok  ', case, 'binned steps', int(got['pic_steps']), 'plane', got['plane'].tolist(), 'refreshes by tiles', int(got['tile_refreshes']), 'in place', int(got['inplace']), 'packed early', int(got['early']), 'overlapped', int(got['overlapped']), flush=True)
+            print('ok  ', case, 'binned steps', int(got['pic_steps']), 'plane', got['plane'].tolist(), 'refreshes by tiles', int(got['tile_refreshes']), 'in place', int(got['inplace']), 'packed early', int(got['early']), 'overlapped', int(got['overlapped']), 'tile', got['tile'].tolist(), flush=True)
         except Exception as e:
             fails += 1; print('FAIL', case, type(e).__name__, str(e)[-400:].replace(chr(10), ' | '), flush=True)
     print(f'fuzz dist: {fails} failures', flush=True)
