@@ -55,6 +55,13 @@ def make_case(seed):
     return dict(grid=grid, W=W, H=H, N=N, K=K, agent=str(agent), boundary=str(boundary), agents_die=die, steps=8, migrate_every=me,
                 sort_every=int(rs.choice([0, 2])), seed=seed)
 
+_make_case = make_case
+def make_case(seed):                    # FUZZ_STEPS=n: long runs (many refreshes on the same layouts)
+    case = _make_case(seed)
+    if os.environ.get('FUZZ_STEPS'):
+        case['steps'] = int(os.environ['FUZZ_STEPS'])
+    return case
+
 def build(case, die_amd):
     from tests.test_gpu_parity import random_state, f32
     rs = np.random.RandomState(case['seed'] + 1000)
