@@ -227,7 +227,11 @@ __global__ __launch_bounds__(1024) void k_pic_ghost_scan(RfArgs a) {
                 bool in;
                 const uint32_t c = count(t, in);
                 if (in != (pass == 0)) continue;
-                a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+                // (a segment that would end behind the arrays is published EMPTY — the capacity flag below is raised for it —: with the
+                // refresh under the next step, that step's kernels are queued before the host reads the flag and must never index past
+                // the arrays' end)
+                const bool fits = (unsigned long long)run + c <= (unsigned long long)a.capacity;
+                a.dst.off[t] = fits ? run : 0u; a.dst.n[t] = fits ? c : 0u; a.dst.s[t] = fits ? c : 0u; a.dst.inc[t] = 0;
                 run += c;
             }
         }
@@ -339,7 +343,8 @@ __global__ __launch_bounds__(1024) void k_pic_ghost_scan_inplace(RfArgs a) {
         uint32_t run = block_scan(own_sum, own_total) - own_sum;
         each([&](int t, int kd, uint32_t c, uint32_t) {
             if (kd != 1) return;
-            a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+            const bool fits = (unsigned long long)run + c <= (unsigned long long)a.capacity;
+            a.dst.off[t] = fits ? run : 0u; a.dst.n[t] = fits ? c : 0u; a.dst.s[t] = fits ? c : 0u; a.dst.inc[t] = 0;
             run += c;
         });
         if (threadIdx.x == 0) {
@@ -354,7 +359,8 @@ __global__ __launch_bounds__(1024) void k_pic_ghost_scan_inplace(RfArgs a) {
     uint32_t run = own_total + block_scan(halo_sum, halo_total) - halo_sum;
     each([&](int t, int kd, uint32_t c, uint32_t) {
         if (kd != 0) return;
-        a.dst.off[t] = run; a.dst.n[t] = c; a.dst.s[t] = c; a.dst.inc[t] = 0;
+        const bool fits = (unsigned long long)run + c <= (unsigned long long)a.capacity;        // (else EMPTY: see k_pic_ghost_scan)
+        a.dst.off[t] = fits ? run : 0u; a.dst.n[t] = fits ? c : 0u; a.dst.s[t] = fits ? c : 0u; a.dst.inc[t] = 0;
         run += c;
     });
     const uint32_t room_incl = block_scan(room_sum, room_total);
@@ -397,6 +403,18 @@ __global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_halo(RfArgs a) {
     int i;
     const int k = rf_halo_side(a, tx, ty, i);
     uint32_t c = 0;
+    // A new segment that would end behind the arrays is not laid at all: the tile is left EMPTY (off = s = n = 0), so that the step's
+    // kernels — which are already queued behind this one when the host reads the flag — never index past the arrays' end.  (Round 5's
+    // development build bounded the stores below but still published off = tail[t], s, n for such a tile: the agent kernel of the step
+    // that followed then read x[tail[t] + i] beyond the allocation — the memory fault of gpurun_out/r5_t8.log)
+    {
+        uint32_t c_in = 0;
+        if (k >= 0) { c_in = a.side[k].recv_counts[i]; if (c_in > a.side[k].cap) c_in = 0; }
+        if ((unsigned long long)base + c_in + (n_old - s_old) > (unsigned long long)capacity) {
+            if (threadIdx.x == 0) { rf_flag(a, RF_FLAG_CAPACITY); L.off[t] = 0; L.s[t] = 0; L.n[t] = 0; }
+            return;
+        }
+    }
     if (k >= 0) {
         const RfSide& S = a.side[k];
         const uint32_t* counts = S.recv_counts;

@@ -123,7 +123,10 @@ class DeviceMedium:
         return False
 
     def sel(self, channel: str) -> torch.Tensor:
-        self.sensed()
+        # (No `sensed()` here: on a decomposed rank the hook is a COLLECTIVE ghost refresh, and sel() / to_numpy() are what a
+        # rank-local observer calls — `if rank == 0: env.medium.to_numpy()` must not start an exchange its peers do not join.
+        # The cells a rank owns are right without a refresh; whoever wants fresh halos calls DistEnv.flush_refresh() on every
+        # rank, as gather_world(), the stand-alone forward and the NCA sensing do.  ADVICE r5.)
         if channel == 'agents':
             return self.occupied().to(torch.float32)
         if channel == 'env_food':

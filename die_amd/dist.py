@@ -923,6 +923,23 @@ class DistEnv:
             return False
         return pic.is_current(self, pic.agent)
 
+    def _inplace_room(self, n: int, P) -> bool:
+        """Is there surely room behind the arrays' old end for the halo tiles' new segments of a refresh in place?  The new
+        segments hold what arrives (at most the messages' capacities) plus the agents the halo tiles hold today: the ghosts of
+        the previous refresh (n − owned; n does not change between two refreshes) plus the owned agents that have drifted into
+        the halo since — those stood in the bands then (a halo is as wide as `migrate_every` steps reach, the ghost mode's own
+        precondition), so they are at most what the previous refresh SENT (the message capacities while that is unknown).  The
+        owned count of the previous refresh alone was no bound.  `DIE_REFRESH_IN_PLACE_FORCE=1` skips the test
+        (tests only: it sends a refresh that does not fit through the kernels' own capacity guards, RF_FLAG_CAPACITY)."""
+        if os.environ.get('DIE_REFRESH_IN_PLACE_FORCE', '0') == '1':
+            return True
+        owned = self._owned
+        ghosts = n if owned is None else max(n - int(owned), 0)
+        drift = self.__dict__.get('_sent_prev')
+        if drift is None:
+            drift = sum(P.caps)
+        return n + sum(P.caps) + ghosts + int(drift) <= self.capacity
+
     def _build_tile_plan(self):
         from types import SimpleNamespace
         lib, g, dev, pic = self._lib, self.geo, self.device, self._pic
@@ -1077,7 +1094,7 @@ class DistEnv:
                       'die_pic_ghost_merge')
             self._tick('new layout (scan, merge, words)')
             adopt_new_layout()
-        elif self._refresh_in_place and n + sum(P.caps) + max(n - int(getattr(self, '_owned', 0) or 0), 0) <= self.capacity:
+        elif self._refresh_in_place and self._inplace_room(n, P):
             # (… when the halo tiles' new segments surely fit behind the arrays' old end: what can arrive + the old halo agents)
             # IN PLACE (round 5): the step that follows reads the layout the step before left (interior tiles: stayers + leavers where
             # they are — the agent kernel gathers a tile's agents from there anyway; nothing is copied, where the merge rewrote every
@@ -1140,6 +1157,7 @@ class DistEnv:
         if n_new > n:                                      # every slot is alive on this path; readers (gather_world) look at the bytes
             A.alive[n:n_new] = 1
         self._owned = kept
+        self._sent_prev = int(sum(sent))                   # (bounds the drift into the halo until the next refresh: _inplace_room)
         if nd:
             self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))
         A.N = n_new
@@ -1262,10 +1280,12 @@ class DistEnv:
         if n_new > self.capacity:
             raise RuntimeError(f'rank {comm.rank}: {n_new} agents (ghosts included) exceed the local capacity {self.capacity}')
         self._owned = kept
+        self._sent_prev = int(sum(sent))
         if nd:
             self.ghost_fill = max(getattr(self, 'ghost_fill', 0.0), max(max(sent[k], arrived[k]) / P.caps[k] for k in range(nd)))
         A.N = n_new
-        action.N = n_new
+        if action is not None:                 # (None: a refresh that had been left for the next step, done by flush_refresh)
+            action.N = n_new
         self._ghosts_fresh = True
 
     # -- the same refresh written with torch index operations (cross-check of the native path: DIE_GHOST_REFRESH=torch) --
@@ -1291,6 +1311,7 @@ class DistEnv:
         matrix = comm.all_gather_counts(counts)                # host: matrix[rank] = (per-side counts…, owned)
         self._tick('count all_gather')
         self._owned = int(matrix[comm.rank, -1])
+        self._sent_prev = int(matrix[comm.rank, :-1].sum())
         owned_world = int(matrix[:, -1].sum())
         if owned_world != self.world_agents:
             raise RuntimeError(f'ghost refresh: {owned_world} agents are owned, the world has {self.world_agents}: an agent moved '
@@ -1337,7 +1358,8 @@ class DistEnv:
             lib.check(lib.lib.die_records_scatter(ptrs, esz, len(arrs), C.c_void_p(arr_dst.data_ptr()), n_arr,
                                                   C.c_void_p(arrivals.data_ptr()), sp), 'die_records_scatter')
         A.N = n_new
-        action.N = n_new
+        if action is not None:
+            action.N = n_new
         self._tick('compaction + scatter')
         if nd:
             halo_exchange([self.medium.chem, self.medium.food], g, comm, self._plans)

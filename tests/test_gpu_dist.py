@@ -39,7 +39,7 @@ def _wave_dynamics(die_amd, W, H, kind=True):
 
 
 def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migrate_every, out_path, backend='gloo', ghosts=False,
-            wave=False, f16=False, read_actions=False, materialise_at=(), capacity=None):
+            wave=False, f16=False, read_actions=False, materialise_at=(), capacity=None, final=None, expect_error=None):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -55,6 +55,9 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         dev = f'cuda:{rank}'
         torch.cuda.set_device(rank)
         dist.init_process_group('nccl', rank=rank, world_size=size, device_id=torch.device(dev))
+    elif expect_error is not None:   # (a rank that did NOT fail would wait for its dead peers: bounded)
+        import datetime
+        dist.init_process_group('gloo', rank=rank, world_size=size, timeout=datetime.timedelta(seconds=240))
     else:
         dist.init_process_group('gloo', rank=rank, world_size=size)
     try:
@@ -62,10 +65,16 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         from die_amd.dist import DistEnv
         medium, agents, dir0 = _state(W, H, N, K, 5)
         kw = dict(scale=1.53 / (W - 1), sense_offset=10.2 / (W - 1), sense_angle=100)
-        env = DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H, wave) if wave else None, probe_reach=11,
-                                        device=dev, sort_every=sort_every,
-                                        overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
-                                        field_dtype=torch.float16 if f16 else torch.float32, **({'capacity': capacity} if capacity else {}))
+        def make(cap_):
+            return DistEnv.from_global_numpy(medium, agents, grid, _wave_dynamics(die_amd, W, H, wave) if wave else None, probe_reach=11,
+                                             device=dev, sort_every=sort_every,
+                                             overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
+                                             field_dtype=torch.float16 if f16 else torch.float32, **({'capacity': cap_} if cap_ else {}))
+        if capacity == 'tight':              # arrays that hold the agents a rank starts with and a few entries more — on every rank
+            n0 = torch.tensor([make(None).agents.N], dtype=torch.int64)
+            dist.all_reduce(n0, op=dist.ReduceOp.MAX)
+            capacity = int(n0.item()) + 16
+        env = make(capacity)
         cap = env.capacity
         agent = die_amd.PhysarumAgent(max_agents=cap, seed=9, **kw)
         local = torch.zeros(cap, dtype=torch.float32, device=dev)
@@ -73,17 +82,29 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
         agent.set_state_local(env.agents, local)
         obs = env._get_current_obs
         rewards = []
-        for i in range(steps):
-            act = agent.forward(obs)
-            if i in materialise_at:          # the stand-alone forward runs NOW, on what the rank holds now (a ghost refresh
-                act.to_numpy()               # that was left for this step has to happen first — the halos are past their window)
-            obs, res = env.step(act)
-            rewards.append(env.read_result(res))
-            if read_actions:                 # the binned step kept it in registers: re-derived from what the step left behind
-                a = act.to_numpy()
-                assert a.shape[0] == 3 and np.isfinite(a).all()
+        try:
+            for i in range(steps):
+                act = agent.forward(obs)
+                if i in materialise_at:      # the stand-alone forward runs NOW, on what the rank holds now (a ghost refresh
+                    act.to_numpy()           # that was left for this step has to happen first — the halos are past their window)
+                obs, res = env.step(act)
+                rewards.append(env.read_result(res))
+                if read_actions:             # the binned step kept it in registers: re-derived from what the step left behind
+                    a = act.to_numpy()
+                    assert a.shape[0] == 3 and np.isfinite(a).all()
+        except RuntimeError as e:
+            if expect_error is None or expect_error not in str(e):
+                raise
+            torch.cuda.synchronize()         # (whatever was queued behind the refresh has run: no fault)
+            np.savez(f'{out_path}.rank{rank}.npz', error=str(e), step=i, inplace=getattr(env, 'inplace_refreshes', 0))
+            return
+        if expect_error is not None:
+            raise AssertionError(f'rank {rank}: the run was expected to fail with "{expect_error}"')
         if ghosts and env._all_alive:       # every local entry is alive, also those a refresh appended beyond the old count
             assert bool(env.agents.alive[:env.agents.N].all())
+        if final == 'sort':                  # the tile order is voided while a refresh is still waiting for the next step
+            assert env._refresh_due, 'the run was meant to end on a deferred refresh'
+            env.sort_agents()
         world = env.gather_world()
         if hasattr(env, 'check'):
             env.check()
@@ -260,6 +281,51 @@ def test_action_materialised_before_the_step_that_follows_a_deferred_refresh(tmp
     for c in range(3):
         assert np.array_equal(got['medium'][c], m[c])
     assert np.array_equal(got['rewards'], r)
+
+
+@pytest.mark.parametrize('grid,refresh_every', [((1, 2), 3), ((2, 2), 2)])
+def test_deferred_refresh_then_sort_then_gather(tmp_path, grid, refresh_every):
+    """A run that ENDS on a refresh left for the next step, then sort_agents() (which voids the tile order), then gather_world(): the
+    flushed refresh goes agent by agent (native path) with no action to re-count.  ADVICE r5: `action.N = n_new` on None."""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    W, H, N = 384, 256, 12000
+    steps = 2 * refresh_every                # (the last step is followed by a refresh, which overlap defers)
+    out = str(tmp_path / 'dist.npz')
+    size = grid[0] * grid[1]
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, True, refresh_every, out, 'gloo', True, False, False, False, (),
+                            None, 'sort'), nprocs=size, join=True)
+    got = np.load(out)
+    m, a, r = _single_device_run(W, H, N, N, steps, False, False)
+    assert np.array_equal(got['agents'], a)
+    for c in range(3):
+        assert np.array_equal(got['medium'][c], m[c])
+    assert np.array_equal(got['rewards'], r)
+
+
+@pytest.mark.parametrize('grid,refresh_every', [((2, 2), 2), ((1, 2), 2)])
+def test_refresh_in_place_out_of_room_fails_cleanly_on_every_rank(tmp_path, monkeypatch, grid, refresh_every):
+    """The ghost refresh in place (die_pic_ghost_inplace) with arrays a few entries longer than the agents they hold — the host's
+    own test of the room switched off (DIE_REFRESH_IN_PLACE_FORCE=1) so that the KERNELS' guards are what is exercised: the halo
+    tiles' new segments do not fit behind the arrays' old end, the scan raises RF_FLAG_CAPACITY, no halo tile is laid past the end
+    (such a tile is published empty), the step queued behind the refresh runs without touching memory beyond the arrays, and
+    every rank raises the same clean RuntimeError.  (Round 5's development build faulted here on one rank while another raised:
+    gpurun_out/r5_t8.log)"""
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import torch.multiprocessing as mp
+    monkeypatch.setenv('DIE_REFRESH_IN_PLACE_FORCE', '1')
+    W, H, N, steps = 384, 256, 12000, 6
+    out = str(tmp_path / 'dist.npz')
+    size = grid[0] * grid[1]
+    mp.spawn(_worker, args=(size, _free_port(), grid, W, H, N, N, steps, 0, True, refresh_every, out, 'gloo', True, False, False, False, (),
+                            'tight', None, 'do not fit the local arrays'), nprocs=size, join=True)
+    for rank in range(size):
+        got = np.load(f'{out}.rank{rank}.npz')
+        assert 'do not fit the local arrays' in str(got['error'])
+        assert int(got['step']) == refresh_every           # the step that carried the first deferred refresh
+        assert int(got['inplace']) == 1                    # … which took the in-place path
 
 
 @pytest.mark.parametrize('ghosts,migrate_every', [(True, 3), (False, 1), (False, 4)])
