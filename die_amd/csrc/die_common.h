@@ -22,6 +22,14 @@ void die_set_error(const char* fmt, ...);
         }                                           \
     } while (0)
 
+// The three words of a step's result (reward, num_alive, status) may live in pinned HOST memory that the caller polls while the
+// kernel that writes them is still running (Env(sync=True): include/die_hip.h die_host_device_pointer).  Written as system-scope
+// atomic stores (write-through, `sc0 sc1`), so that their visibility to the host does not rest on the allocation being
+// fine-grained / uncached or on the kernel's end; the host waits for each word's sentinel on its own, so no order between them is
+// needed and no fence is issued (a release fence here would write back the XCD's whole L2 in the middle of the field kernel).
+__device__ __forceinline__ void die_store_result_f64(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void die_store_result_i64(long long* p, long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+
 #define DIE_CHECK_LAUNCH(name)                                                        \
     do {                                                                              \
         hipError_t e_ = hipGetLastError();                                            \

@@ -441,7 +441,10 @@ __global__ __launch_bounds__(DIF_BLOCK) void k_diffuse_rows(RowsArgs a) {
             }
             cnt = s_c[0];
         }
-        if (threadIdx.x == 0) { a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = a.part_alive ? cnt : a.alive_const; }
+        if (threadIdx.x == 0) {
+            die_store_result_f64(&a.result->reward, (double)s_g[0] / DIE_FIX_ONE);
+            die_store_result_i64((long long*)&a.result->num_alive, a.part_alive ? cnt : a.alive_const);
+        }
         return;
     }
     const T* src = (const T*)a.src;

@@ -1049,8 +1049,8 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
                 __syncthreads();
             }
             if (threadIdx.x == 0) {
-                a.result->reward = (double)s_g[0] / DIE_FIX_ONE; a.result->num_alive = alive;
-                if (a.status_out) *a.status_out = (long long)*a.error;     // (set by the agent kernel: a kernel boundary lies in between)
+                die_store_result_f64(&a.result->reward, (double)s_g[0] / DIE_FIX_ONE); die_store_result_i64((long long*)&a.result->num_alive, alive);
+                if (a.status_out) die_store_result_i64(a.status_out, (long long)*a.error);     // (set by the agent kernel: a kernel boundary lies in between)
             }
         } else if (blockIdx.x >= 2 && a.turn_bits) {        // the rest of the row: the next step's turn bits (this step's agent kernel is done with the table)
             pic_turn_bits_fill(a.turn_bits, a.turn_words, a.turn_seed, a.turn_step, (int64_t)(blockIdx.x - 2) * BLOCK + threadIdx.x,

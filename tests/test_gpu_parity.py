@@ -167,6 +167,28 @@ def physarum_margins(agent_ref, agents, medium, dir0, W, H):
     return np.minimum.reduce([m_cell, m_clip, m_turn, m_sense, m_pi, m_zero])
 
 
+def gradient_margins(agent_ref, agents, medium, dir0, W, H):
+    """The same for a GradientAgent (core/agent/gradient.py:96-124): the probe's cell rounding and the gradient clip are its only
+    float thresholds."""
+    off = np.stack(R.polar2xy(agent_ref._sense_offset_scale, dir0))
+    fx = (agents[0] + off[0]) * (W - 1) + 0.5
+    fy = (agents[1] + off[1]) * (H - 1) + 0.5
+    m_cell = np.minimum(np.abs(fx - np.round(fx)), np.abs(fy - np.round(fy)))
+    grad = np.stack(np.gradient(medium[R.M_CHEM]))
+    g = grad[:, R.cell(agents[0] + off[0], W), R.cell(agents[1] + off[1], H)]
+    m_clip = np.abs(np.hypot(g[0], g[1]) - agent_ref._grad_clip) / max(agent_ref._grad_clip, 1e-30)
+    return np.minimum(m_cell, m_clip)
+
+
+def assert_forward_mismatches_explained(bad, margins, N, what=''):
+    """The rule of test_physarum_forward_parity, for every test that compares a device forward with the oracle's: at most 1e-4 of
+    the slots (3 in small worlds) may disagree, and each of them must sit within 1e-4 of one of the forward's float thresholds
+    (core/agent/gradient.py:168-193: the decisions the reference takes in float64 on values the device holds in float32)."""
+    bad = np.asarray(bad)
+    assert (margins[bad] < 1e-4).all(), f'{what}unexplained forward mismatches: slots {np.nonzero(bad)[0][:20]}, margins {margins[bad][:20]}'
+    assert bad.sum() <= max(3, 1e-4 * N), f'{what}forward differs for {bad.sum()} of {N} slots'
+
+
 @pytest.mark.parametrize('W,H,N', [(16, 12, 50), (64, 64, 3000), (200, 333, 40000), (2, 2, 7), (1024, 1024, 200000)])
 @pytest.mark.parametrize('cfg', ['default', 'wide'])
 def test_physarum_forward_parity(die, W, H, N, cfg):
@@ -539,7 +561,13 @@ def _binned_steps_against_the_oracle(die, medium, agents, dyn, tile, agent_kind,
         got_action = action.to_numpy()
         # atol: sin/cos of a heading at a zero crossing carry the f32 angle rounding (~2e-7 rad) x scale
         bad = ~np.isclose(got_action, want_action, rtol=max(RTOL, frtol), atol=1e-6 * abs(kw['scale']) + (1e-3 if f16 else 0)).all(axis=0)
-        assert bad.mean() < 2e-3, f'step {step}: forward differs for {bad.sum()} of {N} slots'
+        if kw.get('noise_scale', 0) != 0 or momentum:
+            # (momentum: the mismatching slots' _prev_grad is compared above; noise: the oracle draws the device's own Philox normals)
+            assert bad.mean() < 2e-3, f'step {step}: forward differs for {bad.sum()} of {N} slots'
+        else:
+            # the strict rule of the stand-alone forward's test: few, and each explained by a float threshold
+            margins = (physarum_margins if agent_kind == 'physarum' else gradient_margins)(ref, a0, m0, d0, W, H)
+            assert_forward_mismatches_explained(bad, margins, N, f'step {step}: ')
         _, want_reward, want_term, _, want_info = renv.step(applied(got_action))
         ga, gm = env.agents.to_numpy(), env.medium.to_numpy()
         if dyn.boundary == die.BoundaryCondition.limit:     # 1.0 is stored as 1 − 2^-32
@@ -628,7 +656,8 @@ def test_configs2_full_size_teacher_forced_step_vs_oracle(die):
         ref._calls += 1                                     # (the Philox step counter of the oracle's agent keeps pace)
     assert env._pic is not None and env._pic.held[0] is env.agents.x and env._pic.two_launch(env, dev)
     m0, a0 = env.medium.to_numpy(), env.agents.to_numpy()
-    ref._direction_rads = dev.direction_rads_numpy()
+    d0 = dev.direction_rads_numpy()
+    ref._direction_rads = d0.copy()
     rd = R.RefDynamics(rate_feed=float(np.float32(0.1)), rate_decay_chem=float(np.float32(0.1)), diffuse_sigma=0.5)
     renv = R.RefEnv(m0, a0, rd)
     want_action = ref.forward(renv.obs)
@@ -637,7 +666,7 @@ def test_configs2_full_size_teacher_forced_step_vs_oracle(die):
     reward, num_agents = env.read_result(res)
     got_action = action.to_numpy()
     bad = ~np.isclose(got_action, want_action, rtol=RTOL, atol=1e-6 * kw['scale']).all(axis=0)
-    assert bad.mean() < 1e-3, f'forward differs for {bad.sum()} of {N} slots'
+    assert_forward_mismatches_explained(bad, physarum_margins(ref, a0, m0, d0, W, H), N)      # (the stand-alone forward's strict rule)
     _, want_reward, _, _, want_info = renv.step(applied(got_action))
     ga = env.agents.to_numpy()
     assert np.array_equal(ga[:3], renv.agents[:3])
