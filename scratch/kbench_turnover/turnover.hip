@@ -64,6 +64,8 @@ int main(int argc, char** argv) {
     unsigned long long s0 = ~0ull, e1 = 0; double life = 0;
     for (int i = 0; i < nwg; ++i) { s0 = std::min(s0, h[2 * i]); e1 = std::max(e1, h[2 * i + 1]); life += (double)(h[2 * i + 1] - h[2 * i]); }
     const double dur = (double)(e1 - s0) * 0.01, mean = life / nwg * 0.01, inflight = life * 0.01 / dur;
+    if (nwg % slots == 0)      // whole rounds: every slot turns over nwg / slots − 1 times, no partial last round in the average
+        printf("   WHOLE ROUNDS (%d): span / rounds - life = %.2f us per turnover (incl. 1/rounds of the launch ramp)\n", nwg / slots, dur / (nwg / slots) - mean);
     printf("%d stream(s): nwg %d x %d threads, %d B LDS, spin %d us, %d KB in + out per workgroup: launch %.1f us, life mean %.2f us, %.0f workgroups in flight on average of %d slots "
            "(%.0f %%), gap per turnover %.2f us\n", ns, nwg, threads, lds, us, kb, dur, mean, inflight, slots, 100.0 * inflight / slots, mean * (slots / inflight - 1.0));
     return 0;

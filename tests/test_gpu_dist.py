@@ -71,7 +71,10 @@ def _worker(rank, size, port, grid, W, H, N, K, steps, sort_every, overlap, migr
                                              overlap=overlap, migrate_every=migrate_every, max_step_cells=1.6, ghosts=ghosts,
                                              field_dtype=torch.float16 if f16 else torch.float32, **({'capacity': cap_} if cap_ else {}))
         if capacity == 'tight':              # arrays that hold the agents a rank starts with and a few entries more — on every rank
-            n0 = torch.tensor([make(None).agents.N], dtype=torch.int64)
+            probe = make(None)
+            probe._refresh_ghosts(None, after_step=True)      # (collective: the ghosts a rank holds from its first refresh on)
+            n0 = torch.tensor([probe.agents.N], dtype=torch.int64)
+            del probe
             dist.all_reduce(n0, op=dist.ReduceOp.MAX)
             capacity = int(n0.item()) + 16
         env = make(capacity)
