@@ -185,6 +185,11 @@ struct PicArgs {
     const uint4* dd_geo;
     const uint32_t* dd_win;
     uint32_t* dd_wout;
+    // an ORDER TABLE for the workgroups of both step kernels (NULL: the band mapping of pic_xcd_tile): XCD j = linear workgroup id mod 8
+    // walks order[j·order_len + k], k = id div 8 — a tile, or 0xFFFF (that workgroup returns).  Lists of different lengths balance the
+    // XCDs' work when the tiles' populations differ; the order inside a list decides which tiles make up the launch's tail.
+    const uint16_t* order;
+    int order_len;
     uint32_t* dd_spill;             // agents that found no room in their segment: [0] count, then records of 8 words (x, y, agent_food, slot, heading hi, lo, deposit, tile)
     uint32_t dd_spill_cap;
 };
@@ -247,6 +252,15 @@ __device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t
         tx = (int)(r / rem); ty = (int)((wb << 3) + (r - (uint32_t)tx * rem));
     }
 #endif
+}
+
+__device__ __forceinline__ bool pic_order_tile(const PicArgs& p, uint32_t L, int& tx, int& ty) {      // false: no tile for this workgroup
+    const uint32_t k = L >> 3;
+    if (k >= (uint32_t)p.order_len) return false;
+    const uint32_t t = p.order[(L & 7u) * (uint32_t)p.order_len + k];
+    if (t == 0xFFFFu) return false;
+    tx = (int)(t / (uint32_t)p.nty); ty = (int)(t - (uint32_t)tx * (uint32_t)p.nty);
+    return true;
 }
 
 __device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty) {        // false: not this launch's tile
@@ -493,7 +507,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile of this workgroup
     int tx = (int)blockIdx.y, ty = (int)blockIdx.x;
-    if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx);
+    if (p.order) { if (!pic_order_tile(p, blockIdx.y * gridDim.x + blockIdx.x, tx, ty)) return; }
+    else if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int tile = tx * p.nty + ty;
     (void)NT;
@@ -1170,7 +1185,8 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 #ifndef PIC_XCD_MAP_KB
 #define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0);
+    if (p.order) { if (!pic_order_tile(p, (blockIdx.y - row0) * gridDim.x + blockIdx.x, tx, ty)) return; }
+    else if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
@@ -1695,7 +1711,7 @@ static void launch_forward_move_dd(int kind, const FwdArgs& f, const PicArgs& k,
 
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s, bool mom = false) {
-    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx);
+    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.order ? (8 * k.order_len + k.nty - 1) / k.nty : (k.sub_mode == 1 ? k.sub_ntx : k.ntx));
     if constexpr (!TILED) {
         if (kind != DIE_AGENT_PHYSARUM && mom) {
             k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, false, true><<<grid, block, lds, s>>>(f, k);
@@ -1715,7 +1731,7 @@ static void launch_resolve_diffuse(const PicArgs& k, const KbArgs& a, int R, hip
     const int WR = TX + 2 * R, WC = TY + 2 * R;
     const size_t lds = ((size_t)WR * CP + (size_t)(WR * WC > TX * CP ? WR * WC : TX * CP)) * 4;
     // (a rectangle of tiles only: no extra grid row — the scan / reduction / turn bits belong to the launch that completes the step)
-    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx + 1);
+    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.order ? (8 * k.order_len + k.nty - 1) / k.nty + 1 : (k.sub_mode == 1 ? k.sub_ntx : k.ntx + 1));
     constexpr int B = KbShape<XS, YS>::BLOCK;
     switch (R) {
         case 1: k_pic_resolve_diffuse<T, XS, YS, 1, TILED><<<grid, B, lds, s>>>(k, a); break;
@@ -1790,6 +1806,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const bool keep_pg = mom && g->inertia != 0.f;
     k.ipgx = keep_pg ? pg_in[0] : nullptr; k.ipgy = keep_pg ? pg_in[1] : nullptr; k.opgx = keep_pg ? pg_out[0] : nullptr; k.opgy = keep_pg ? pg_out[1] : nullptr;
     k.dd_geo = nullptr; k.dd_win = nullptr; k.dd_wout = nullptr; k.dd_spill = nullptr; k.dd_spill_cap = 0;
+    k.order = nullptr; k.order_len = 0;
     DIE_REQUIRE(p->sub_mode >= 0 && p->sub_mode <= 2, "die_pic_forward_env_step: sub_mode %d", p->sub_mode);
     if (p->sub_mode) {
         DIE_REQUIRE(p->stages == 1 || p->stages == 2, "die_pic_forward_env_step: a subset of the tiles is one launch (stages 1 or 2), not a whole step");
@@ -1857,6 +1874,48 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             const int64_t blocks = (turn_words / 4 + DIE_BLOCK - 1) / DIE_BLOCK;
             k_turn_bits<<<(int)(blocks < 1024 ? blocks : 1024), DIE_BLOCK, 0, s>>>(p->turn_bits, turn_words, g->seed, g->step);
         }
+    }
+    // round 6, experiment (DIE_PIC_ORDER = 1..4): an order table built on the HOST from the populations of the layout
+    // this step reads — the stream is synchronised for it, so only the kernels' own durations (rocprofv3) mean anything in such a run.
+    //   1 the XCDs' lists balanced by work (population + a fixed cost per tile), band order kept inside a list
+    //   2 balanced, and inside a list the tiles by descending number of 8-wave rounds (stable: band order inside a class)
+    //   3 balanced, and inside a list by descending population      4 lists of equal length (the band mapping itself), by rounds
+    static const int order_mode = getenv("DIE_PIC_ORDER") ? atoi(getenv("DIE_PIC_ORDER")) : 0;
+    static uint16_t* d_order = nullptr; static int d_cap = 0, d_len = 0;
+    if (order_mode && two && !tiled && !dead && !p->sub_mode && (k.nty & 7) == 0 && NT <= 65535 && stages == 2 && d_len) {
+        k.order = d_order; k.order_len = d_len;              // (the field kernel launched on its own: the table of this step's agent kernel)
+    } else
+    if (order_mode && two && !tiled && !dead && !p->sub_mode && (k.nty & 7) == 0 && NT <= 65535) {
+        std::vector<uint32_t> n((size_t)NT);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(n.data(), k.in.n, (size_t)NT * 4, hipMemcpyDeviceToHost);
+        const int wb = k.nty >> 3, per = wb * k.ntx;
+        const double w0 = getenv("DIE_PIC_ORDER_W0") ? atof(getenv("DIE_PIC_ORDER_W0")) : 1400.0;
+        std::vector<int> seq((size_t)NT);
+        for (int j = 0; j < 8; ++j) for (int q = 0; q < per; ++q) seq[(size_t)j * per + q] = (q / wb) * k.nty + j * wb + q % wb;
+        double total = 0; for (int t = 0; t < NT; ++t) total += n[t] + w0;
+        std::vector<std::vector<int>> part(8);
+        double run = 0; int j = 0;
+        for (int i = 0; i < NT; ++i) {
+            if (order_mode == 4) j = i / per;
+            else { while (j < 7 && run >= (j + 1) * total / 8.0) ++j; }
+            part[j].push_back(seq[i]);
+            run += n[seq[i]] + w0;
+        }
+        auto rounds = [&](int t) { return (int)(((n[t] + 63) / 64 + 7) / 8); };
+        int len = 0;
+        for (auto& v : part) {
+            if (order_mode == 2 || order_mode == 4) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return rounds(a) > rounds(b); });
+            if (order_mode == 3) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return n[a] > n[b]; });
+            len = std::max(len, (int)v.size());
+        }
+        std::vector<uint16_t> tab((size_t)8 * len, (uint16_t)0xFFFF);
+        for (int q = 0; q < 8; ++q) for (size_t i = 0; i < part[q].size(); ++i) tab[(size_t)q * len + i] = (uint16_t)part[q][i];
+        if (d_cap < 8 * len) { if (d_order) (void)hipFree(d_order); (void)hipMalloc((void**)&d_order, (size_t)16 * len * 2); d_cap = 16 * len; }
+        (void)hipMemcpy(d_order, tab.data(), tab.size() * 2, hipMemcpyHostToDevice);
+        k.order = d_order; k.order_len = d_len = len;
+        static int said = 0;
+        if (!said++) fprintf(stderr, "[order table] mode %d: lists of %zu..%d tiles\n", order_mode, std::min_element(part.begin(), part.end(), [](auto& a, auto& b) { return a.size() < b.size(); })->size(), len);
     }
     // round 6's pricing harness (DIE_DD_PROBE=1 / 2: ahead of / behind the step's own agent kernel): the layout the step reads is
     // converted to a direct-delivery layout in scratch buffers and the DD agent kernel runs on it into a second scratch layout — same
