@@ -33,9 +33,6 @@
 // path: die_agents_mark_owner materialises it when somebody asks (DeviceMedium.occupied / owner_slots / render).
 #include "die_forward.h"
 #include <stdlib.h>
-#include <stdio.h>
-#include <algorithm>
-#include <vector>
 
 // (PIC_K2_FEED, PIC_K1_BLOCK, PIC_K2_BLOCK, PIC_STAGE_FOOD, PIC_K1_MINW: knobs of the A/B builds of scratch/build_variant.sh;
 // the values below are the measured best)
@@ -180,43 +177,7 @@ struct PicArgs {
     // GradientAgent with momentum (inertia ≠ 0: die_pic.prev_grad): _prev_grad in `in` order / where the step leaves it, `out` order
     const float *ipgx, *ipgy;
     float *opgx, *opgy;
-    // direct-delivery layouts (DD, below): the segments' geometry (shared by both layouts) and the per-tile count rows of the layout
-    // the step reads / writes
-    const uint4* dd_geo;
-    const uint32_t* dd_win;
-    uint32_t* dd_wout;
-    // an ORDER TABLE for the workgroups of both step kernels (NULL: the band mapping of pic_xcd_tile): XCD j = linear workgroup id mod 8
-    // walks order[j·order_len + k], k = id div 8 — a tile, or 0xFFFF (that workgroup returns).  Lists of different lengths balance the
-    // XCDs' work when the tiles' populations differ; the order inside a list decides which tiles make up the launch's tail.
-    const uint16_t* order;
-    int order_len;
-    uint32_t* dd_spill;             // agents that found no room in their segment: [0] count, then records of 8 words (x, y, agent_food, slot, heading hi, lo, deposit, tile)
-    uint32_t dd_spill_cap;
 };
-
-// ---- direct-delivery layout (DD; round 6) ---------------------------------------------------------------------------------------
-// The exact layout above keeps an agent that walks onto another tile in the segment of the tile it LEFT (a segment of |set| entries
-// always fits), and the agent kernel of a tile gathers its arrivals from the leaver ranges of the 8 tiles around it: ≈ 640 candidates
-// read and tested for ≈ 80 hits, a compaction pass, a barrier — 11 % of a workgroup's life (profiles/r04_final_phase_stamps.txt).
-// In a DD layout a leaver is written straight into the segment of the tile it walked ONTO:
-//   segment of tile t = [doff, doff + F + 4·E + 4·C): a front region of F entries for its stayers (first `s` used), then one
-//   sub-region per SOURCE neighbour — 8 of them, edge neighbours E entries, corner neighbours C — which only that neighbour's
-//   workgroup writes: the place of an arrival comes from an LDS counter of the writing workgroup, no global atomic, no contention.
-//   dd_geo[t] = (doff, F, E, C): fixed between two re-binnings, the same for both layouts of the ping-pong.
-//   count row of tile t in a layout: 16 words, [0] = s, [1 + k] = arrivals from source direction k (ring order of pic_meta_load:
-//   k = d < 4 ? d : d − 1 for d = (ddx + 1)·3 + ddy + 1).  The row is written by 9 different workgroups of the step that wrote the
-//   layout (each word by exactly one: a world has at least 3 × 3 tiles) and read by ONE load of 9 words by the next step.
-// An agent that finds no room (front region or sub-region full: a crowd) goes to the spill list; a step that finds the list non-empty
-// takes every workgroup through it (slow, correct), and the host re-bins with new capacities when it sees the flag (error bit 3).
-// Order inside a segment is arbitrary; nothing depends on it (claims are a maximum over slot ids, the reward an integer sum, the random
-// turn is keyed by the slot id).
-__device__ __forceinline__ uint32_t pic_dd_suboff(int k, uint32_t E, uint32_t C) {         // start of sub-region k behind the front region
-    // d = k < 4 ? k : k + 1; edge directions are the odd d.  Edge sub-regions before k: 0 0 1 1 2 3 3 4, corner ones: 0 1 1 2 2 2 3 3
-    const uint32_t ne = (0x43321100u >> (4 * k)) & 15u, nc = (0x33222110u >> (4 * k)) & 15u;
-    return ne * E + nc * C;
-}
-__device__ __forceinline__ uint32_t pic_dd_subcap(int k, uint32_t E, uint32_t C) { return ((k < 4 ? k : k + 1) & 1) ? E : C; }
-#define PIC_DD_ROW 16           // words per count row
 // Workgroups are handed to the 8 XCDs round robin (linear workgroup id modulo 8), and every XCD has its own L2.  With the plain
 // (blockIdx.y, blockIdx.x) = (tx, ty) mapping the tiles that share cache lines — the margins of their staged windows: a row of a
 // window starts 16–48 bytes before a 256-byte boundary and so touches a 128-byte line of each neighbour along y, the margin rows are
@@ -252,15 +213,6 @@ __device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t
         tx = (int)(r / rem); ty = (int)((wb << 3) + (r - (uint32_t)tx * rem));
     }
 #endif
-}
-
-__device__ __forceinline__ bool pic_order_tile(const PicArgs& p, uint32_t L, int& tx, int& ty) {      // false: no tile for this workgroup
-    const uint32_t k = L >> 3;
-    if (k >= (uint32_t)p.order_len) return false;
-    const uint32_t t = p.order[(L & 7u) * (uint32_t)p.order_len + k];
-    if (t == 0xFFFFu) return false;
-    tx = (int)(t / (uint32_t)p.nty); ty = (int)(t - (uint32_t)tx * (uint32_t)p.nty);
-    return true;
 }
 
 __device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty) {        // false: not this launch's tile
@@ -456,7 +408,7 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 // (Two persistent forms of this kernel — a tile queue with the next tile's agents prefetched, and one 16-wave workgroup per CU with
 // LDS-DMA loader waves — were built, bit-equal, and measured slower in round 4 (96 / 101 µs against 75–81): DESIGN.md §3.1,
 // scratch/refuted_r04/.)
-template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool MOM = false, bool DD = false>
+template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool MOM = false>
 // (waves per SIMD the compiler must leave room for: with fp16 planes the staged windows are 25 KB per workgroup, FOUR workgroups fit a
 // CU's LDS and the registers have to fit 8 waves per SIMD too — 78 scalar registers + 29 spilled instead of 106 + 17; with fp32
 // planes, 49 KB, only three fit whatever the registers)
@@ -469,7 +421,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)
     // MOM (GradientAgent with inertia / noise, gradient.py:82-91): the momentum path stays; _prev_grad is read from the `in`
     // arrays at the agent's index and written to the `out` arrays where the agent goes
-    static_assert(!DD || (RIM && !TILED && !MOM), "direct-delivery layouts: the two-launch form of an undivided world, no momentum");
     f.pgx = MOM ? (float*)p.ipgx : nullptr; f.pgy = MOM ? (float*)p.ipgy : nullptr; f.step_base = nullptr; f.mask = nullptr;
     if (!MOM) { f.inertia = 0.f; f.noise_scale = 0.f; }
     f.normalized = 1;
@@ -493,8 +444,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     __shared__ uint32_t s_next, s_nlist;
     __shared__ uint32_t s_inc[9];                                  // arrivals this tile sends to each neighbour: (ddx + 1)·3 + ddy + 1
     __shared__ __align__(4) uint8_t s_rimc[RIM ? PIC_RIM_CAP_MAX : 4];   // RIM: the codes of this tile's list (flushed as words)
-    __shared__ uint32_t s_list[DD ? 1 : PIC_LIST_CAP];               // (DD: nothing to filter — every entry of the segment stands on the tile)
-    __shared__ uint32_t s_dbase[DD ? 9 : 1], s_dcap[DD ? 9 : 1];     // DD: where this tile's leavers towards direction d go, and the room there
+    __shared__ uint32_t s_list[PIC_LIST_CAP];
     __shared__ long long s_gain[PIC_K1_BLOCK / DIE_WAVE];
     __shared__ uint32_t s_alv[TILED ? PIC_K1_BLOCK / DIE_WAVE : 1];   // TILED: agents this rank accounts for (die_medium.own_*)
     const int NT = p.ntx * p.nty;
@@ -507,8 +457,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile of this workgroup
     int tx = (int)blockIdx.y, ty = (int)blockIdx.x;
-    if (p.order) { if (!pic_order_tile(p, blockIdx.y * gridDim.x + blockIdx.x, tx, ty)) return; }
-    else if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx);
+    if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int tile = tx * p.nty + ty;
     (void)NT;
@@ -521,7 +470,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     float pA = 0.f;
     bool chas = false;
     auto prefetch_agents = [&]() {
-        const uint32_t own = s_pre[1], ncand = DD ? 0u : s_pre[9] - own, base0 = s_base[0];
+        const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
         // this thread's first candidate arrival and the agent streams of this wave's first chunk of stayers
         cj = 0; cX = 0; cY = 0;
         chas = threadIdx.x < ncand;
@@ -547,19 +496,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     PIC_SETPRIO(PIC_PRIO_K1, 0);
     // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
     // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
-    PicMeta mt = {0u, 0u, 0u};
-    uint4 dd_g = make_uint4(0u, 0u, 0u, 0u), dd_g0 = dd_g;
-    uint32_t dd_w = 0;
-    if (DD) {
-        // this tile's count row (ONE line: [0] stayers, [1 + k] arrivals from source direction k), its geometry, and the geometry of the
-        // 8 tiles its leavers may walk onto
-        if (threadIdx.x < 9) {
-            const int q = threadIdx.x, k3 = q == 0 ? 4 : (q <= 4 ? q - 1 : q);
-            dd_g = p.dd_geo[pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty)];
-            dd_g0 = p.dd_geo[tile];
-            dd_w = p.dd_win[(size_t)tile * PIC_DD_ROW + q];
-        }
-    } else mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
+    const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
     // the tiles to stage depend on nothing but the tile index: their loads go out next and overlap both round trips
     const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, (int)blockDim.x / (pitch / SV)};
     const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, (int)blockDim.x / (fpitch / SV)};
@@ -568,38 +505,13 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
         st_c.issue(sc);
         st_f.issue(sf);
     }
-    uint32_t obase, on;             // where this tile's stayers go in the layout being written, and the room there
-    if (DD) { const uint4 g0 = p.dd_geo[tile]; obase = g0.x; on = g0.y; }
-    else { obase = p.out.off[tile]; on = p.out.n[tile]; }
+    const uint32_t obase = p.out.off[tile], on = p.out.n[tile];
     // (TILED, the step behind a refresh in place — die_pic_ghost_inplace: a halo tile holds exactly what arrived for it; the neighbours'
     // leavers that stand on it are stale copies of agents that came with the message)
-    if (DD) {
-        __shared__ uint32_t s_len[9];
-        if (threadIdx.x < 9) {
-            const int q = threadIdx.x;
-            if (q == 0) { s_base[0] = dd_g0.x; s_len[0] = min(dd_w, dd_g0.y); }
-            else {
-                const int k = q - 1, d = k < 4 ? k : k + 1;
-                s_base[q] = dd_g0.x + dd_g0.y + pic_dd_suboff(k, dd_g0.z, dd_g0.w);
-                s_len[q] = min(dd_w, pic_dd_subcap(k, dd_g0.z, dd_g0.w));
-                // this tile's leavers towards direction d: the sub-region that tile keeps for ITS neighbour in the opposite direction (k' = 7 − k)
-                s_dbase[d] = dd_g.x + dd_g.y + pic_dd_suboff(7 - k, dd_g.z, dd_g.w);
-                s_dcap[d] = pic_dd_subcap(7 - k, dd_g.z, dd_g.w);
-            }
-        }
-        PA_BARRIER();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int q = 0; q < 9; ++q) { s_pre[q] = run; run += s_len[q]; }
-            s_pre[9] = run;
-        }
-        PA_BARRIER();
-    } else
     pic_ranges_finish(mt, s_base, s_pre, TILED && p.halo_fresh && p.g.own_x1 > 0 && (x0 < p.g.own_x0 || x0 >= p.g.own_x1 || y0 < p.g.own_y0 || y0 >= p.g.own_y1));
     prefetch_agents();
     PIC_STAMP(1);
-    const uint32_t own = s_pre[1], ncand = DD ? 0u : s_pre[9] - own, base0 = s_base[0];
-    const uint32_t n_direct = DD ? s_pre[9] : own;         // entries taken straight from their place (DD: the stayers and the 8 sub-regions)
+    const uint32_t own = s_pre[1], ncand = s_pre[9] - own, base0 = s_base[0];
     PIC_SETPRIO(PIC_PRIO_K1, 1);
     FwdTileMem<T, TILED> tm;
     tm.g = p.g;
@@ -642,7 +554,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
         PA_BARRIER();                                           // publishes the staged tiles and the list
         PIC_STAMP(3);
         PIC_SETPRIO(PIC_PRIO_K1, 2);
-        const uint32_t n_own = cb == 0 ? n_direct : 0u, count = n_own + s_nlist;
+        const uint32_t n_own = cb == 0 ? own : 0u, count = n_own + s_nlist;
         bool first = cb == 0;
         uint32_t cprev = 0;
         for (;;) {                         // a wave's first chunk is fixed (its streams are already here), then it takes
@@ -666,12 +578,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
             double hd = 0.0;
             uint32_t code = 0;
             bool listed = false;
-            [[maybe_unused]] uint32_t dd_dir = 4, dd_pos = 0, dd_tile = 0;
             if (act) {
-                uint32_t j;
-                if (idx < own || !DD) j = idx < n_own ? base0 + idx : s_list[idx - n_own];
-                else { int r = 1; while (idx >= s_pre[r + 1]) ++r; j = s_base[r] + (idx - s_pre[r]); }     // DD: an arrival, in its sub-region
-                if (first && idx < own) {                        // (this wave's prefetched chunk: idx = wave·64 + lane < own)
+                const uint32_t j = idx < n_own ? base0 + idx : s_list[idx - n_own];
+                if (first && idx < n_own) {                      // (this wave's prefetched chunk: idx = wave·64 + lane < own)
                     X = pX; Y = pY; sid = pS; hh = pHh; hl = pHl; af = pA;
                 } else {
                     // (the pointers first — their scalar loads go out together —, then all six streams in flight together)
@@ -733,13 +642,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
                     ddx = ntx_ - tx; ddy = nty_ - ty;
                     ddx = ddx > 1 ? ddx - p.ntx : (ddx < -1 ? ddx + p.ntx : ddx);
                     ddy = ddy > 1 ? ddy - p.nty : (ddy < -1 ? ddy + p.nty : ddy);
-                    if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) { atomicOr(p.error, 2u); ddx = ddy = 0; if (DD) stay = true; }
-                    else if (DD) {
-                        // its place in the destination's sub-region for this tile: this workgroup is the only writer of that sub-region
-                        dd_dir = (uint32_t)((ddx + 1) * 3 + ddy + 1);
-                        dd_pos = atomicAdd(&s_inc[dd_dir], 1u);
-                        dd_tile = (uint32_t)(ntx_ * p.nty + nty_);
-                    }
+                    if (ddx < -1 || ddx > 1 || ddy < -1 || ddy > 1) { atomicOr(p.error, 2u); ddx = ddy = 0; }
                     else atomicAdd(&s_inc[(ddx + 1) * 3 + ddy + 1], 1u);   // one global atomic per neighbour at the end (2.5 M
                 }                                                          // agents: 11 µs of contended global atomics otherwise)
                 if (RIM) {
@@ -761,9 +664,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
                                                     ((unsigned long long)__popcll(m_rim) << 42));
             base = __shfl(base, 0, DIE_WAVE);
             const uint32_t bf = (uint32_t)base & 0x1FFFFFu, bb = (uint32_t)(base >> 21) & 0x1FFFFFu, br = (uint32_t)(base >> 42) & 0x1FFFFFu;
-            uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
-            uint32_t qbase = obase;
-            if (DD && !stay) { k = dd_pos < s_dcap[dd_dir] ? dd_pos : 0xFFFFFFFFu; qbase = s_dbase[dd_dir]; }        // (k ≥ on below: no room)
+            const uint32_t k = stay ? bf + (uint32_t)__popcll(m_stay & below) : on - 1u - (bb + (uint32_t)__popcll(m_leave & below));
             if (RIM && act && listed) {
                 const uint32_t at = br + (uint32_t)__popcll(m_rim & below);
                 if (at < (uint32_t)p.rim_cap) {
@@ -773,7 +674,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
             }
             if (act) {
                 if (k < on) {
-                    const uint32_t q = qbase + k;
+                    const uint32_t q = obase + k;
                     uint32_t *ox_ = PIC_KP(out.x, uint32_t*), *oy_ = PIC_KP(out.y, uint32_t*), *os_ = PIC_KP(out.slot, uint32_t*);
                     uint32_t *ohh_ = PIC_KP(out.hhi, uint32_t*), *ohl_ = PIC_KP(out.hlo, uint32_t*);
                     float *oa_ = PIC_KP(out.agent_food, float*), *od_ = PIC_KP(dep, float*);
@@ -789,17 +690,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
                     PIC_ST(1, ohl_, uint32_t, q, (uint32_t)__double2loint(hd));
                     PIC_ST(0, od_, float, q, dep);
                     if (MOM && p.opgx) { PIC_AT(p.opgx, float, q) = pux; PIC_AT(p.opgy, float, q) = puy; }
-                } else if (DD) {
-                    // no room in the front region / the sub-region (a crowd): the spill list, which the next step's workgroups all read
-                    uint32_t* sp = PIC_KP(dd_spill, uint32_t*);
-                    atomicOr(PIC_KP(error, uint32_t*), 8u);
-                    const uint32_t at = sp ? atomicAdd(sp, 1u) : 0xFFFFFFFFu;
-                    if (at < p.dd_spill_cap) {
-                        uint4* rec = (uint4*)(sp + 8) + 2 * (size_t)at;
-                        rec[0] = make_uint4(X, Y, __float_as_uint(af), sid);
-                        rec[1] = make_uint4((uint32_t)__double2hiint(hd), (uint32_t)__double2loint(hd), __float_as_uint(dep),
-                                            stay ? (uint32_t)tile : dd_tile);
-                    } else atomicOr(PIC_KP(error, uint32_t*), 16u);              // (agents lost: the host raises)
                 } else {
                     atomicOr(PIC_KP(error, uint32_t*), 1u);
                 }
@@ -822,16 +712,6 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     }
     PA_BARRIER();
     PIC_STAMP(5);
-    if (DD) {
-        // the count rows of the layout just written: this tile's stayers, and — in the 8 tiles around — what this tile sent them (always:
-        // a zero must replace the count of two steps ago)
-        if (threadIdx.x < 9) {
-            const int d = (int)threadIdx.x, ddx = d / 3 - 1, ddy = d % 3 - 1, k = d < 4 ? d : d - 1;
-            uint32_t* wo = PIC_KP(dd_wout, uint32_t*);
-            if (d == 4) wo[(size_t)tile * PIC_DD_ROW] = min((uint32_t)s_cnt & 0x1FFFFFu, on);
-            else wo[(size_t)(pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)) * PIC_DD_ROW + 1 + (7 - k)] = min(s_inc[d], s_dcap[d]);
-        }
-    } else
     if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
         const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
         atomicAdd(&PIC_KP(out.inc, uint32_t*)[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
@@ -853,11 +733,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
             PIC_KP(part_gain, long long*)[(size_t)p.ntx * p.nty + tile] = c;  // second half of the array: owned agents per tile
         }
         const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
-        if (DD) { if (nfront + nback != s_pre[9]) atomicOr(p.error, 1u); }
-        else {
-            p.out.s[tile] = nfront;
-            if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
-        }
+        p.out.s[tile] = nfront;
+        if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
     }
 }
 
@@ -1185,8 +1062,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 #ifndef PIC_XCD_MAP_KB
 #define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (p.order) { if (!pic_order_tile(p, (blockIdx.y - row0) * gridDim.x + blockIdx.x, tx, ty)) return; }
-    else if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0);
+    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
@@ -1518,69 +1394,6 @@ __global__ __launch_bounds__(DIE_BLOCK) void k_mark_owner(die_geo g, int64_t N, 
     }
 }
 
-// ---- direct-delivery layouts: conversions -------------------------------------------------------------------------------------
-// exact layout → DD layout (one workgroup per tile): the tile's stayers into the front region of its segment, the leavers of the 8
-// tiles around it that stand on it into the sub-region of the neighbour they came from — what the agent kernel would have left had the
-// previous step written a DD layout.  (Re-binning, the switch from the exact layout, and round 6's pricing harness.)
-__global__ __launch_bounds__(256) void k_pic_dd_from_exact(PicArgs p, PicLayout dd, const uint4* geo, uint32_t* words, uint32_t* error) {
-    __shared__ uint32_t s_cnt8[8];
-    const int tile = blockIdx.x, tx = tile / p.nty, ty = tile - tx * p.nty;
-    const uint4 g0 = geo[tile];
-    if (threadIdx.x < 8) s_cnt8[threadIdx.x] = 0;
-    __syncthreads();
-    auto copy = [&](uint32_t from, uint32_t to) {
-        dd.x[to] = p.in.x[from]; dd.y[to] = p.in.y[from]; dd.agent_food[to] = p.in.agent_food[from]; dd.slot[to] = p.in.slot[from];
-        dd.hhi[to] = p.in.hhi[from]; dd.hlo[to] = p.in.hlo[from];
-    };
-    const uint32_t off = p.in.off[tile], ns = p.in.s[tile];
-    for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) {
-        if (i < g0.y) copy(off + i, g0.x + i);
-        else atomicOr(error, 16u);
-    }
-    for (int k = 0; k < 8; ++k) {
-        const int k3 = k < 4 ? k : k + 1;
-        const int t = pic_wrap(tx + k3 / 3 - 1, p.ntx) * p.nty + pic_wrap(ty + k3 % 3 - 1, p.nty);
-        const uint32_t lo = p.in.off[t] + p.in.s[t], hi = p.in.off[t] + p.in.n[t];
-        const uint32_t base = g0.x + g0.y + pic_dd_suboff(k, g0.z, g0.w), cap = pic_dd_subcap(k, g0.z, g0.w);
-        for (uint32_t j = lo + threadIdx.x; j < hi; j += blockDim.x) {
-            if (pic_tile_of<false>(p, p.in.x[j], p.in.y[j]) != tile) continue;
-            const uint32_t at = atomicAdd(&s_cnt8[k], 1u);
-            if (at < cap) copy(j, base + at);
-            else atomicOr(error, 16u);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) words[(size_t)tile * PIC_DD_ROW] = min(ns, g0.y);
-    else if (threadIdx.x <= 8) words[(size_t)tile * PIC_DD_ROW + threadIdx.x] = min(s_cnt8[threadIdx.x - 1], pic_dd_subcap((int)threadIdx.x - 1, g0.z, g0.w));
-}
-// every tile the same segment: doff = t·(F + 4E + 4C)
-__global__ void k_pic_dd_geo_uniform(uint4* geo, int NT, uint32_t F, uint32_t E, uint32_t C) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < NT) geo[t] = make_uint4((uint32_t)t * (F + 4u * E + 4u * C), F, E, C);
-}
-// segments sized by the tiles' populations in an exact layout (one workgroup): F = 5/4·n + 64 in whole 128-byte lines, E = F/8 (a
-// step moves ≈ 3 % of a tile's agents across each edge), C = 32; doff = exclusive scan
-__global__ __launch_bounds__(1024) void k_pic_dd_geo_from_counts(uint4* geo, int NT, const uint32_t* n) {
-    __shared__ uint32_t s[1024];
-    const int per = (NT + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, NT);
-    auto shape = [&](int t, uint32_t& F, uint32_t& E, uint32_t& C) {
-        F = (n[t] + n[t] / 4u + 64u + 31u) & ~31u; E = (F / 8u + 31u) & ~31u; C = 32u;
-        return F + 4u * E + 4u * C;
-    };
-    uint32_t sum = 0, F, E, C;
-    for (int t = lo; t < hi; ++t) sum += shape(t, F, E, C);
-    s[threadIdx.x] = sum;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const uint32_t v = (int)threadIdx.x >= o ? s[threadIdx.x - o] : 0u;
-        __syncthreads();
-        s[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t run = s[threadIdx.x] - sum;
-    for (int t = lo; t < hi; ++t) { const uint32_t len = shape(t, F, E, C); geo[t] = make_uint4(run, F, E, C); run += len; }
-}
-
 // ---- host side ----------------------------------------------------------------------------------------------------
 int die_sweep_dep_plane(const die_medium* m, const die_dynamics* d, const float* dep_plane, const long long* part_gain, int n_part,
                         die_step_result* result, long long alive_const, void* stream);   // die_env.hip
@@ -1701,17 +1514,9 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
     }
 }
 
-template <typename T>
-static void launch_forward_move_dd(int kind, const FwdArgs& f, const PicArgs& k, int block, size_t lds, hipStream_t s) {
-    const dim3 grid(k.nty, k.ntx);
-    if (kind != DIE_AGENT_PHYSARUM) k_pic_forward_move<T, DIE_AGENT_GRADIENT, true, true, true, false, false, true><<<grid, block, lds, s>>>(f, k);
-    else if (k.adx) k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, true, true, false, false, true><<<grid, block, lds, s>>>(f, k);
-    else k_pic_forward_move<T, DIE_AGENT_PHYSARUM, true, false, true, false, false, true><<<grid, block, lds, s>>>(f, k);
-}
-
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s, bool mom = false) {
-    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.order ? (8 * k.order_len + k.nty - 1) / k.nty : (k.sub_mode == 1 ? k.sub_ntx : k.ntx));
+    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx);
     if constexpr (!TILED) {
         if (kind != DIE_AGENT_PHYSARUM && mom) {
             k_pic_forward_move<T, DIE_AGENT_GRADIENT, STAGE, true, RIM, false, true><<<grid, block, lds, s>>>(f, k);
@@ -1731,7 +1536,7 @@ static void launch_resolve_diffuse(const PicArgs& k, const KbArgs& a, int R, hip
     const int WR = TX + 2 * R, WC = TY + 2 * R;
     const size_t lds = ((size_t)WR * CP + (size_t)(WR * WC > TX * CP ? WR * WC : TX * CP)) * 4;
     // (a rectangle of tiles only: no extra grid row — the scan / reduction / turn bits belong to the launch that completes the step)
-    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.order ? (8 * k.order_len + k.nty - 1) / k.nty + 1 : (k.sub_mode == 1 ? k.sub_ntx : k.ntx + 1));
+    const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx + 1);
     constexpr int B = KbShape<XS, YS>::BLOCK;
     switch (R) {
         case 1: k_pic_resolve_diffuse<T, XS, YS, 1, TILED><<<grid, B, lds, s>>>(k, a); break;
@@ -1805,8 +1610,6 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.halo_fresh = m->gW > 0 ? p->halo_fresh : 0;
     const bool keep_pg = mom && g->inertia != 0.f;
     k.ipgx = keep_pg ? pg_in[0] : nullptr; k.ipgy = keep_pg ? pg_in[1] : nullptr; k.opgx = keep_pg ? pg_out[0] : nullptr; k.opgy = keep_pg ? pg_out[1] : nullptr;
-    k.dd_geo = nullptr; k.dd_win = nullptr; k.dd_wout = nullptr; k.dd_spill = nullptr; k.dd_spill_cap = 0;
-    k.order = nullptr; k.order_len = 0;
     DIE_REQUIRE(p->sub_mode >= 0 && p->sub_mode <= 2, "die_pic_forward_env_step: sub_mode %d", p->sub_mode);
     if (p->sub_mode) {
         DIE_REQUIRE(p->stages == 1 || p->stages == 2, "die_pic_forward_env_step: a subset of the tiles is one launch (stages 1 or 2), not a whole step");
@@ -1875,90 +1678,6 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             k_turn_bits<<<(int)(blocks < 1024 ? blocks : 1024), DIE_BLOCK, 0, s>>>(p->turn_bits, turn_words, g->seed, g->step);
         }
     }
-    // round 6, experiment (DIE_PIC_ORDER = 1..4): an order table built on the HOST from the populations of the layout
-    // this step reads — the stream is synchronised for it, so only the kernels' own durations (rocprofv3) mean anything in such a run.
-    //   1 the XCDs' lists balanced by work (population + a fixed cost per tile), band order kept inside a list
-    //   2 balanced, and inside a list the tiles by descending number of 8-wave rounds (stable: band order inside a class)
-    //   3 balanced, and inside a list by descending population      4 lists of equal length (the band mapping itself), by rounds
-    static const int order_mode = getenv("DIE_PIC_ORDER") ? atoi(getenv("DIE_PIC_ORDER")) : 0;
-    static uint16_t* d_order = nullptr; static int d_cap = 0, d_len = 0;
-    if (order_mode && two && !tiled && !dead && !p->sub_mode && (k.nty & 7) == 0 && NT <= 65535 && stages == 2 && d_len) {
-        k.order = d_order; k.order_len = d_len;              // (the field kernel launched on its own: the table of this step's agent kernel)
-    } else
-    if (order_mode && two && !tiled && !dead && !p->sub_mode && (k.nty & 7) == 0 && NT <= 65535) {
-        std::vector<uint32_t> n((size_t)NT);
-        (void)hipStreamSynchronize(s);
-        (void)hipMemcpy(n.data(), k.in.n, (size_t)NT * 4, hipMemcpyDeviceToHost);
-        const int wb = k.nty >> 3, per = wb * k.ntx;
-        const double w0 = getenv("DIE_PIC_ORDER_W0") ? atof(getenv("DIE_PIC_ORDER_W0")) : 1400.0;
-        std::vector<int> seq((size_t)NT);
-        for (int j = 0; j < 8; ++j) for (int q = 0; q < per; ++q) seq[(size_t)j * per + q] = (q / wb) * k.nty + j * wb + q % wb;
-        double total = 0; for (int t = 0; t < NT; ++t) total += n[t] + w0;
-        std::vector<std::vector<int>> part(8);
-        double run = 0; int j = 0;
-        for (int i = 0; i < NT; ++i) {
-            if (order_mode == 4) j = i / per;
-            else { while (j < 7 && run >= (j + 1) * total / 8.0) ++j; }
-            part[j].push_back(seq[i]);
-            run += n[seq[i]] + w0;
-        }
-        auto rounds = [&](int t) { return (int)(((n[t] + 63) / 64 + 7) / 8); };
-        int len = 0;
-        for (auto& v : part) {
-            if (order_mode == 2 || order_mode == 4) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return rounds(a) > rounds(b); });
-            if (order_mode == 3) std::stable_sort(v.begin(), v.end(), [&](int a, int b) { return n[a] > n[b]; });
-            len = std::max(len, (int)v.size());
-        }
-        std::vector<uint16_t> tab((size_t)8 * len, (uint16_t)0xFFFF);
-        for (int q = 0; q < 8; ++q) for (size_t i = 0; i < part[q].size(); ++i) tab[(size_t)q * len + i] = (uint16_t)part[q][i];
-        if (d_cap < 8 * len) { if (d_order) (void)hipFree(d_order); (void)hipMalloc((void**)&d_order, (size_t)16 * len * 2); d_cap = 16 * len; }
-        (void)hipMemcpy(d_order, tab.data(), tab.size() * 2, hipMemcpyHostToDevice);
-        k.order = d_order; k.order_len = d_len = len;
-        static int said = 0;
-        if (!said++) fprintf(stderr, "[order table] mode %d: lists of %zu..%d tiles\n", order_mode, std::min_element(part.begin(), part.end(), [](auto& a, auto& b) { return a.size() < b.size(); })->size(), len);
-    }
-    // round 6's pricing harness (DIE_DD_PROBE=1 / 2: ahead of / behind the step's own agent kernel): the layout the step reads is
-    // converted to a direct-delivery layout in scratch buffers and the DD agent kernel runs on it into a second scratch layout — same
-    // agents, same arithmetic, nothing of it is used by the step.  rocprofv3 then shows both instantiations side by side.
-    static const int dd_probe = getenv("DIE_DD_PROBE") ? atoi(getenv("DIE_DD_PROBE")) : 0;
-    auto dd_probe_run = [&]() {
-        struct Scratch { int NT = 0; uint32_t* a[2][6] = {}; float* dep = nullptr; uint4* geo = nullptr; uint32_t* w[2] = {}; uint4* rim = nullptr;
-                         uint8_t* rim_code = nullptr; uint32_t* rim_cnt = nullptr; long long* part = nullptr; uint32_t* error = nullptr; };
-        static Scratch S;
-        // DIE_DD_F > 0: every tile the same segment (F, E = F/16, C = 16); default: sized by the tiles' populations (k_pic_dd_geo_from_counts)
-        const uint32_t F = getenv("DIE_DD_F") ? (uint32_t)atoi(getenv("DIE_DD_F")) : 0u;
-        const uint32_t E = F / 16, Cc = 16;
-        const size_t total = F ? (size_t)NT * (F + 4 * E + 4 * Cc) : (size_t)p->N * 2 + (size_t)NT * 512;
-        if (S.NT != NT) {
-            for (int l = 0; l < 2; ++l) { for (int q = 0; q < 6; ++q) (void)hipMalloc((void**)&S.a[l][q], total * 4); (void)hipMalloc((void**)&S.w[l], (size_t)NT * PIC_DD_ROW * 4); (void)hipMemset(S.w[l], 0, (size_t)NT * PIC_DD_ROW * 4); }
-            (void)hipMalloc((void**)&S.dep, total * 4); (void)hipMalloc((void**)&S.geo, (size_t)NT * 16);
-            (void)hipMalloc((void**)&S.rim, (size_t)NT * k.rim_cap * 16); (void)hipMalloc((void**)&S.rim_code, (size_t)NT * k.rim_cap); (void)hipMalloc((void**)&S.rim_cnt, (size_t)NT * 4);
-            (void)hipMalloc((void**)&S.part, (size_t)NT * 16); (void)hipMalloc((void**)&S.error, 16); (void)hipMemset(S.error, 0, 16);
-            S.NT = NT;
-        }
-        auto lay = [&](int l) { PicLayout o; o.x = S.a[l][0]; o.y = S.a[l][1]; o.agent_food = (float*)S.a[l][2]; o.slot = S.a[l][3]; o.hhi = S.a[l][4]; o.hlo = S.a[l][5];
-                                o.off = o.n = o.s = o.inc = nullptr; return o; };
-        if (F) k_pic_dd_geo_uniform<<<(NT + 255) / 256, 256, 0, s>>>(S.geo, NT, F, E, Cc);
-        else k_pic_dd_geo_from_counts<<<1, 1024, 0, s>>>(S.geo, NT, k.in.n);
-        k_pic_dd_from_exact<<<NT, 256, 0, s>>>(k, lay(0), S.geo, S.w[0], S.error);
-        PicArgs kd = k;
-        kd.in = lay(0); kd.out = lay(1); kd.dep = S.dep; kd.dd_geo = S.geo; kd.dd_win = S.w[0]; kd.dd_wout = S.w[1];
-        kd.rim = S.rim; kd.rim_code = S.rim_code; kd.rim_cnt = S.rim_cnt; kd.part_gain = S.part; kd.error = S.error; kd.adx = kd.ady = kd.adep = nullptr;
-        if (m->dtype == DIE_F32) launch_forward_move_dd<float>(g->kind, f, kd, block, lds, s);
-        else launch_forward_move_dd<__half>(g->kind, f, kd, block, lds, s);
-        if (getenv("DIE_DD_PROBE_CHECK")) {              // the error word of the scratch run, and the totals of the layout it wrote
-            (void)hipStreamSynchronize(s);
-            uint32_t e = 0; (void)hipMemcpy(&e, S.error, 4, hipMemcpyDeviceToHost);
-            std::vector<uint32_t> w((size_t)NT * PIC_DD_ROW);
-            (void)hipMemcpy(w.data(), S.w[1], w.size() * 4, hipMemcpyDeviceToHost);
-            unsigned long long tot = 0, mx = 0, mxe = 0;
-            for (int t = 0; t < NT; ++t) { for (int q = 0; q < 9; ++q) tot += w[(size_t)t * PIC_DD_ROW + q]; mx = std::max<unsigned long long>(mx, w[(size_t)t * PIC_DD_ROW]);
-                                           for (int q = 1; q < 9; ++q) mxe = std::max<unsigned long long>(mxe, w[(size_t)t * PIC_DD_ROW + q]); }
-            fprintf(stderr, "[dd probe] error word %u, agents in the written layout %llu of %lld, largest front %llu, largest sub-region %llu\n", e, tot, (long long)p->N, mx, mxe);
-        }
-    };
-    const bool dd_ok = dd_probe && two && stage && !tiled && !dead && !mom && !p->sub_mode && (stages & 1);
-    if (dd_ok && dd_probe == 1) dd_probe_run();
     if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s, mom); \
                                        else launch_forward_move<T, STAGE, false>(g->kind, f, k, NT, block, LDS, s, mom); } while (0)
@@ -1974,7 +1693,6 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
         }
 #undef DIE_PIC_K1
     }
-    if (dd_ok && dd_probe == 2) dd_probe_run();
     // dead slots (two-launch form): the cells the alive agents stand on now, then the slots that never lived
 #ifndef PIC_DEAD_BLOCKS_CAP
 #define PIC_DEAD_BLOCKS_CAP 0          // workgroups of k_pic_dead: 0 = one slot per thread, else at most this many (grid-stride)

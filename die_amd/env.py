@@ -474,10 +474,15 @@ class Env(_EnvBase):
             # 53.4, 2048² 58.5 / 53.3 / 70.7 (bench.py, with its per-step events: 58.4 / 57.1), 3072×2048 78.0 / 64.5 / 80.5,
             # 3072² 107 / 90 / 112, 4096×2048 95.6 / 77.6 / 95.2: 64×64 tiles from 2^22 cells upwards, the smaller shapes (worlds
             # that 64 does not divide) from 2^23
+            # fp16 field channels (BASELINE configs[4]): 32×128 tiles first.  A row of a 64-cell-wide tile is ONE 128-byte line of an
+            # fp16 plane; with 128 cells per row the field kernel's loads and stores run 256 bytes like the fp32 planes' — measured
+            # (r6, profiles/r06_f16_tile_shapes.txt): 4096² 9 132 → 9 540 steps/s, 16384² 541 → 587 (field kernel 878 → 751 µs)
+            from .pic import TILE_SHAPES
+            f16 = self.medium.dtype == torch.float16
             if W * H >= self.PIC_MIN_CELLS:
-                self._pic_tile = pick_tile(W, H, reach) or False
+                self._pic_tile = pick_tile(W, H, reach, shapes=(((5, 7),) if f16 else ()) + TILE_SHAPES) or False
             elif W * H >= self.PIC_MIN_CELLS_64:
-                self._pic_tile = pick_tile(W, H, reach, shapes=((6, 6),)) or False
+                self._pic_tile = pick_tile(W, H, reach, shapes=((5, 7), (6, 6)) if f16 else ((6, 6),)) or False
             else:
                 self._pic_tile = False
         if not (bool(self._pic_tile) and reach <= min(1 << self._pic_tile[0], 1 << self._pic_tile[1]) - 1):

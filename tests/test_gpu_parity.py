@@ -599,6 +599,7 @@ BINNED_ORACLE_CASES = [
     dict(W=96, H=384, tile=(5, 7), food_infinite=True),
     dict(W=192, H=256, tile=(6, 6), zero_cost=True, sigma=0.8, rate_feed=0.3, decay=0.05),    # gaussian radius 3
     dict(W=128, H=192, tile=(5, 6), f16=True),
+    dict(W=96, H=384, tile=(5, 7), f16=True, collide=0.5),                   # what Env picks for fp16 fields (32×128 tiles)
     dict(W=128, H=192, tile=(5, 6), agent='gradient'),
     # GradientAgent with momentum (the reference's defaults: inertia .9, noise .025 — gradient.py:19-30): _prev_grad in the layouts
     dict(W=128, H=192, tile=(5, 6), agent='gradient', inertia=0.9, noise=0.025),
