@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 
 class Medium(C.Structure):
@@ -191,6 +191,7 @@ _SIGNATURES = {
     'die_pic_forward_env_step': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Action), _P(Dynamics), C.c_void_p,
                                            C.c_void_p]),
     'die_pic_run': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, _P(GradientAgent), _P(Dynamics), C.c_int32, C.c_void_p, C.c_void_p]),
+    'die_pic_run_completed': (C.c_int32, []),
     'die_agents_mark_owner': (C.c_int, [_P(Medium), _P(Agents), C.c_void_p]),
     'die_pic_action_physarum': (C.c_int, [_P(Pic), C.c_int32, _P(GradientAgent), _P(Action), C.c_void_p]),
     'die_pic_ghost_pack': (C.c_int, [_P(Medium), _P(Pic), C.c_int32, C.c_int32, _P(PicSide), C.c_void_p, C.c_void_p]),

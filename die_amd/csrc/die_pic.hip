@@ -125,6 +125,9 @@ template <> struct Vec4<__half> {
 #endif
 #define PIC_SETPRIO(word, i) do { if ((i) == 0 ? (((word) >> 12) & 3) != 0 : ((((word) >> (12 - 4 * (i))) & 3) != (((word) >> (16 - 4 * (i))) & 3))) \
                                       __builtin_amdgcn_s_setprio(((word) >> (12 - 4 * (i))) & 3); } while (0)
+#ifndef PIC_R6
+#define PIC_R6 1                // A/B: 0 = round 5's prologue and epilogue of the agent kernel (divisions and gridDim in the prologue, priority raised behind it, the tile's last words from wave 0 alone)
+#endif
 #ifndef PIC_K1_BLOCK
 #define PIC_K1_BLOCK 512       // ≈ 614 agents stand on a 64×64 tile at ratio 0.15: one or two trips of the loop
 #endif
@@ -147,6 +150,10 @@ struct PicLayout {
 struct PicArgs {
     die_geo g;
     int ntx, nty, xs, ys;           // tiles per axis, log2 of the tile shape
+    // divisions the host has done for the kernels' first instructions (a workgroup's PROLOGUE — kernel entry to its first loads — ran
+    // 0.86 µs on a loaded CU, a twelfth of its life, half of it four runtime integer divisions: profiles/r06_cu_timeline_4096.txt):
+    uint32_t xcd_wb_mul;            // ceil(2^32 / wb), wb = tiles per row / 8 (pic_xcd_tile); 0: divide
+    int rp_c, rp_f;                 // rows per staging pass of the chem / food block = workgroup size / 16-byte vectors per staged row
     int margin;                     // K1 stages chem of the tile ± margin cells (a multiple of the 16-byte vector width)
     int fm_r, fm_c;                 // … and food of the tile ± fm_r rows / fm_c columns (periodic): the cells an agent of the tile can walk onto
     uint32_t mg_c, mg_f;            // ceil(2^20 / 16-byte vectors per staged row) of the chem / food block (PicStageRows)
@@ -192,7 +199,7 @@ struct PicArgs {
 #define PIC_XCD_MAP 2
 #endif
 template <bool REVERSE = false>
-__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t row0 = 0) {      // ntx: rows of tiles; row0: grid rows ahead of the tiles' (the field kernel's extra row)
+__device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t row0, uint32_t wb_mul, uint32_t nty_) {      // ntx: rows of tiles; row0: grid rows ahead of the tiles' (the field kernel's extra row); wb_mul: PicArgs.xcd_wb_mul; nty_ = gridDim.x = tiles per row (from the arguments: gridDim is a dependent load through the dispatch packet)
 #if PIC_XCD_MAP == 1
     if (((gridDim.x * (uint32_t)ntx) & 7u) == 0) {
         const uint32_t L = (blockIdx.y - row0) * gridDim.x + blockIdx.x, G8 = (gridDim.x * (uint32_t)ntx) >> 3;
@@ -202,12 +209,12 @@ __device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t
 #elif PIC_XCD_MAP == 2
     // (gridDim.x = tiles per row.  Bands of wb = floor(nty / 8) columns; the nty mod 8 columns left over — a decomposed rank's planes:
     // 68 tiles per row — come last, in the plain order)
-    const uint32_t nty = gridDim.x, wb = nty >> 3, banded = (wb << 3) * (uint32_t)ntx;
+    const uint32_t nty = PIC_R6 ? nty_ : gridDim.x, wb = nty >> 3, banded = (wb << 3) * (uint32_t)ntx;
     const uint32_t L = (blockIdx.y - row0) * nty + blockIdx.x;
     if (wb == 0) return;
     if (L < banded) {
         const uint32_t k = REVERSE ? wb * (uint32_t)ntx - 1u - (L >> 3) : L >> 3;      // (REVERSE: the band walked from its far end — A/B only)
-        tx = (int)(k / wb); ty = (int)((L & 7u) * wb + (k - (uint32_t)tx * wb));
+        tx = (int)(PIC_R6 && wb_mul ? __umulhi(k, wb_mul) : k / wb); ty = (int)((L & 7u) * wb + (k - (uint32_t)tx * wb));
     } else {
         const uint32_t r = L - banded, rem = nty - (wb << 3);
         tx = (int)(r / rem); ty = (int)((wb << 3) + (r - (uint32_t)tx * rem));
@@ -377,10 +384,26 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 // of wave 0 behind the error word (the caller allocates 2 + 32·tiles words: 16 64-bit stamps per tile, [0, 8) the agent
 // kernel's, [8, 16) the field kernel's).  No stamp executes in the shipped kernel.
 #if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
-#define PIC_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+#ifdef PIC_STAMPS_RT            // s_memrealtime: ONE 100 MHz clock for the whole GPU (s_memtime's counters are per XCD and not comparable)
+#define PIC_CLOCK "s_memrealtime"
+#else
+#define PIC_CLOCK "s_memtime"
+#endif
+#define PIC_NOW(t_) asm volatile(PIC_CLOCK " %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory")
+#define PIC_STAMP(k) do { if (threadIdx.x == 0) { unsigned long long t_; PIC_NOW(t_); \
                           ((unsigned long long*)(p.error + 2))[(size_t)tile * 16 + (k)] = t_; } } while (0)
+// round 6: where a workgroup ran and when it ENTERED the kernel — 4 more 64-bit words per tile behind the 16 stamps (the caller
+// allocates 2 + 40·tiles words): [0] agent kernel: XCC_ID << 32 | HW_ID, [1] its entry time, [2] / [3] the field kernel's.
+// (kernel-entry time is taken before the tile is known: PIC_ENTRY_DECL at the top, PIC_ENTRY_STORE once `tile` exists)
+#define PIC_ENTRY_DECL unsigned long long t_entry_ = 0; if (threadIdx.x == 0) PIC_NOW(t_entry_)
+#define PIC_ENTRY_STORE(which) do { if (threadIdx.x == 0) { uint32_t hw_, xcc_; \
+                                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_)); \
+                                unsigned long long* e_ = (unsigned long long*)(p.error + 2) + (size_t)p.ntx * p.nty * 16 + (size_t)tile * 4 + 2 * (which); \
+                                e_[0] = ((unsigned long long)xcc_ << 32) | hw_; e_[1] = t_entry_; } } while (0)
 #else
 #define PIC_STAMP(k) do { } while (0)
+#define PIC_ENTRY_DECL do { } while (0)
+#define PIC_ENTRY_STORE(which) do { } while (0)
 #endif
 
 #ifndef PIC_K1_MINW
@@ -416,6 +439,15 @@ template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool
 #define PIC_K1_MINW_F16 8
 #endif
 __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : PIC_K1_MINW)) void k_pic_forward_move(FwdArgs f, PicArgs p) {
+    PIC_ENTRY_DECL;
+    // (a starting workgroup's FIRST instructions already run at raised priority: its ≈ 300 instructions of prologue otherwise queue
+    // behind the resident workgroups' chunk loops — round 6, profiles/r06_cu_timeline_4096.txt)
+    if (PIC_R6 && ((PIC_PRIO_K1 >> 12) & 3) != 0) __builtin_amdgcn_s_setprio((PIC_PRIO_K1 >> 12) & 3);
+#ifndef PIC_K1_ARGS_FIRST
+#define PIC_K1_ARGS_FIRST 0     // (A/B: 1 =) every argument the prologue needs is requested with the FIRST scalar loads: the compiler otherwise loads
+#endif                          // them where they are first used — five dependent round trips (≈ 0.15 µs each on a loaded CU) ahead of the window loads
+    if (PIC_K1_ARGS_FIRST) asm volatile("" :: "s"(p.g.W), "s"(p.g.H), "s"(p.g.gW), "s"(p.g.gH), "s"(p.in.off), "s"(p.in.s), "s"(p.in.n), "s"(p.fm_r), "s"(p.fm_c),
+                                        "s"(p.mg_c), "s"(p.mg_f), "s"(p.margin), "s"(p.rp_c), "s"(p.rp_f), "s"(f.chem), "s"(p.food));
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
     // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)
@@ -457,7 +489,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile of this workgroup
     int tx = (int)blockIdx.y, ty = (int)blockIdx.x;
-    if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx);
+    if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx, 0, p.xcd_wb_mul, (uint32_t)p.nty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int tile = tx * p.nty + ty;
     (void)NT;
@@ -492,14 +524,15 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
         }
     };
     const int x0 = tx << p.xs, y0 = ty << p.ys;
+    PIC_ENTRY_STORE(0);
     PIC_STAMP(0);
     PIC_SETPRIO(PIC_PRIO_K1, 0);
     // 1st round trip: the per-tile words (small arrays, L2-resident).  Requested FIRST: vector loads return in order, so a
     // word requested behind the tile loads would only arrive after all of them (stamps: 6 600 cycles for this phase).
     const PicMeta mt = pic_meta_load(p.in, tx, ty, p.ntx, p.nty);
     // the tiles to stage depend on nothing but the tile index: their loads go out next and overlap both round trips
-    const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, (int)blockDim.x / (pitch / SV)};
-    const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, (int)blockDim.x / (fpitch / SV)};
+    const PicStageRows<T, 7, false> st_c = {(const T*)f.chem, x0 - P, y0 - P, pitch / SV, rows, p.g.W, p.g.H, p.mg_c, PIC_R6 ? p.rp_c : (int)blockDim.x / (pitch / SV)};
+    const PicStageRows<T, 5, true> st_f = {food, x0 - FR, y0 - FC, fpitch / SV, frows, p.g.W, p.g.H, p.mg_f, PIC_R6 ? p.rp_f : (int)blockDim.x / (fpitch / SV)};
     uint4 sc[4], sf[3];                   // 64×64 tile, 512 threads: chem ± 12 cells = 88 × 22 vectors, food ± (3, 4) = 70 × 18
     if (STAGE) {
         st_c.issue(sc);
@@ -710,32 +743,46 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
         const long long c = die_wave_sum((long long)nowned);
         if (lane == 0) s_alv[threadIdx.x / DIE_WAVE] = (uint32_t)c;
     }
+    // The tile's last words — arrival counts, rim codes, reward partial, stayer count — go out from THREE waves side by side, and the
+    // pointers they go to are requested ahead of the barrier.  (Round 6: all of it in wave 0, one dependent scalar load after the other,
+    // kept a workgroup's slot 0.64 µs beyond its last barrier — profiles/r06_cu_timeline_4096.txt; the slot is not refilled before the
+    // last wave has ended.)
+    const int w_inc = PIC_R6 && nwaves > 1 ? 1 : 0, w_rim = PIC_R6 && nwaves > 2 ? 2 : 0;
+    uint32_t* e_inc = nullptr; uint8_t* e_rimc = nullptr; uint32_t* e_rimn = nullptr; long long* e_gain = nullptr;
+    if (wave == w_inc) e_inc = PIC_KP(out.inc, uint32_t*);
+    if (RIM && wave == w_rim) { e_rimc = PIC_KP(rim_code, uint8_t*); e_rimn = PIC_KP(rim_cnt, uint32_t*); }
+    if (wave == 0) e_gain = PIC_KP(part_gain, long long*);
     PA_BARRIER();
     PIC_STAMP(5);
-    if (threadIdx.x < 9 && s_inc[threadIdx.x]) {
-        const int ddx = (int)threadIdx.x / 3 - 1, ddy = (int)threadIdx.x % 3 - 1;
-        atomicAdd(&PIC_KP(out.inc, uint32_t*)[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[threadIdx.x]);
+    if (wave == w_inc && lane < 9 && s_inc[lane]) {
+        const int ddx = lane / 3 - 1, ddy = lane % 3 - 1;
+        atomicAdd(&e_inc[pic_wrap(tx + ddx, p.ntx) * p.nty + pic_wrap(ty + ddy, p.nty)], s_inc[lane]);
     }
-    if (RIM) {
+    if (RIM && wave == w_rim) {
         // (a segment too long for the 24-bit positions counts as an overflowing list: the reader scans it)
         const uint32_t nr = on >= (1u << 21) ? (uint32_t)p.rim_cap + 1u : (uint32_t)(s_cnt >> 42) & 0x1FFFFFu;
-        for (uint32_t i = threadIdx.x; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += blockDim.x)
-            pic_st<2>(&((uint32_t*)PIC_KP(rim_code, uint8_t*))[((size_t)tile * p.rim_cap) / 4 + i], ((const uint32_t*)s_rimc)[i]);
-        if (threadIdx.x == 0) PIC_KP(rim_cnt, uint32_t*)[tile] = nr;
+        for (uint32_t i = (uint32_t)lane; i < (min(nr, (uint32_t)p.rim_cap) + 3u) / 4u; i += DIE_WAVE)
+            pic_st<2>(&((uint32_t*)e_rimc)[((size_t)tile * p.rim_cap) / 4 + i], ((const uint32_t*)s_rimc)[i]);
+        if (lane == 0) e_rimn[tile] = nr;
     }
-    if (threadIdx.x == 0) {
-        long long t = 0;
-        for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) t += s_gain[i];
-        PIC_KP(part_gain, long long*)[tile] = t;
-        if (TILED) {
-            long long c = 0;
-            for (int i = 0; i < (int)blockDim.x / DIE_WAVE; ++i) c += s_alv[i];
-            PIC_KP(part_gain, long long*)[(size_t)p.ntx * p.nty + tile] = c;  // second half of the array: owned agents per tile
+    if (wave == 0) {
+        long long t = die_wave_sum(lane < nwaves ? s_gain[lane] : 0ll);          // (integers: any order)
+        [[maybe_unused]] long long c = 0;
+        if (TILED) c = die_wave_sum(lane < nwaves ? (long long)s_alv[lane] : 0ll);
+        if (lane == 0) {
+            e_gain[tile] = t;
+            if (TILED) e_gain[(size_t)p.ntx * p.nty + tile] = c;               // second half of the array: owned agents per tile
+            const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
+            p.out.s[tile] = nfront;
+            if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
         }
-        const uint32_t nfront = (uint32_t)s_cnt & 0x1FFFFFu, nback = (uint32_t)(s_cnt >> 21) & 0x1FFFFFu;
-        p.out.s[tile] = nfront;
-        if (nfront + nback != on || on >= (1u << 21)) atomicOr(p.error, 1u);
     }
+    PIC_STAMP(7);
+#if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
+    // (diagnostic: when have wave 0's own stores — the epilogue's, issued a moment ago — been acknowledged?)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PIC_STAMP(6);
+#endif
 }
 
 // ---- dead slots on the tile-binned path (the reference's default layout: max_agents = W·H slots, core/data_init.py:143-144) ----------
@@ -972,6 +1019,7 @@ template <int XS, int YS> struct KbShape {
 #endif
 template <typename T, int XS, int YS, int R, bool TILED>
 __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_resolve_diffuse(PicArgs p, KbArgs a) {
+    PIC_ENTRY_DECL;
     constexpr int TX = 1 << XS, TY = 1 << YS, BLOCK = KbShape<XS, YS>::BLOCK;
     constexpr int A = 16 / (int)sizeof(T);                 // cells per 16-byte vector
     constexpr int WR = TX + 2 * R, WC = TY + 2 * R;        // the window
@@ -1062,11 +1110,12 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 #ifndef PIC_XCD_MAP_KB
 #define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0);
+    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0, p.xcd_wb_mul, (uint32_t)p.nty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
     [[maybe_unused]] const int tile = tx * p.nty + ty;
+    PIC_ENTRY_STORE(1);
     PIC_STAMP(8);
     PIC_SETPRIO(PIC_PRIO_KB, 0);
     const T* chem = (const T*)a.chem;
@@ -1634,6 +1683,13 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const int vpr_c = (TY + 2 * k.margin) / V, vpr_f = (TY + 2 * k.fm_c) / V;     // 16-byte vectors per staged row
     k.mg_c = ((1u << 20) + (uint32_t)vpr_c - 1u) / (uint32_t)vpr_c;
     k.mg_f = ((1u << 20) + (uint32_t)vpr_f - 1u) / (uint32_t)vpr_f;
+    {   // k / wb of pic_xcd_tile as one multiply (checked for every k the mapping can see)
+        const uint32_t wb = (uint32_t)k.nty >> 3;
+        k.xcd_wb_mul = wb > 1 ? (uint32_t)((((uint64_t)1 << 32) + wb - 1) / wb) : 0u;
+        bool ok = true;
+        for (uint32_t q = 0; ok && k.xcd_wb_mul && q < wb * (uint32_t)k.ntx; ++q) ok = (uint32_t)(((uint64_t)q * k.xcd_wb_mul) >> 32) == q / wb;
+        if (!ok) k.xcd_wb_mul = 0;
+    }
     if (stage) {                                            // (the multiply-shift division of PicStageRows, checked for every thread)
         bool ok = true;
         for (int i = 0; ok && i < PIC_K1_BLOCK; ++i) ok = (int)(((uint32_t)i * k.mg_c) >> 20) == i / vpr_c && (int)(((uint32_t)i * k.mg_f) >> 20) == i / vpr_f;
@@ -1666,6 +1722,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     const bool feed_in_k2 = PIC_K2_FEED && !d->food_infinite;
     int block = p->k1_threads > 0 ? p->k1_threads : (TX * TY >= 4096 ? 512 : 256);
     DIE_REQUIRE(block % DIE_WAVE == 0 && block >= DIE_WAVE && block <= PIC_K1_BLOCK, "die_pic_forward_env_step: k1_threads %d", block);
+    k.rp_c = stage ? block / vpr_c : 1; k.rp_f = stage ? block / vpr_f : 1;
     // the random turn bits of this step (PhysarumAgent): a table over the slot ids, filled by the previous step's field kernel
     // or — the first step, a changed seed, a step counter that did not advance by one — right here
     const bool physarum = g->kind == DIE_AGENT_PHYSARUM;
@@ -1773,8 +1830,11 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
 // n_steps × (forward + step) without the host in between (include/die_hip.h die_pic_run): the loop of examples/minimal_run.py:23-25 for a
 // caller that reads nothing back on the way.  Every step is die_pic_forward_env_step with the roles of the two layouts and of the
 // two chem planes exchanged and the Philox step counter advanced — the same launches, the same bits.
+static thread_local int32_t g_pic_run_done = 0;        // whole steps the last die_pic_run of this thread had enqueued when it returned
+extern "C" int32_t die_pic_run_completed(void) { return g_pic_run_done; }
 extern "C" int die_pic_run(const die_medium* m, const die_pic* p, int32_t from, const die_gradient_agent* g, const die_dynamics* d,
                            int32_t n_steps, die_step_result* results, void* stream) {
+    g_pic_run_done = 0;
     DIE_REQUIRE(m && p && g && d && results && n_steps >= 0 && (from == 0 || from == 1), "die_pic_run: null argument");
     DIE_REQUIRE(p->stages == 0 && p->sub_mode == 0, "die_pic_run: whole steps only (stages = 0, all tiles)");
     die_medium mm = *m;
@@ -1783,6 +1843,7 @@ extern "C" int die_pic_run(const die_medium* m, const die_pic* p, int32_t from, 
     for (int32_t i = 0; i < n_steps; ++i) {
         const int rc = die_pic_forward_env_step(&mm, &pp, (from + i) & 1, &gg, nullptr, d, results + i, stream);
         if (rc != DIE_OK) return rc;
+        g_pic_run_done = i + 1;
         void* t = mm.chem; mm.chem = mm.chem_next; mm.chem_next = t;                    // Env.step: swap_chem
         gg.step += 1u;                                                                   // the agent object's call counter
         // (the two-launch form's field kernel has left the next step's turn bits in the table; the three-launch form fills it itself)

@@ -611,14 +611,17 @@ class Env(_EnvBase):
         if not self._pic.is_current(self, agent):
             self._pic.bin(self, agent)
             action.rebind(self.agents)
-        _lib.check(self._pic.run(self, agent, action, self._c_dynamics(), results, n), 'die_pic_run')
-        agent._forward_consumed(action)
-        agent._calls += n - 1
-        if n & 1:
-            self.medium.swap_chem()
-        self.medium.owner_stale = self._mark_owner
-        self._steps += n
-        self.last_result = results[n - 1]
+        rc = self._pic.run(self, agent, action, self._c_dynamics(), results, n)
+        n = self._pic.run_done                                          # (= n unless the call failed part-way: the state reached is adopted first)
+        if n > 0:
+            agent._forward_consumed(action)
+            agent._calls += n - 1
+            if n & 1:
+                self.medium.swap_chem()
+            self.medium.owner_stale = self._mark_owner
+            self._steps += n
+            self.last_result = results[n - 1]
+        _lib.check(rc, 'die_pic_run')
         self.library_runs = getattr(self, 'library_runs', 0) + 1
         return n
 

@@ -80,7 +80,7 @@ class PicState:
         self.n_alive = int(getattr(env, '_pic_n_alive', 0) or 0)
         self.occ = torch.zeros(W * H, dtype=torch.uint8, device=dev) if 0 < self.n_alive < N else None
         self.part = torch.zeros(2 * self.NT, dtype=torch.int64, device=dev)       # reward partials | owned agents (decomposed tiles)
-        self.error = torch.zeros(2 + 32 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds
+        self.error = torch.zeros(2 + 40 * self.NT, dtype=torch.int32, device=dev)      # [0]: error word; the rest: diagnostic builds (-DPIC_STAMPS)
         i32 = lambda: torch.empty(N, dtype=torch.int32, device=dev)
         self.spare = [i32(), i32(), torch.empty(N, dtype=torch.float32, device=dev), i32(), i32()]     # x, y, agent_food, heading hi / lo
         self.spare_pg = None         # GradientAgent with inertia: the (2, N) _prev_grad array of the layout that is not current (die_pic.prev_grad)
@@ -314,7 +314,10 @@ class PicState:
         p.sub_mode, p.sub_tx0, p.sub_ty0, p.sub_ntx, p.sub_nty, p.halo_fresh = 0, 0, 0, 0, 0, 0
         m = env.medium.c_struct(need_owner=False)
         rc = _lib.lib.die_pic_run(C.byref(m), C.byref(p), self.cur, C.byref(g), C.byref(dyn), int(n), _ptr(results), stream_ptr(env.device))
-        if rc != 0:
+        # (an error behind the first step — a failed launch — leaves `done` whole steps in the stream: the state THEY reach is adopted,
+        # so that a caller who catches the exception holds a consistent Env)
+        self.run_done = n = int(n) if rc == 0 else int(_lib.lib.die_pic_run_completed())
+        if n == 0:
             return rc
         self._turn_for = (turn_key[0], (turn_key[1] + n) & 0xFFFFFFFF) if two and lazy_ok(agent) else None
         self.steps_since_check += n
@@ -324,7 +327,7 @@ class PicState:
         else:                                                  # the agents are back in the arrays they started from (new slot array)
             env.agents.slot = agent._order = held[3]
             self.held = held
-        return 0
+        return rc
 
     def check(self):
         """After a synchronisation: did every agent stay within its tile's neighbourhood?"""

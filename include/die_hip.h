@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 21
+#define DIE_ABI_VERSION 22
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -488,6 +488,11 @@ int die_pic_forward_env_step(const die_medium* m, const die_pic* p, int32_t from
  * subset of the tiles; p->turn_ready as for the first step.  Same launches, same bits as n_steps separate calls. */
 int die_pic_run(const die_medium* m, const die_pic* p, int32_t from, const die_gradient_agent* g, const die_dynamics* d,
                 int32_t n_steps, die_step_result* results, void* stream);
+/* Steps the calling thread's last die_pic_run had enqueued when it returned: n_steps on success; on an error the number of
+ * whole steps already in the stream (arguments are checked by every step, so a failure behind the first one means a failed
+ * launch) — the caller adopts the state those steps reach (layout (from + done) & 1, the chem plane roles exchanged `done`
+ * times, step counter + done) before it reports the error.  ABI 22. */
+int32_t die_pic_run_completed(void);
 /* `act` of die_pic_forward_env_step may be NULL: the action then stays in registers.  For a normalised PhysarumAgent it can
  * still be produced afterwards — until the next step overwrites p->dep — from what the step left in layout[lay] (the layout it
  * WROTE): (dx, dy) = scale * polar2xy(1, heading'), deposit = p->dep; same bits as the action the step would have stored, in
