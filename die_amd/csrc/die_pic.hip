@@ -118,7 +118,7 @@ template <> struct Vec4<__half> {
 #define PIC_KARG 1
 #endif
 #ifndef PIC_PRIO_K1
-#define PIC_PRIO_K1 0x3000      // (the waves of a starting workgroup issue their loads ahead of the resident workgroups' chunk loops: 83.5 → 81.4 µs;
+#define PIC_PRIO_K1 0x3003      // (the waves of a starting workgroup issue their loads ahead of the resident workgroups' chunk loops: 83.5 → 81.4 µs;
 #endif                          //  raising the chunk loop, or the waves that take a second chunk: worse — DESIGN §3.1)
 #ifndef PIC_PRIO_KB
 #define PIC_PRIO_KB 0x0000
