@@ -11,7 +11,7 @@ obs = env._get_current_obs
 for _ in range(40):
     obs, *_ = env.step(ag.forward(obs))
 torch.cuda.synchronize()
-raw = env._pic.error[2:].cpu().numpy().view(np.uint64).reshape(-1, 16)
+raw = env._pic.error[2:2 + 32 * env._pic.NT].cpu().numpy().view(np.uint64).reshape(-1, 16)
 st = raw[:, :6].astype(np.float64)
 d = np.diff(st, axis=1)
 names = ['tile loads issued, per-tile words, ranges', 'agent streams issued, tiles committed to LDS', 'filter arrivals + barrier', 'chunk loop (wave 0)', 'wave sum + final barrier']

@@ -12,7 +12,7 @@ for _ in range(STEPS):
     obs, *_ = env.step(ag.forward(obs))
 torch.cuda.synchronize()
 pic = env._pic
-raw = pic.error[2:].cpu().numpy().view(np.uint64).reshape(-1, 16).astype(np.float64)
+raw = pic.error[2:2 + 32 * pic.NT].cpu().numpy().view(np.uint64).reshape(-1, 16).astype(np.float64)      # (16 stamps per tile; round 6's build keeps 4 more words per tile behind them: scratch/r6_cu_timeline.py)
 n_in = pic.meta[1 - pic.cur][1].cpu().numpy().astype(np.int64)       # the layout the last step READ: agents per tile the agent kernel processed
 n_out = pic.meta[pic.cur][1].cpu().numpy().astype(np.int64)
 rim = pic.rim_cnt.cpu().numpy().astype(np.int64)
