@@ -35,7 +35,7 @@
 #include <stdlib.h>
 
 // (PIC_K2_FEED, PIC_K1_BLOCK, PIC_K2_BLOCK, PIC_STAGE_FOOD, PIC_K1_MINW: knobs of the A/B builds of scratch/build_variant.sh;
-// the values below are the measured best)
+// the values below are the measured best: LABBOOK.md, rounds 2–5)
 #ifndef PIC_K2_FEED
 #define PIC_K2_FEED 1
 #endif
@@ -47,7 +47,7 @@
 //   8 field kernel: chem window      9 field kernel: food store
 // PIC_PRIO = s_setprio around the phases that issue the long loads.
 #ifndef PIC_NT
-#define PIC_NT 0      // (3 buys the field kernel 2.5 µs at 4096² fp32 and costs the agent kernel 3–5 % at 8192² and with fp16 planes: DESIGN §3.1)
+#define PIC_NT 0      // (3 buys the field kernel 2.5 µs at 4096² fp32 and costs the agent kernel 3–5 % at 8192² and with fp16 planes: LABBOOK.md, round 3)
 #endif
 typedef uint32_t pic_u4v __attribute__((ext_vector_type(4)));
 typedef uint32_t pic_u2v __attribute__((ext_vector_type(2)));
@@ -119,7 +119,7 @@ template <> struct Vec4<__half> {
 #endif
 #ifndef PIC_PRIO_K1
 #define PIC_PRIO_K1 0x3003      // (the waves of a starting workgroup issue their loads ahead of the resident workgroups' chunk loops: 83.5 → 81.4 µs;
-#endif                          //  raising the chunk loop, or the waves that take a second chunk: worse — DESIGN §3.1)
+#endif                          //  raising the chunk loop, or the waves that take a second chunk: worse — LABBOOK.md, rounds 3 and 6)
 #ifndef PIC_PRIO_KB
 #define PIC_PRIO_KB 0x0000
 #endif
@@ -376,7 +376,7 @@ struct PicStageRows {
 #endif
 // (The first round appends up to one candidate per thread: a list shorter than the workgroup is written past its end.  A
 // round-2 experiment build with a shorter list faulted that way — most probably the `n1` run of gpurun_out/sw3_n1.err,
-// DESIGN.md §10 — hence the assertion; tests/test_gpu_parity.py::test_tile_binned_step_with_a_crowd_crossing_one_border
+// DESIGN.md §9 — hence the assertion; tests/test_gpu_parity.py::test_tile_binned_step_with_a_crowd_crossing_one_border
 // drives the rounds below beyond the first on the shipped kernel.)
 static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
 
@@ -429,7 +429,7 @@ static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is on
 #endif
 #define PIC_AT(base, type, idx) (*(type*)((char*)(base) + (size_t)(uint32_t)((uint32_t)(idx) << 2)))
 // (Two persistent forms of this kernel — a tile queue with the next tile's agents prefetched, and one 16-wave workgroup per CU with
-// LDS-DMA loader waves — were built, bit-equal, and measured slower in round 4 (96 / 101 µs against 75–81): DESIGN.md §3.1,
+// LDS-DMA loader waves — were built, bit-equal, and measured slower in round 4 (96 / 101 µs against 75–81): LABBOOK.md,
 // scratch/refuted_r04/.)
 template <typename T, int KIND, bool STAGE, bool ACT, bool RIM, bool TILED, bool MOM = false>
 // (waves per SIMD the compiler must leave room for: with fp16 planes the staged windows are 25 KB per workgroup, FOUR workgroups fit a

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(RF_BLOCK) void k_pic_ghost_halo(RfArgs a) {
     // A new segment that would end behind the arrays is not laid at all: the tile is left EMPTY (off = s = n = 0), so that the step's
     // kernels — which are already queued behind this one when the host reads the flag — never index past the arrays' end.  (Round 5's
     // development build bounded the stores below but still published off = tail[t], s, n for such a tile: the agent kernel of the step
-    // that followed then read x[tail[t] + i] beyond the allocation — the memory fault of gpurun_out/r5_t8.log, DESIGN.md §10.)
+    // that followed then read x[tail[t] + i] beyond the allocation — the memory fault of gpurun_out/r5_t8.log, DESIGN.md §9.)
     {
         uint32_t c_in = 0;
         if (k >= 0) { c_in = a.side[k].recv_counts[i]; if (c_in > a.side[k].cap) c_in = 0; }

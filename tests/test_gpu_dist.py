@@ -314,7 +314,7 @@ def test_refresh_in_place_out_of_room_fails_cleanly_on_every_rank(tmp_path, monk
     tiles' new segments do not fit behind the arrays' old end, the scan raises RF_FLAG_CAPACITY, no halo tile is laid past the end
     (such a tile is published empty), the step queued behind the refresh runs without touching memory beyond the arrays, and
     every rank raises the same clean RuntimeError.  (Round 5's development build faulted here on one rank while another raised:
-    gpurun_out/r5_t8.log, DESIGN.md §10.)"""
+    gpurun_out/r5_t8.log, DESIGN.md §9.)"""
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
     import torch.multiprocessing as mp
