@@ -582,7 +582,9 @@ def main():
         # (counts over the WHOLE run incl. the untimed per-step-event pass behind the timed steps)
         line['config'].update(steps_total_rank0=int(denv._steps), tile_binned_steps_rank0=int(getattr(denv, 'pic_steps', 0)),
                               refreshes_by_tiles_rank0=int(getattr(denv, 'tile_refreshes', 0)),
-                              refreshes_under_the_next_steps_interior_rank0=int(getattr(denv, 'overlapped_refreshes', 0)))
+                              refreshes_under_the_next_steps_interior_rank0=int(getattr(denv, 'overlapped_refreshes', 0)),
+                              refreshes_in_place_rank0=int(getattr(denv, 'inplace_refreshes', 0)),
+                              band_tiles_packed_under_the_previous_step_rank0=int(getattr(denv, 'early_packs', 0)))
         line['roofline'] = {'bound': 'hbm', 'kernel': 'whole step (all ranks)', 'achieved': round(Bw / (dt / args.steps) / 1e9, 1),
                             'peak': HBM_PEAK_GBS * world, 'unit': 'GB/s', 'frac': round(Bw / (dt / args.steps) / 1e9 / (HBM_PEAK_GBS * world), 4),
                             'traffic': None, 'algorithmic_bytes_per_launch': Bw}

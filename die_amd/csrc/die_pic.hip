@@ -443,11 +443,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     // (a starting workgroup's FIRST instructions already run at raised priority: its ≈ 300 instructions of prologue otherwise queue
     // behind the resident workgroups' chunk loops — round 6, profiles/r06_cu_timeline_4096.txt)
     if (PIC_R6 && ((PIC_PRIO_K1 >> 12) & 3) != 0) __builtin_amdgcn_s_setprio((PIC_PRIO_K1 >> 12) & 3);
-#ifndef PIC_K1_ARGS_FIRST
-#define PIC_K1_ARGS_FIRST 0     // (A/B: 1 =) every argument the prologue needs is requested with the FIRST scalar loads: the compiler otherwise loads
-#endif                          // them where they are first used — five dependent round trips (≈ 0.15 µs each on a loaded CU) ahead of the window loads
-    if (PIC_K1_ARGS_FIRST) asm volatile("" :: "s"(p.g.W), "s"(p.g.H), "s"(p.g.gW), "s"(p.g.gH), "s"(p.in.off), "s"(p.in.s), "s"(p.in.n), "s"(p.fm_r), "s"(p.fm_c),
-                                        "s"(p.mg_c), "s"(p.mg_f), "s"(p.margin), "s"(p.rp_c), "s"(p.rp_f), "s"(f.chem), "s"(p.food));
+// (Requesting every argument the prologue needs with the FIRST scalar loads changed nothing, 75.1 against 74.6–75.3 µs: the compiler
+    // re-loads them where it uses them.  LABBOOK.md, round 6.)
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
     // spilling scalar registers to vector lanes: ≈ 290 of its 1 900 vector instructions were v_readlane / v_writelane)

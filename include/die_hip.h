@@ -412,7 +412,7 @@ typedef struct die_pic {
     uint32_t* rim_cnt;           /* die_pic_tiles() words */
     int64_t* status_out;         /* two-launch form, may be NULL: the step copies *error here next to writing `result` — a caller that
                                     places it behind its die_step_result reads reward, num_alive and the error word in ONE copy (both
-                                    may be device-visible pinned host memory: one thread writes the three words with plain stores) */
+                                    may be device-visible pinned host memory: one thread writes the three words with system-scope atomic stores, so their visibility does not wait for the kernel's end) */
     /* PhysarumAgent's random turn (core/agent/gradient.py:183) on this path: one bit per slot id from a table the library
      * fills, one Philox block per 128 slots (same bits as the stand-alone forward evaluates per agent: csrc/die_rng.h
      * die_turn_word).  The field kernel of a step fills it for (g->seed, g->step + 1); a caller that steps with the same
