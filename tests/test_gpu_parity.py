@@ -642,6 +642,23 @@ def test_tile_binned_step_vs_oracle(die, case):
                                      form=case.get('form', 'two launches'))
 
 
+@pytest.mark.parametrize('shape,f16,want', [((2048, 2048), True, (5, 7)), ((2048, 2048), False, (6, 6)), ((2048, 2112), True, (6, 6)),
+                                            ((4096, 2048 + 32), True, (4, 5))])
+def test_tile_shape_the_env_picks(die, shape, f16, want):
+    """fp16 field channels take 32x128 tiles where the world divides into them (a 64-cell row of an fp16 plane is one 128-byte line;
+    round 6: +4.5 % at 4096^2, +8.5 % at 16384^2), fp32 planes 64x64; worlds those do not divide fall back along pic.TILE_SHAPES.
+    One step, on the binned path, two launches."""
+    W, H = shape
+    env = die.Env((W, H), die.Dynamics(init_agent_ratio=0.05), seed=3, max_agents='alive', sync=False,
+                  field_dtype=torch.float16 if f16 else torch.float32)
+    ag = die.PhysarumAgent(max_agents=env.agents.N, seed=3, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+    obs, res, *_ = env.step(ag.forward(env._get_current_obs))
+    assert env._pic is not None and env._pic.held is not None and (env._pic.xs, env._pic.ys) == want == tuple(env._pic_tile)
+    assert env._pic.two_launch(env, ag)
+    reward, n = env.read_result(res)
+    assert n == env.agents.N and np.isfinite(reward)
+
+
 def test_configs2_full_size_teacher_forced_step_vs_oracle(die):
     """BASELINE configs[2] at FULL size — PhysarumAgent, 4096x4096 fp32, ratio 0.15, the benchmark's parameters — on the
     benchmarked (tile-binned, two-launch) path: after four free steps (chem exists, segments hold leavers and arrivals)
@@ -1704,6 +1721,8 @@ def test_run_of_tile_binned_steps_is_one_library_call(die, kind):
     obs, res0, *_ = a_env.step(act0)
     r1 = a_env.run(a_ag, 7)
     assert a_env._pic is not None and a_env._pic.held[0] is a_env.agents.x and a_env._pic.steps_since_check >= 8
+    from die_amd import _lib
+    assert _lib.lib.die_pic_run_completed() == 7 and a_env._pic.run_done == 7      # (ABI 22: the steps the last die_pic_run of this thread had enqueued)
     obs = a_env._get_current_obs
     plain = []
     for _ in range(3):
