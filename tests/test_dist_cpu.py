@@ -233,3 +233,31 @@ def test_peer_message_layouts_of_all_ranks_fit_together(grid):
                 assert o == at
                 at += n
             assert at == sspan[p_][1]
+
+
+def test_room_test_of_the_refresh_in_place_is_a_true_bound(monkeypatch):
+    """DistEnv._inplace_room (host side of die_pic_ghost_inplace): the halo tiles' new segments hold what arrives (≤ the messages'
+    capacities) plus today's halo population = the ghosts of the previous refresh + the owned agents that drifted into the halo
+    since (≤ what that refresh sent; the capacities while that is unknown).  ADVICE r5: the owned count of the previous refresh
+    alone was no bound.  Pure host arithmetic: no GPU, no process group."""
+    from types import SimpleNamespace
+    from die_amd.dist import DistEnv
+    monkeypatch.delenv('DIE_REFRESH_IN_PLACE_FORCE', raising=False)
+    P = SimpleNamespace(caps=[1000, 1000, 500])
+    def env(capacity, owned, sent_prev=None):
+        e = SimpleNamespace(capacity=capacity, _owned=owned)
+        if sent_prev is not None:
+            e._sent_prev = sent_prev
+        return e
+    n = 10000
+    # ghosts = n - owned = 2000; arrivals <= 2500; drift <= sent_prev = 1800  ->  needs 10000 + 2500 + 2000 + 1800 = 16300
+    assert DistEnv._inplace_room(env(16300, 8000, 1800), n, P)
+    assert not DistEnv._inplace_room(env(16299, 8000, 1800), n, P)
+    # what the previous refresh sent is not known yet: the capacities stand in (2500)  ->  17000
+    assert DistEnv._inplace_room(env(17000, 8000), n, P) and not DistEnv._inplace_room(env(16999, 8000), n, P)
+    # no refresh has happened at all: every agent may be a halo agent
+    assert DistEnv._inplace_room(env(25000, None), n, P) and not DistEnv._inplace_room(env(24999, None), n, P)
+    # round 5's test (n + caps + ghosts = 14500) would have said yes here although 1800 drifters need room too
+    assert not DistEnv._inplace_room(env(14500, 8000, 1800), n, P)
+    monkeypatch.setenv('DIE_REFRESH_IN_PLACE_FORCE', '1')          # (tests only: the kernels' own guards are what is exercised then)
+    assert DistEnv._inplace_room(env(1, 8000, 1800), n, P)
