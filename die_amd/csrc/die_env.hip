@@ -244,7 +244,10 @@ __global__ __launch_bounds__(1024) void k_reduce(const long long* pa, int na, co
         if ((int)threadIdx.x < o) { sg[threadIdx.x] += sg[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { out->reward = (double)sg[0] / DIE_FIX_ONE; out->num_alive = alive_const >= 0 ? alive_const : sc[0]; }
+    if (threadIdx.x == 0) {         // (`out` may be pinned host memory a sync=True caller polls: die_common.h die_store_result_*)
+        die_store_result_f64(&out->reward, (double)sg[0] / DIE_FIX_ONE);
+        die_store_result_i64((long long*)&out->num_alive, alive_const >= 0 ? alive_const : sc[0]);
+    }
 }
 
 // ---- diffusion --------------------------------------------------------------------------
