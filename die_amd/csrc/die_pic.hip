@@ -381,8 +381,8 @@ struct PicStageRows {
 static_assert(PIC_LIST_CAP >= PIC_K1_BLOCK, "the first round of candidates is one per thread");
 
 // Diagnostic build only (-DPIC_STAMPS; scratch/pic_stamps.py): s_memtime at the phase boundaries of K1, written by lane 0
-// of wave 0 behind the error word (the caller allocates 2 + 32·tiles words: 16 64-bit stamps per tile, [0, 8) the agent
-// kernel's, [8, 16) the field kernel's).  No stamp executes in the shipped kernel.
+// of wave 0 behind the error word (the caller allocates 2 + 40·tiles words: 16 64-bit stamps per tile, [0, 8) the agent
+// kernel's, [8, 16) the field kernel's; then 4 more per tile, below).  No stamp executes in the shipped kernel.
 #if defined(PIC_STAMPS) && !defined(PIC_STAMPS_AGENTS_ONLY)
 #ifdef PIC_STAMPS_RT            // s_memrealtime: ONE 100 MHz clock for the whole GPU (s_memtime's counters are per XCD and not comparable)
 #define PIC_CLOCK "s_memrealtime"
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     // (a starting workgroup's FIRST instructions already run at raised priority: its ≈ 300 instructions of prologue otherwise queue
     // behind the resident workgroups' chunk loops — round 6, profiles/r06_cu_timeline_4096.txt)
     if (PIC_R6 && ((PIC_PRIO_K1 >> 12) & 3) != 0) __builtin_amdgcn_s_setprio((PIC_PRIO_K1 >> 12) & 3);
-// (Requesting every argument the prologue needs with the FIRST scalar loads changed nothing, 75.1 against 74.6–75.3 µs: the compiler
+    // (Requesting every argument the prologue needs with the FIRST scalar loads changed nothing, 75.1 against 74.6–75.3 µs: the compiler
     // re-loads them where it uses them.  LABBOOK.md, round 6.)
     // what die_pic_forward_env_step has checked on the host, spelled out for the compiler: the momentum / noise / graph
     // replay paths of the shared forward code and the scalar registers that feed them drop out of this kernel (it was
