@@ -512,6 +512,35 @@ def test_tile_binned_step_equals_classic_step(die, W, H, boundary, f16, tile, fo
         assert np.array_equal(a, b), name
 
 
+@pytest.mark.parametrize('W,H,tile,threads', [(128, 96, (4, 5), (64, 128, 192)), (192, 256, (6, 6), (64, 128, 320, 448))])
+def test_tile_binned_step_with_other_workgroup_sizes_of_the_agent_kernel(die, W, H, tile, threads):
+    """`die_pic.k1_threads` (DIE_PIC_THREADS): the agent kernel with 1, 2, 3, 5, 7 waves per workgroup instead of its default — the
+    chunk loop takes more trips, and the tile's last words (arrival counts, rim codes, reward partial) leave from one, two or three
+    waves (round 6: three side by side when there are that many).  Bit for bit the default size's results, dense collisions included."""
+    N = 9000
+    rs = np.random.RandomState(W + 7 * H)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.4)
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    outs = []
+    for thr in (0,) + tuple(threads):
+        env = die.Env.from_numpy(medium, agents, sort_every=0, pic=True)
+        env._pic_tile = tile
+        env._pic_k1_threads = thr
+        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        rewards = []
+        for _ in range(4):
+            obs, rew, _, _, info = env.step(ag.forward(obs))
+            rewards.append((rew, info['num_agents']))
+        assert env._pic is not None and env._pic.held[0] is env.agents.x and env._pic.k1_threads == thr
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array(rewards)))
+    for got in outs[1:]:
+        for name, a, b in zip(('medium', 'agents', 'heading', 'rewards'), outs[0], got):
+            assert np.array_equal(a, b), name
+
+
 def applied(action):
     """The action as the device applies it: displacements rounded to the Q0.32 grid of the coordinates (at most 2^-33 away
     from the float the agent computed — enough to put ≈ 1e-6 of the agents of a 4096-cell axis on the other side of a cell
