@@ -599,6 +599,9 @@ def main():
         B = algorithmic_bytes(C, K, action_stored=not lazy_action, bf=bf)
         line['config']['step_kind'] = (('tile-binned, ' + ('two' if env._pic.two_launch(env, agent) else 'three') + ' launches') if binned else 'classic') + \
             (', action kept in registers (re-derived bit-identically when read; --eager-actions stores it every step)' if lazy_action else '')
+        if binned:
+            line['config']['tile'] = [1 << env._pic.xs, 1 << env._pic.ys]
+            line['config']['order_table'] = bool(env._pic.order is not None)     # die_pic.order: crowded tiles first inside every XCD band, rebuilt every 8th step (DIE_PIC_ORDER=0: band mapping)
         if lazy_action:
             # the same loop with the action of every step stored, as round 1 did: reported beside the headline, not instead of it
             env._pic.flush_lazy()

@@ -18,7 +18,7 @@ DIE_COST_LINEAR, DIE_COST_ZERO = 0, 1
 DIE_AGENT_GRADIENT, DIE_AGENT_PHYSARUM = 0, 1
 OWNER_EPOCH_SHIFT, OWNER_EPOCH_MAX, OWNER_SLOT_MASK = 27, 31, 0x07FFFFFF
 DIFFUSE_MODES = {'wrap': 0, 'nearest': 1, 'reflect': 2, 'mirror': 3, 'constant': 4}
-ABI_VERSION = 22
+ABI_VERSION = 23
 
 
 class Medium(C.Structure):
@@ -74,8 +74,8 @@ class Pic(C.Structure):
                 ('dep', C.c_void_p), ('dep_plane', C.c_void_p), ('part_gain', C.c_void_p), ('error', C.c_void_p),
                 ('k1_threads', C.c_int32), ('stages', C.c_int32),
                 ('rim', C.c_void_p), ('rim_code', C.c_void_p), ('rim_cnt', C.c_void_p), ('status_out', C.c_void_p),
-                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('reserved3', C.c_int32),
-                ('reserved5', C.c_void_p), ('sub_mode', C.c_int32), ('sub_tx0', C.c_int32), ('sub_ty0', C.c_int32), ('sub_ntx', C.c_int32),
+                ('turn_bits', C.c_void_p), ('turn_slots', C.c_int64), ('turn_ready', C.c_int32), ('order_ready', C.c_int32),
+                ('order', C.c_void_p), ('sub_mode', C.c_int32), ('sub_tx0', C.c_int32), ('sub_ty0', C.c_int32), ('sub_ntx', C.c_int32),
                 ('sub_nty', C.c_int32), ('halo_fresh', C.c_int32), ('n_alive', C.c_int64), ('occ', C.c_void_p),
                 ('prev_grad', (C.c_void_p * 2) * 2)]
 

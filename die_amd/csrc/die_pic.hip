@@ -184,6 +184,11 @@ struct PicArgs {
     // GradientAgent with momentum (inertia ≠ 0: die_pic.prev_grad): _prev_grad in `in` order / where the step leaves it, `out` order
     const float *ipgx, *ipgy;
     float *opgx, *opgy;
+    // ORDER TABLE (die_pic.order; NULL: the band mapping of pic_xcd_tile): XCD j = linear workgroup id mod 8 takes the tile
+    // order[j·order_len + k], k = id div 8 — a permutation of band j's tiles with the crowded ones first (k_pic_order), so that the tiles
+    // that live longest do not make up a launch's tail
+    const uint16_t* order;
+    int order_len;                  // tiles per band = ntx · (nty / 8)
 };
 // Workgroups are handed to the 8 XCDs round robin (linear workgroup id modulo 8), and every XCD has its own L2.  With the plain
 // (blockIdx.y, blockIdx.x) = (tx, ty) mapping the tiles that share cache lines — the margins of their staged windows: a row of a
@@ -220,6 +225,17 @@ __device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t
         tx = (int)(r / rem); ty = (int)((wb << 3) + (r - (uint32_t)tx * rem));
     }
 #endif
+}
+
+// tile of linear workgroup L under an order table; false: no tile (a grid rounded up to whole rows, or — never, unless the table is
+// broken — an entry beyond the tiles: such a workgroup returns, the step's bookkeeping word then reports the missing tile)
+__device__ __forceinline__ bool pic_order_tile(const PicArgs& p, uint32_t L, int& tx, int& ty) {
+    const uint32_t k = L >> 3;
+    if (k >= (uint32_t)p.order_len) return false;
+    const uint32_t t = p.order[(L & 7u) * (uint32_t)p.order_len + k];
+    if (t >= (uint32_t)(p.ntx * p.nty)) return false;
+    tx = (int)(t / (uint32_t)p.nty); ty = (int)(t - (uint32_t)tx * (uint32_t)p.nty);
+    return true;
 }
 
 __device__ __forceinline__ bool pic_sub_tile(const PicArgs& p, int& tx, int& ty) {        // false: not this launch's tile
@@ -486,7 +502,8 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile of this workgroup
     int tx = (int)blockIdx.y, ty = (int)blockIdx.x;
-    if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx, 0, p.xcd_wb_mul, (uint32_t)p.nty);
+    if (p.order) { if (!pic_order_tile(p, blockIdx.y * gridDim.x + blockIdx.x, tx, ty)) return; }
+    else if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx, 0, p.xcd_wb_mul, (uint32_t)p.nty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int tile = tx * p.nty + ty;
     (void)NT;
@@ -1107,7 +1124,8 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 #ifndef PIC_XCD_MAP_KB
 #define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0, p.xcd_wb_mul, (uint32_t)p.nty);
+    if (p.order) { if (!pic_order_tile(p, (blockIdx.y - row0) * gridDim.x + blockIdx.x, tx, ty)) return; }
+    else if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0, p.xcd_wb_mul, (uint32_t)p.nty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
@@ -1349,6 +1367,61 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     PIC_STAMP(14);
 }
 
+// ---- order table (die_pic.order): which workgroup of a launch takes which tile --------------------------------------
+// One workgroup per XCD band j (pic_xcd_tile: columns [j·wb, (j + 1)·wb) of tiles, walked row of tiles by row of tiles): the band's
+// tiles sorted by the number of 8-wave rounds their population costs the agent kernel, descending, band order among equals (a stable
+// counting sort over 8 classes) — the crowded tiles, and with them the tiles whose rim lists overflow in the field kernel, start
+// first; neighbouring tiles of one class still run side by side in one L2.  n = populations of the layout the coming step reads.
+#define PIC_ORDER_BLOCK 512
+#define PIC_ORDER_PERIOD 8      // steps between two rebuilds of the table (populations drift by ≈ 3 % of a tile per step)
+__global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n, int ntx, int nty, uint16_t* order) {
+    __shared__ uint32_t s_cnt[8][PIC_ORDER_BLOCK];         // [class][thread]: tiles of that class in this thread's stretch of the band
+    __shared__ uint32_t s_first[8];                        // first place of a class
+    const int j = blockIdx.x, wb = nty >> 3, len = wb * ntx, per = (len + PIC_ORDER_BLOCK - 1) / PIC_ORDER_BLOCK;
+    const int lo = min((int)threadIdx.x * per, len), hi = min(lo + per, len);
+    auto tile_at = [&](int q) { return (q / wb) * nty + j * wb + q % wb; };
+    auto cls = [&](int t) { const uint32_t r = ((n[t] + 63u) / 64u + 7u) / 8u; return 7 - (int)min(r, 7u); };      // 0: the most crowded
+    uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = lo; q < hi; ++q) {
+        const int k = cls(tile_at(q));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c[i] += i == k ? 1u : 0u;      // (no dynamically indexed registers: they would go to scratch)
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s_cnt[i][threadIdx.x] = c[i];
+    __syncthreads();
+    {                                                       // exclusive scan of every class's row: wave w takes class w, 64 entries per trip
+        static_assert(PIC_ORDER_BLOCK / DIE_WAVE == 8, "one wave per class");
+        const int w = threadIdx.x / DIE_WAVE, lane = threadIdx.x & (DIE_WAVE - 1);
+        uint32_t run = 0;
+        for (int b = 0; b < PIC_ORDER_BLOCK; b += DIE_WAVE) {
+            const uint32_t v = s_cnt[w][b + lane];
+            uint32_t x = v;
+#pragma unroll
+            for (int o = 1; o < DIE_WAVE; o <<= 1) { const uint32_t u = __shfl_up(x, o, DIE_WAVE); if (lane >= o) x += u; }
+            s_cnt[w][b + lane] = run + x - v;
+            run += __shfl(x, DIE_WAVE - 1, DIE_WAVE);
+        }
+        if (lane == 0) s_first[w] = run;                    // (the class's total, for now)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 8; ++i) { const uint32_t v = s_first[i]; s_first[i] = run; run += v; }
+    }
+    __syncthreads();
+    uint32_t at[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) at[i] = s_first[i] + s_cnt[i][threadIdx.x];
+    for (int q = lo; q < hi; ++q) {
+        const int t = tile_at(q), k = cls(t);
+        uint32_t place = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) if (i == k) { place = at[i]; at[i] += 1u; }
+        order[(size_t)j * len + place] = (uint16_t)t;
+    }
+}
+
 // ---- (re)binning: any order of the agent arrays → a layout with every agent a stayer ---------------------------
 struct PicBinArgs {
     die_geo g;
@@ -1562,6 +1635,7 @@ static void launch_resolve(const PicArgs& k, float* dep_plane, int NT, bool f32,
 
 template <typename T, bool STAGE, bool RIM, bool TILED = false>
 static void launch_forward_move(int kind, const FwdArgs& f, const PicArgs& k, int NT, int block, size_t lds, hipStream_t s, bool mom = false) {
+    // (an order table covers exactly the tiles: 8 · order_len = ntx · nty workgroups, the same grid)
     const dim3 grid(k.sub_mode == 1 ? k.sub_nty : k.nty, k.sub_mode == 1 ? k.sub_ntx : k.ntx);
     if constexpr (!TILED) {
         if (kind != DIE_AGENT_PHYSARUM && mom) {
@@ -1656,6 +1730,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     k.halo_fresh = m->gW > 0 ? p->halo_fresh : 0;
     const bool keep_pg = mom && g->inertia != 0.f;
     k.ipgx = keep_pg ? pg_in[0] : nullptr; k.ipgy = keep_pg ? pg_in[1] : nullptr; k.opgx = keep_pg ? pg_out[0] : nullptr; k.opgy = keep_pg ? pg_out[1] : nullptr;
+    k.order = nullptr; k.order_len = 0;
     DIE_REQUIRE(p->sub_mode >= 0 && p->sub_mode <= 2, "die_pic_forward_env_step: sub_mode %d", p->sub_mode);
     if (p->sub_mode) {
         DIE_REQUIRE(p->stages == 1 || p->stages == 2, "die_pic_forward_env_step: a subset of the tiles is one launch (stages 1 or 2), not a whole step");
@@ -1731,6 +1806,13 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
             const int64_t blocks = (turn_words / 4 + DIE_BLOCK - 1) / DIE_BLOCK;
             k_turn_bits<<<(int)(blocks < 1024 ? blocks : 1024), DIE_BLOCK, 0, s>>>(p->turn_bits, turn_words, g->seed, g->step);
         }
+    }
+    // the order table (die_pic.order): both kernels of the two-launch form take their tiles from it; rebuilt from the populations of the
+    // layout this step reads before its agent kernel — the first time, and every PIC_ORDER_PERIOD-th step
+    if (p->order && two && !tiled && !p->sub_mode && (k.nty & 7) == 0 && NT <= 65536) {
+        k.order = p->order; k.order_len = NT >> 3;
+        if ((stages & 1) && (!p->order_ready || (g->step % PIC_ORDER_PERIOD) == 0))
+            k_pic_order<<<8, PIC_ORDER_BLOCK, 0, s>>>(k.in.n, k.ntx, k.nty, p->order);
     }
     if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s, mom); \
@@ -1845,6 +1927,7 @@ extern "C" int die_pic_run(const die_medium* m, const die_pic* p, int32_t from, 
         gg.step += 1u;                                                                   // the agent object's call counter
         // (the two-launch form's field kernel has left the next step's turn bits in the table; the three-launch form fills it itself)
         pp.turn_ready = 1;
+        pp.order_ready = 1;                                                              // (the first step has built the order table)
     }
     return DIE_OK;
 }

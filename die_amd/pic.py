@@ -75,6 +75,12 @@ class PicState:
         self.turn_slots = max(N, int(getattr(env, 'world_agents', 0) or 0))
         self.turn_bits = torch.zeros(4 * ((self.turn_slots + 127) // 128), dtype=torch.int32, device=dev)
         self._turn_for = None
+        # the order table of the two-launch form's workgroups (include/die_hip.h `die_pic.order`): crowded tiles first inside every XCD
+        # band, rebuilt by the library every 8th step; an undivided world whose tiles per row divide by 8 (else the band mapping)
+        nty = H >> self.ys
+        self.order = torch.zeros(self.NT, dtype=torch.int16, device=dev) \
+            if (self.fused and env.medium.world is None and nty % 8 == 0 and self.NT <= 65536 and os.environ.get('DIE_PIC_ORDER', '1') != '0') else None
+        self._order_ready = False
         # the reference's default slot layout (max_agents = W·H: most slots never lived): the alive agents in the tiles' segments,
         # the dead slots behind them (include/die_hip.h `die_pic.n_alive`); `occ`: this step's occupancy map (a byte per cell) for their feeding
         self.n_alive = int(getattr(env, '_pic_n_alive', 0) or 0)
@@ -120,7 +126,7 @@ class PicState:
             lay[1 - cur] = self._layout(ot, self.meta[1 - cur])
             p = self._structs[key] = _lib.Pic(self.xs, self.ys, self._n_agents, (_lib.PicLayout * 2)(*lay), _ptr(self.dep), _ptr(self._dep_plane),
                                               _ptr(self.part), _ptr(self.error), self.k1_threads, stages, _ptr(self.rim), _ptr(self.rim_code),
-                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, None, 0, 0, 0, 0, 0, 0,
+                                              _ptr(self.rim_cnt), status_out, _ptr(self.turn_bits), self.turn_slots, 0, 0, _ptr(self.order), 0, 0, 0, 0, 0, 0,
                                               self.n_alive if self.occ is not None else 0, _ptr(self.occ))
             for lay_i, t in ((cur, ct[6]), (1 - cur, ot[6])):
                 for axis in (0, 1):
@@ -274,6 +280,7 @@ class PicState:
             p = self._struct(self.held, out, stages, status_out if two else None)
             p.halo_fresh = int(item[2]) if len(item) > 2 else 0      # (the agent kernel behind a refresh in place: die_pic_ghost_inplace)
             p.turn_ready = int(self._turn_for == turn_key)
+            p.order_ready = int(self._order_ready)
             p.sub_mode, p.sub_tx0, p.sub_ty0, p.sub_ntx, p.sub_nty = sub if sub is not None else (0, 0, 0, 0, 0)
             if events is not None:
                 events[i].record()
@@ -284,6 +291,8 @@ class PicState:
                 return rc
             if (stages & 1 or stages == 0) and lazy_ok(agent):
                 self._turn_for = turn_key                      # (the agent kernel's launch has filled the table if it was not ready)
+            if (stages & 1 or stages == 0) and two and sub is None and self.order is not None:
+                self._order_ready = True                       # (that launch has built the order table if it was not there)
         if events is not None:
             events[2 if two else 3].record()
         # (the field kernel of the two-launch form has filled the table for the next step of this seed)
@@ -311,6 +320,7 @@ class PicState:
         two = self.two_launch(env, agent)
         p = self._struct(held, out, 0, None)
         p.turn_ready = int(self._turn_for == turn_key)
+        p.order_ready = int(self._order_ready)
         p.sub_mode, p.sub_tx0, p.sub_ty0, p.sub_ntx, p.sub_nty, p.halo_fresh = 0, 0, 0, 0, 0, 0
         m = env.medium.c_struct(need_owner=False)
         rc = _lib.lib.die_pic_run(C.byref(m), C.byref(p), self.cur, C.byref(g), C.byref(dyn), int(n), _ptr(results), stream_ptr(env.device))
@@ -320,6 +330,8 @@ class PicState:
         if n == 0:
             return rc
         self._turn_for = (turn_key[0], (turn_key[1] + n) & 0xFFFFFFFF) if two and lazy_ok(agent) else None
+        if two and self.order is not None:
+            self._order_ready = True
         self.steps_since_check += n
         if n & 1:
             self.cur = 1 - self.cur

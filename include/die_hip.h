@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DIE_ABI_VERSION 22
+#define DIE_ABI_VERSION 23
 
 typedef enum die_status {
     DIE_OK = 0,
@@ -420,8 +420,17 @@ typedef struct die_pic {
     uint32_t* turn_bits;         /* 4 * ceil(turn_slots / 128) words */
     int64_t turn_slots;          /* slot ids are < turn_slots (>= N; a decomposed world: the world's slot count) */
     int32_t turn_ready;          /* the table already holds the bits of (g->seed, g->step) */
-    int32_t reserved3;
-    void* reserved5;             /* (ABI 20: the tile queue of a persistent form of the agent kernel — measured slower, removed) */
+    /* ORDER TABLE of the two-launch form's workgroups (ABI 23; may be NULL: workgroup id -> tile by XCD bands of columns, as before).
+     * order[j * (tiles / 8) + k] = the tile the k-th workgroup of XCD j takes (linear workgroup id = 8 k + j): a permutation of band j's
+     * tiles, written by the library (k_pic_order: crowded tiles first, band order among equals) from the populations of the layout a
+     * step reads — when order_ready == 0 and every 8th step (g->step % 8 == 0).  Only WHICH workgroup takes a tile changes, never a
+     * result.  Late in a run, when the agents have aggregated (tiles of 3 000 agents beside tiles of 100), the crowded tiles — and the
+     * tiles whose rim lists overflow — no longer make up a launch's tail: 166 -> 144 us per step at world step 3 000 of the benchmark
+     * world (round 6).  Used when tiles-per-row % 8 == 0, tiles <= 65 536, an undivided world, all tiles in one launch; ignored otherwise.
+     * The caller allocates die_pic_tiles() 16-bit words and sets order_ready = 1 once a step has run with them (the table stays a valid
+     * permutation across re-binning: it is only stale then). */
+    int32_t order_ready;
+    uint16_t* order;
     /* ONE launch (stages = 1 or 2) over a subset of the tiles: sub_mode 0 all tiles; 1 only the rectangle [sub_tx0, sub_tx0 +
      * sub_ntx) x [sub_ty0, sub_ty0 + sub_nty) of tiles; 2 all tiles but that rectangle — and, for stages = 2, the workgroups that
      * complete a step (next offsets, reward, turn bits).  A decomposed rank steps the tiles that need nothing from its neighbours

@@ -541,6 +541,52 @@ def test_tile_binned_step_with_other_workgroup_sizes_of_the_agent_kernel(die, W,
             assert np.array_equal(a, b), name
 
 
+def test_order_table_of_the_two_launch_form(die, monkeypatch):
+    """die_pic.order (round 6): which workgroup takes which tile — crowded tiles first inside every XCD band, rebuilt by the library
+    every 8th step from the populations of the layout a step reads.  The table must be a permutation of every band's tiles, sorted by
+    the 8-wave rounds a tile costs (descending, band order among equals), and must change no result: the same world stepped with
+    DIE_PIC_ORDER=0 (band mapping) gives the same bits.  A crowd in one corner makes the classes differ."""
+    W, H, tile = 128, 512, (4, 5)                             # 8 x 16 tiles: two columns of tiles per XCD band
+    N = 30000
+    rs = np.random.RandomState(5)
+    medium, agents = random_state(W, H, N, N, rs, collide=0.2)
+    agents[0, :12000] = rs.uniform(0.02, 0.2, 12000)          # a crowd: tiles of > 512 agents beside tiles of ~ 100
+    agents[1, :12000] = rs.uniform(0.02, 0.15, 12000)
+    agents[:2] = q32(agents[:2])
+    turn = np.radians(30)
+    dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
+    outs = []
+    for use in ('1', '0'):
+        monkeypatch.setenv('DIE_PIC_ORDER', use)
+        env = die.Env.from_numpy(medium, agents, sort_every=0, pic=True)
+        env._pic_tile = tile
+        ag = die.PhysarumAgent(max_agents=N, seed=5, scale=1.53 / (max(W, H) - 1), sense_offset=10.2 / (max(W, H) - 1))
+        ag.set_state(dir0)
+        obs = env._get_current_obs
+        rewards = []
+        for i in range(10):                                   # (the agent's step counter passes a multiple of 8: a rebuild mid-run)
+            obs, rew, _, _, info = env.step(ag.forward(obs))
+            rewards.append((rew, info['num_agents']))
+        pic = env._pic
+        assert pic is not None and pic.held[0] is env.agents.x and pic.two_launch(env, ag)
+        if use == '1':
+            assert pic.order is not None and pic._order_ready
+            # the table as the last rebuild left it (step counter 8: the populations of the layout step 8 read) against the rule
+            order = pic.order.cpu().numpy().astype(np.int64) & 0xFFFF
+            ntx, nty = W >> tile[0], H >> tile[1]
+            wb, per = nty // 8, ntx * (nty // 8)
+            for j in range(8):
+                band = [(q // wb) * nty + j * wb + q % wb for q in range(per)]
+                got = order[j * per:(j + 1) * per].tolist()
+                assert sorted(got) == sorted(band), f'band {j}: not a permutation of its tiles'
+            assert len(set(order.tolist())) == ntx * nty
+        else:
+            assert pic.order is None
+        outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array(rewards)))
+    for name, a, b in zip(('medium', 'agents', 'heading', 'rewards'), outs[0], outs[1]):
+        assert np.array_equal(a, b), name
+
+
 def applied(action):
     """The action as the device applies it: displacements rounded to the Q0.32 grid of the coordinates (at most 2^-33 away
     from the float the agent computed — enough to put ≈ 1e-6 of the agents of a 4096-cell axis on the other side of a cell
