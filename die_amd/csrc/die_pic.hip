@@ -1373,14 +1373,22 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 // counting sort over 8 classes) — the crowded tiles, and with them the tiles whose rim lists overflow in the field kernel, start
 // first; neighbouring tiles of one class still run side by side in one L2.  n = populations of the layout the coming step reads.
 #define PIC_ORDER_BLOCK 512
+#ifndef PIC_ORDER_PERIOD
 #define PIC_ORDER_PERIOD 8      // steps between two rebuilds of the table (populations drift by ≈ 3 % of a tile per step)
+#endif
 __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n, int ntx, int nty, uint16_t* order) {
     __shared__ uint32_t s_cnt[8][PIC_ORDER_BLOCK];         // [class][thread]: tiles of that class in this thread's stretch of the band
     __shared__ uint32_t s_first[8];                        // first place of a class
     const int j = blockIdx.x, wb = nty >> 3, len = wb * ntx, per = (len + PIC_ORDER_BLOCK - 1) / PIC_ORDER_BLOCK;
     const int lo = min((int)threadIdx.x * per, len), hi = min(lo + per, len);
     auto tile_at = [&](int q) { return (q / wb) * nty + j * wb + q % wb; };
-    auto cls = [&](int t) { const uint32_t r = ((n[t] + 63u) / 64u + 7u) / 8u; return 7 - (int)min(r, 7u); };      // 0: the most crowded
+#ifndef PIC_ORDER_RMIN
+#define PIC_ORDER_RMIN 0        // A/B: tiles of at most this many rounds count as one class (band order among them) …
+#endif
+#ifndef PIC_ORDER_RMAX
+#define PIC_ORDER_RMAX 7        // … and so do tiles of at least this many
+#endif
+    auto cls = [&](int t) { const uint32_t r = ((n[t] + 63u) / 64u + 7u) / 8u; return 7 - (int)min(max(r, (uint32_t)PIC_ORDER_RMIN), (uint32_t)PIC_ORDER_RMAX); };      // 0: the most crowded
     uint32_t c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = lo; q < hi; ++q) {
         const int k = cls(tile_at(q));
