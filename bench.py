@@ -601,7 +601,7 @@ def main():
             (', action kept in registers (re-derived bit-identically when read; --eager-actions stores it every step)' if lazy_action else '')
         if binned:
             line['config']['tile'] = [1 << env._pic.xs, 1 << env._pic.ys]
-            line['config']['order_table'] = bool(env._pic.order is not None)     # die_pic.order: crowded tiles first inside every XCD band, rebuilt every 8th step (DIE_PIC_ORDER=0: band mapping)
+            line['config']['order_table'] = bool(env._pic.order is not None)     # die_pic.order: crowded tiles first inside every XCD band, rebuilt every 32nd step (DIE_PIC_ORDER=0: band mapping)
         if lazy_action:
             # the same loop with the action of every step stored, as round 1 did: reported beside the headline, not instead of it
             env._pic.flush_lazy()

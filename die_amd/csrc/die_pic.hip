@@ -229,10 +229,26 @@ __device__ __forceinline__ void pic_xcd_tile(int& tx, int& ty, int ntx, uint32_t
 
 // tile of linear workgroup L under an order table; false: no tile (a grid rounded up to whole rows, or — never, unless the table is
 // broken — an entry beyond the tiles: such a workgroup returns, the step's bookkeeping word then reports the missing tile)
-__device__ __forceinline__ bool pic_order_tile(const PicArgs& p, uint32_t L, int& tx, int& ty) {
+// Only the last PIC_ORDER_SPAN tiles of a band are ever out of band order (k_pic_order): workgroups ahead of them map by arithmetic
+// (`use_table` false: the caller takes pic_xcd_tile), the others read ONE table entry — by a SCALAR load of the 32-bit word that holds
+// it: as a 16-bit vector load the lookup put a vector-memory round trip (1–2 µs on a loaded CU) in front of every workgroup's first
+// loads, which cost an 8192² / 16384² world 2–3 % where the order buys little.
+#define PIC_ORDER_SPAN 512
+// (Both kernels follow the table.  In a world without crowds the field kernel is ≈ 2 µs slower as soon as the AGENT kernel follows it —
+// whatever its own order: measured with the field kernel in band order, 64.3 against 62.1 µs, and following the table too, 63.4 — while
+// the agent kernel gains 1–3 µs; with crowds the field kernel gains 14 µs: 82 → 68 µs at world step 3 000, tiles whose rim lists overflow.)
+__device__ __forceinline__ uint32_t pic_sload(const uint32_t* a) {
+    uint32_t w;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(a) : "memory");
+    return w;
+}
+__device__ __forceinline__ bool pic_order_tile(const PicArgs& p, uint32_t L, int& tx, int& ty, bool& use_table) {
     const uint32_t k = L >> 3;
+    use_table = k + (uint32_t)PIC_ORDER_SPAN >= (uint32_t)p.order_len;
+    if (!use_table) return true;
     if (k >= (uint32_t)p.order_len) return false;
-    const uint32_t t = p.order[(L & 7u) * (uint32_t)p.order_len + k];
+    const uint32_t e = (L & 7u) * (uint32_t)p.order_len + k;
+    const uint32_t t = (pic_sload((const uint32_t*)p.order + (e >> 1)) >> ((e & 1u) * 16u)) & 0xFFFFu;
     if (t >= (uint32_t)(p.ntx * p.nty)) return false;
     tx = (int)(t / (uint32_t)p.nty); ty = (int)(t - (uint32_t)tx * (uint32_t)p.nty);
     return true;
@@ -502,8 +518,9 @@ __global__ __launch_bounds__(PIC_K1_BLOCK, (sizeof(T) == 2 ? PIC_K1_MINW_F16 : P
     const int FR = p.fm_r, FC = p.fm_c, fpitch = TY + 2 * FC, frows = TX + 2 * FR;
     // the tile of this workgroup
     int tx = (int)blockIdx.y, ty = (int)blockIdx.x;
-    if (p.order) { if (!pic_order_tile(p, blockIdx.y * gridDim.x + blockIdx.x, tx, ty)) return; }
-    else if (p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx, 0, p.xcd_wb_mul, (uint32_t)p.nty);
+    bool by_table = false;
+    if (p.order && !pic_order_tile(p, blockIdx.y * (uint32_t)p.nty + blockIdx.x, tx, ty, by_table)) return;
+    if (!by_table && p.sub_mode == 0) pic_xcd_tile(tx, ty, p.ntx, 0, p.xcd_wb_mul, (uint32_t)p.nty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int tile = tx * p.nty + ty;
     (void)NT;
@@ -1124,8 +1141,9 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 #ifndef PIC_XCD_MAP_KB
 #define PIC_XCD_MAP_KB 1        // 2: bands walked from their far end (does an XCD's L2 keep the agent kernel's last tiles across the kernel boundary? no: same counters)
 #endif
-    if (p.order) { if (!pic_order_tile(p, (blockIdx.y - row0) * gridDim.x + blockIdx.x, tx, ty)) return; }
-    else if (PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0, p.xcd_wb_mul, (uint32_t)p.nty);
+    bool by_table = false;
+    if (p.order && !pic_order_tile(p, (blockIdx.y - row0) * (uint32_t)p.nty + blockIdx.x, tx, ty, by_table)) return;
+    if (!by_table && PIC_XCD_MAP_KB && p.sub_mode == 0) pic_xcd_tile<PIC_XCD_MAP_KB == 2>(tx, ty, p.ntx, row0, p.xcd_wb_mul, (uint32_t)p.nty);
     if (!pic_sub_tile(p, tx, ty)) return;
     const int x0 = tx << XS, y0 = ty << YS;
     const int W = p.g.W, H = p.g.H;
@@ -1374,14 +1392,25 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 // first; neighbouring tiles of one class still run side by side in one L2.  n = populations of the layout the coming step reads.
 #define PIC_ORDER_BLOCK 512
 #ifndef PIC_ORDER_PERIOD
-#define PIC_ORDER_PERIOD 8      // steps between two rebuilds of the table (populations drift by ≈ 3 % of a tile per step)
+#define PIC_ORDER_PERIOD 32     // steps between two rebuilds of the table (an agent walks 3/4 of a tile meanwhile; 8 / 16 / 32: the same rates, the rebuild is 4.8 µs + a kernel boundary)
 #endif
+// Only the LAST PIC_ORDER_SPAN tiles of a band are sorted; the tiles ahead of them keep the band order.  What matters is that no crowded
+// tile sits in a launch's last rounds — a crowded tile in the middle of a launch delays nobody —, and tiles that are neighbours in space
+// should stay neighbours in time (they share the margins of their windows in one L2): with their bands of 2 048 / 8 192 tiles sorted as
+// a whole, or span by span, an 8192² / 16384² world LOST 2–3 % at the bench's window, where the 512-tile bands of 4096² gained.
 __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n, int ntx, int nty, uint16_t* order) {
-    __shared__ uint32_t s_cnt[8][PIC_ORDER_BLOCK];         // [class][thread]: tiles of that class in this thread's stretch of the band
+    __shared__ uint32_t s_cnt[8][PIC_ORDER_BLOCK];         // [class][thread]: tiles of that class in this thread's stretch of the span
     __shared__ uint32_t s_first[8];                        // first place of a class
-    const int j = blockIdx.x, wb = nty >> 3, len = wb * ntx, per = (len + PIC_ORDER_BLOCK - 1) / PIC_ORDER_BLOCK;
-    const int lo = min((int)threadIdx.x * per, len), hi = min(lo + per, len);
+    const int j = blockIdx.x, wb = nty >> 3, blen = wb * ntx;
+    // spans are counted from the band's END: the last one is whole, the first one takes what is left
+    const int q1 = blen - (int)(gridDim.y - 1 - blockIdx.y) * PIC_ORDER_SPAN, q0 = max(q1 - PIC_ORDER_SPAN, 0), len = q1 - q0;
+    const int per = (len + PIC_ORDER_BLOCK - 1) / PIC_ORDER_BLOCK;
+    const int lo = q0 + min((int)threadIdx.x * per, len), hi = min(lo + per, q0 + len);
     auto tile_at = [&](int q) { return (q / wb) * nty + j * wb + q % wb; };
+    if (blockIdx.y + 1 != gridDim.y) {                      // not the band's last span: band order
+        for (int q = lo; q < hi; ++q) order[(size_t)j * blen + q] = (uint16_t)tile_at(q);
+        return;
+    }
 #ifndef PIC_ORDER_RMIN
 #define PIC_ORDER_RMIN 0        // A/B: tiles of at most this many rounds count as one class (band order among them) …
 #endif
@@ -1426,7 +1455,7 @@ __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n
         uint32_t place = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) if (i == k) { place = at[i]; at[i] += 1u; }
-        order[(size_t)j * len + place] = (uint16_t)t;
+        order[(size_t)j * blen + q0 + place] = (uint16_t)t;
     }
 }
 
@@ -1820,7 +1849,7 @@ extern "C" int die_pic_forward_env_step(const die_medium* m, const die_pic* p, i
     if (p->order && two && !tiled && !p->sub_mode && (k.nty & 7) == 0 && NT <= 65536) {
         k.order = p->order; k.order_len = NT >> 3;
         if ((stages & 1) && (!p->order_ready || (g->step % PIC_ORDER_PERIOD) == 0))
-            k_pic_order<<<8, PIC_ORDER_BLOCK, 0, s>>>(k.in.n, k.ntx, k.nty, p->order);
+            k_pic_order<<<dim3(8, ((NT >> 3) + PIC_ORDER_SPAN - 1) / PIC_ORDER_SPAN), PIC_ORDER_BLOCK, 0, s>>>(k.in.n, k.ntx, k.nty, p->order);
     }
     if (stages & 1) {
 #define DIE_PIC_K1(T, STAGE, LDS) do { if (two) launch_forward_move<T, STAGE, true>(g->kind, f, k, NT, block, LDS, s, mom); \

@@ -76,7 +76,7 @@ class PicState:
         self.turn_bits = torch.zeros(4 * ((self.turn_slots + 127) // 128), dtype=torch.int32, device=dev)
         self._turn_for = None
         # the order table of the two-launch form's workgroups (include/die_hip.h `die_pic.order`): crowded tiles first inside every XCD
-        # band, rebuilt by the library every 8th step; an undivided world whose tiles per row divide by 8 (else the band mapping)
+        # band, rebuilt by the library every 32nd step; an undivided world whose tiles per row divide by 8 (else the band mapping)
         nty = H >> self.ys
         self.order = torch.zeros(self.NT, dtype=torch.int16, device=dev) \
             if (self.fused and env.medium.world is None and nty % 8 == 0 and self.NT <= 65536 and os.environ.get('DIE_PIC_ORDER', '1') != '0') else None

@@ -423,12 +423,12 @@ typedef struct die_pic {
     /* ORDER TABLE of the two-launch form's workgroups (ABI 23; may be NULL: workgroup id -> tile by XCD bands of columns, as before).
      * order[j * (tiles / 8) + k] = the tile the k-th workgroup of XCD j takes (linear workgroup id = 8 k + j): a permutation of band j's
      * tiles, written by the library (k_pic_order: crowded tiles first, band order among equals) from the populations of the layout a
-     * step reads — when order_ready == 0 and every 8th step (g->step % 8 == 0).  Only WHICH workgroup takes a tile changes, never a
+     * step reads — when order_ready == 0 and every 32nd step (g->step % 32 == 0).  Only WHICH workgroup takes a tile changes, never a
      * result.  Late in a run, when the agents have aggregated (tiles of 3 000 agents beside tiles of 100), the crowded tiles — and the
      * tiles whose rim lists overflow — no longer make up a launch's tail: 166 -> 144 us per step at world step 3 000 of the benchmark
      * world (round 6).  Used when tiles-per-row % 8 == 0, tiles <= 65 536, an undivided world, all tiles in one launch; ignored otherwise.
-     * The caller allocates die_pic_tiles() 16-bit words and sets order_ready = 1 once a step has run with them (the table stays a valid
-     * permutation across re-binning: it is only stale then). */
+     * The caller allocates die_pic_tiles() 16-bit words (4-byte aligned) and sets order_ready = 1 once a step has run with them (the
+     * table stays a valid permutation across re-binning: it is only stale then). */
     int32_t order_ready;
     uint16_t* order;
     /* ONE launch (stages = 1 or 2) over a subset of the tiles: sub_mode 0 all tiles; 1 only the rectangle [sub_tx0, sub_tx0 +

@@ -541,17 +541,17 @@ def test_tile_binned_step_with_other_workgroup_sizes_of_the_agent_kernel(die, W,
             assert np.array_equal(a, b), name
 
 
-def test_order_table_of_the_two_launch_form(die, monkeypatch):
-    """die_pic.order (round 6): which workgroup takes which tile — crowded tiles first inside every XCD band, rebuilt by the library
-    every 8th step from the populations of the layout a step reads.  The table must be a permutation of every band's tiles, sorted by
+@pytest.mark.parametrize('W,H,N', [(128, 512, 30000), (1536, 2048, 120000)])
+def test_order_table_of_the_two_launch_form(die, monkeypatch, W, H, N):
+    """die_pic.order (round 6): which workgroup takes which tile — crowded tiles first in the last span of every XCD band, rebuilt by the
+    library every 32nd step from the populations of the layout a step reads.  The table must be a permutation of every band's tiles, sorted by
     the 8-wave rounds a tile costs (descending, band order among equals), and must change no result: the same world stepped with
     DIE_PIC_ORDER=0 (band mapping) gives the same bits.  A crowd in one corner makes the classes differ."""
-    W, H, tile = 128, 512, (4, 5)                             # 8 x 16 tiles: two columns of tiles per XCD band
-    N = 30000
-    rs = np.random.RandomState(5)
+    tile = (4, 5)                                             # 8 x 16 tiles: two columns of tiles per XCD band; 96 x 64 tiles: bands of 768
+    rs = np.random.RandomState(5)                             # tiles, of which the last 512 are sorted (k_pic_order: PIC_ORDER_SPAN)
     medium, agents = random_state(W, H, N, N, rs, collide=0.2)
-    agents[0, :12000] = rs.uniform(0.02, 0.2, 12000)          # a crowd: tiles of > 512 agents beside tiles of ~ 100
-    agents[1, :12000] = rs.uniform(0.02, 0.15, 12000)
+    agents[0, :12000] = rs.uniform(0.02, 0.2, 12000) * 128 / W          # a crowd: tiles of > 512 agents beside tiles of ~ 100
+    agents[1, :12000] = rs.uniform(0.02, 0.15, 12000) * 512 / H
     agents[:2] = q32(agents[:2])
     turn = np.radians(30)
     dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
@@ -564,14 +564,14 @@ def test_order_table_of_the_two_launch_form(die, monkeypatch):
         ag.set_state(dir0)
         obs = env._get_current_obs
         rewards = []
-        for i in range(10):                                   # (the agent's step counter passes a multiple of 8: a rebuild mid-run)
+        for i in range(35):                                   # (the agent's step counter passes a multiple of 32: a rebuild mid-run)
             obs, rew, _, _, info = env.step(ag.forward(obs))
             rewards.append((rew, info['num_agents']))
         pic = env._pic
         assert pic is not None and pic.held[0] is env.agents.x and pic.two_launch(env, ag)
         if use == '1':
             assert pic.order is not None and pic._order_ready
-            # the table as the last rebuild left it (step counter 8: the populations of the layout step 8 read) against the rule
+            # the table as the last rebuild left it (step counter 32: the populations of the layout that step read) against the rule
             order = pic.order.cpu().numpy().astype(np.int64) & 0xFFFF
             ntx, nty = W >> tile[0], H >> tile[1]
             wb, per = nty // 8, ntx * (nty // 8)
@@ -579,6 +579,9 @@ def test_order_table_of_the_two_launch_form(die, monkeypatch):
                 band = [(q // wb) * nty + j * wb + q % wb for q in range(per)]
                 got = order[j * per:(j + 1) * per].tolist()
                 assert sorted(got) == sorted(band), f'band {j}: not a permutation of its tiles'
+                # only the band's last 512 tiles are sorted (what must not hold a crowded tile is a launch's tail); the tiles ahead keep the band order
+                assert got[:max(per - 512, 0)] == band[:max(per - 512, 0)], f'band {j}: the tiles ahead of the last span'
+                assert sorted(got[-512:]) == sorted(band[-512:]), f'band {j}: the last span'
             assert len(set(order.tolist())) == ntx * nty
         else:
             assert pic.order is None
