@@ -1411,6 +1411,9 @@ __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n
         for (int q = lo; q < hi; ++q) order[(size_t)j * blen + q] = (uint16_t)tile_at(q);
         return;
     }
+#ifndef PIC_ORDER_MIN_CROWDED
+#define PIC_ORDER_MIN_CROWDED 8 // tiles of four and more rounds in a band's last span from which the span is sorted (A/B: 0 = always)
+#endif
 #ifndef PIC_ORDER_RMIN
 #define PIC_ORDER_RMIN 0        // A/B: tiles of at most this many rounds count as one class (band order among them) …
 #endif
@@ -1442,6 +1445,16 @@ __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n
         if (lane == 0) s_first[w] = run;                    // (the class's total, for now)
     }
     __syncthreads();
+    // A span without crowds stays in band order: sorting costs the L2 sharing of neighbouring tiles' windows (counted traffic of a step
+    // 567 → 613 MB at the bench's window, for 1–2 µs of a shorter tail) and pays once tiles of four and more rounds — more than 1 536
+    // agents: where the agent kernel's workgroups live longest and the field kernel's rim lists overflow — could end up in the tail
+    // (world step 200: 31 such tiles of 4 096; step 1 000: 227; step 8 000: 105; profiles/r06_tile_populations_over_a_run.txt).
+    const bool sorted = s_first[0] + s_first[1] + s_first[2] + s_first[3] >= (uint32_t)PIC_ORDER_MIN_CROWDED;
+    __syncthreads();
+    if (!sorted) {
+        for (int q = lo; q < hi; ++q) order[(size_t)j * blen + q] = (uint16_t)tile_at(q);
+        return;
+    }
     if (threadIdx.x == 0) {
         uint32_t run = 0;
         for (int i = 0; i < 8; ++i) { const uint32_t v = s_first[i]; s_first[i] = run; run += v; }

@@ -550,8 +550,11 @@ def test_order_table_of_the_two_launch_form(die, monkeypatch, W, H, N):
     tile = (4, 5)                                             # 8 x 16 tiles: two columns of tiles per XCD band; 96 x 64 tiles: bands of 768
     rs = np.random.RandomState(5)                             # tiles, of which the last 512 are sorted (k_pic_order: PIC_ORDER_SPAN)
     medium, agents = random_state(W, H, N, N, rs, collide=0.2)
-    agents[0, :12000] = rs.uniform(0.02, 0.2, 12000) * 128 / W          # a crowd: tiles of > 512 agents beside tiles of ~ 100
-    agents[1, :12000] = rs.uniform(0.02, 0.15, 12000) * 512 / H
+    # a crowd in the LAST rows of tiles of the first XCD band: tiles of ~ 2 000 agents (four 8-wave rounds and more: what makes
+    # k_pic_order sort a band's last span) beside tiles of ~ 100
+    nc, xr, yr = (16000, (0.52, 0.98), (0.005, 0.115)) if W == 128 else (40000, (0.905, 0.995), (0.001, 0.029))
+    agents[0, :nc] = rs.uniform(*xr, nc)
+    agents[1, :nc] = rs.uniform(*yr, nc)
     agents[:2] = q32(agents[:2])
     turn = np.radians(30)
     dir0 = f32(np.floor(rs.uniform(-np.pi, np.pi, N) / turn) * turn)
@@ -564,15 +567,16 @@ def test_order_table_of_the_two_launch_form(die, monkeypatch, W, H, N):
         ag.set_state(dir0)
         obs = env._get_current_obs
         rewards = []
+        order = None
         for i in range(35):                                   # (the agent's step counter passes a multiple of 32: a rebuild mid-run)
             obs, rew, _, _, info = env.step(ag.forward(obs))
             rewards.append((rew, info['num_agents']))
+            if i == 0 and env._pic.order is not None:         # the table as the first step built it, from the initial populations (the crowd disperses)
+                order = env._pic.order.cpu().numpy().astype(np.int64) & 0xFFFF
         pic = env._pic
         assert pic is not None and pic.held[0] is env.agents.x and pic.two_launch(env, ag)
         if use == '1':
-            assert pic.order is not None and pic._order_ready
-            # the table as the last rebuild left it (step counter 32: the populations of the layout that step read) against the rule
-            order = pic.order.cpu().numpy().astype(np.int64) & 0xFFFF
+            assert pic.order is not None and pic._order_ready and order is not None
             ntx, nty = W >> tile[0], H >> tile[1]
             wb, per = nty // 8, ntx * (nty // 8)
             for j in range(8):
@@ -583,6 +587,8 @@ def test_order_table_of_the_two_launch_form(die, monkeypatch, W, H, N):
                 assert got[:max(per - 512, 0)] == band[:max(per - 512, 0)], f'band {j}: the tiles ahead of the last span'
                 assert sorted(got[-512:]) == sorted(band[-512:]), f'band {j}: the last span'
             assert len(set(order.tolist())) == ntx * nty
+            moved = [j for j in range(8) if order[j * per:(j + 1) * per].tolist() != [(q // wb) * nty + j * wb + q % wb for q in range(per)]]
+            assert 0 in moved and len(moved) < 8, f'bands out of band order: {moved} (the crowded one should be, the empty ones not)'
         else:
             assert pic.order is None
         outs.append((env.medium.to_numpy(), env.agents.to_numpy(), ag.direction_rads_numpy(), np.array(rewards)))
