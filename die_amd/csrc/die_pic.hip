@@ -1240,19 +1240,36 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
         return uc == 0xFFu ? 0xFFFFFFFFu : (uint32_t)(ri + m);
     };
     // a tile whose list overflowed: every agent of its segment that stands in the window (for d itself: its leavers only)
+    // (Crowded tiles — 3 000 agents and more on a tile once the trails have formed, rim lists long overflowed — lived 60 µs here and WERE the
+    // field kernel's duration at world step 3 000: one agent per thread and trip, coordinates → cell → slot → deposit one dependent round
+    // trip after the other.  PIC_KB_U agents per thread and trip, all their loads requested before the first is used: round 6.)
+#ifndef PIC_KB_U
+#define PIC_KB_U 4
+#endif
     auto scan_segment = [&](int l, bool apply) {
         const uint32_t lo = l == 0 ? own0 + nown : s_off[l], hi = s_off[l] + s_n[l];
-        for (uint32_t j = lo + threadIdx.x; j < hi; j += BLOCK) {
-            const int cx = pic_row<TILED>(p.g, p.out.x[j]), cy = pic_col<TILED>(p.g, p.out.y[j]);
-            int rr = cx - x0, rc = cy - y0;                 // periodic distance to the tile's origin
-            rr = rr > W / 2 ? rr - W : (rr < -(W / 2) ? rr + W : rr);
-            rc = rc > H / 2 ? rc - H : (rc < -(H / 2) ? rc + H : rc);
-            if (rr < -R || rr >= TX + R || rc < -R || rc >= TY + R) continue;
-            const uint32_t widx = (uint32_t)((rr + R) * WC + rc + R), s1 = p.out.slot[j] + 1u;
-            if (!apply) atomicMax(&s_claim[widx], s1);
-            else if (s_claim[widx] == s1) {
-                float* c = &s_chem[(rr + R) * CP + rc + A];
-                *c = die_as_stored<T>(*c + p.dep[j]);
+        for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += PIC_KB_U * BLOCK) {
+            uint32_t X[PIC_KB_U], Y[PIC_KB_U], S[PIC_KB_U], D[PIC_KB_U];
+#pragma unroll
+            for (int u = 0; u < PIC_KB_U; ++u) {
+                const uint32_t j = j0 + (uint32_t)u * BLOCK;
+                X[u] = Y[u] = S[u] = D[u] = 0u;
+                if (j < hi) { X[u] = p.out.x[j]; Y[u] = p.out.y[j]; S[u] = p.out.slot[j]; if (apply) D[u] = __float_as_uint(p.dep[j]); }
+            }
+#pragma unroll
+            for (int u = 0; u < PIC_KB_U; ++u) {
+                if (j0 + (uint32_t)u * BLOCK >= hi) continue;
+                const int cx = pic_row<TILED>(p.g, X[u]), cy = pic_col<TILED>(p.g, Y[u]);
+                int rr = cx - x0, rc = cy - y0;             // periodic distance to the tile's origin
+                rr = rr > W / 2 ? rr - W : (rr < -(W / 2) ? rr + W : rr);
+                rc = rc > H / 2 ? rc - H : (rc < -(H / 2) ? rc + H : rc);
+                if (rr < -R || rr >= TX + R || rc < -R || rc >= TY + R) continue;
+                const uint32_t widx = (uint32_t)((rr + R) * WC + rc + R), s1 = S[u] + 1u;
+                if (!apply) atomicMax(&s_claim[widx], s1);
+                else if (s_claim[widx] == s1) {
+                    float* c = &s_chem[(rr + R) * CP + rc + A];
+                    *c = die_as_stored<T>(*c + __uint_as_float(D[u]));
+                }
             }
         }
     };
@@ -1296,9 +1313,20 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
             if (cw[u] != 0xFFFFFFFFu) atomicMax(&s_claim[cw[u] & 0xFFFFu], cs[u]);
         }
     }
-    for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
-        const uint32_t j = own0 + i, w_ = window_cell(p.out.x[j], p.out.y[j], 0, 0);
-        if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_ & 0xFFFFu], p.out.slot[j] + 1u);
+    for (uint32_t i0 = threadIdx.x + 2 * BLOCK; i0 < nown; i0 += PIC_KB_U * BLOCK) {         // (tiles of more than 1 024 stayers)
+        uint32_t X[PIC_KB_U], Y[PIC_KB_U], S[PIC_KB_U];
+#pragma unroll
+        for (int u = 0; u < PIC_KB_U; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * BLOCK, j = own0 + i;
+            X[u] = Y[u] = S[u] = 0u;
+            if (i < nown) { X[u] = p.out.x[j]; Y[u] = p.out.y[j]; S[u] = p.out.slot[j]; }
+        }
+#pragma unroll
+        for (int u = 0; u < PIC_KB_U; ++u) {
+            if (i0 + (uint32_t)u * BLOCK >= nown) continue;
+            const uint32_t w_ = window_cell(X[u], Y[u], 0, 0);
+            if (w_ != 0xFFFFFFFFu) atomicMax(&s_claim[w_ & 0xFFFFu], S[u] + 1u);
+        }
     }
     if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, false);
     PIC_STAMP(10);
@@ -1313,9 +1341,17 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
     };
 #pragma unroll
     for (int u = 0; u < 2 + NE; ++u) deposit(cw[u], cs[u], cd[u]);
-    for (uint32_t i = threadIdx.x + 2 * BLOCK; i < nown; i += BLOCK) {
-        const uint32_t j = own0 + i;
-        deposit(window_cell(p.out.x[j], p.out.y[j], 0, 0), p.out.slot[j] + 1u, __float_as_uint(p.dep[j]));
+    for (uint32_t i0 = threadIdx.x + 2 * BLOCK; i0 < nown; i0 += PIC_KB_U * BLOCK) {
+        uint32_t X[PIC_KB_U], Y[PIC_KB_U], S[PIC_KB_U], D[PIC_KB_U];
+#pragma unroll
+        for (int u = 0; u < PIC_KB_U; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * BLOCK, j = own0 + i;
+            X[u] = Y[u] = S[u] = D[u] = 0u;
+            if (i < nown) { X[u] = p.out.x[j]; Y[u] = p.out.y[j]; S[u] = p.out.slot[j]; D[u] = __float_as_uint(p.dep[j]); }
+        }
+#pragma unroll
+        for (int u = 0; u < PIC_KB_U; ++u)
+            if (i0 + (uint32_t)u * BLOCK < nown) deposit(window_cell(X[u], Y[u], 0, 0), S[u] + 1u, D[u]);
     }
     if (over) for (int l = 0; l < 9; ++l) if (over >> l & 1u) scan_segment(l, true);
     if (!a.food_infinite) {
