@@ -1437,6 +1437,7 @@ __global__ __launch_bounds__((KbShape<XS, YS>::BLOCK), PIC_KB_MINW) void k_pic_r
 __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n, int ntx, int nty, uint16_t* order) {
     __shared__ uint32_t s_cnt[8][PIC_ORDER_BLOCK];         // [class][thread]: tiles of that class in this thread's stretch of the span
     __shared__ uint32_t s_first[8];                        // first place of a class
+    __shared__ uint32_t s_crowded;                         // tiles of four and more rounds in all eight bands' last spans
     const int j = blockIdx.x, wb = nty >> 3, blen = wb * ntx;
     // spans are counted from the band's END: the last one is whole, the first one takes what is left
     const int q1 = blen - (int)(gridDim.y - 1 - blockIdx.y) * PIC_ORDER_SPAN, q0 = max(q1 - PIC_ORDER_SPAN, 0), len = q1 - q0;
@@ -1448,7 +1449,7 @@ __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n
         return;
     }
 #ifndef PIC_ORDER_MIN_CROWDED
-#define PIC_ORDER_MIN_CROWDED 8 // tiles of four and more rounds in a band's last span from which the span is sorted (A/B: 0 = always)
+#define PIC_ORDER_MIN_CROWDED 96 // tiles of four and more rounds, per 4 096 tiles of the eight bands' last spans TOGETHER, from which every band's span is sorted (A/B: 0 = always)
 #endif
 #ifndef PIC_ORDER_RMIN
 #define PIC_ORDER_RMIN 0        // A/B: tiles of at most this many rounds count as one class (band order among them) …
@@ -1481,12 +1482,24 @@ __global__ __launch_bounds__(PIC_ORDER_BLOCK) void k_pic_order(const uint32_t* n
         if (lane == 0) s_first[w] = run;                    // (the class's total, for now)
     }
     __syncthreads();
-    // A span without crowds stays in band order: sorting costs the L2 sharing of neighbouring tiles' windows (counted traffic of a step
-    // 567 → 613 MB at the bench's window, for 1–2 µs of a shorter tail) and pays once tiles of four and more rounds — more than 1 536
-    // agents: where the agent kernel's workgroups live longest and the field kernel's rim lists overflow — could end up in the tail
-    // (world step 200: 31 such tiles of 4 096; step 1 000: 227; step 8 000: 105; profiles/r06_tile_populations_over_a_run.txt).
-    const bool sorted = s_first[0] + s_first[1] + s_first[2] + s_first[3] >= (uint32_t)PIC_ORDER_MIN_CROWDED;
+    // Spans without crowds stay in band order: sorting costs the L2 sharing of neighbouring tiles' windows (counted traffic of a step
+    // 567 → 613 MB at the bench's window) and pays once enough tiles of four and more rounds — more than 1 536 agents: where the agent
+    // kernel's workgroups live longest and the field kernel's rim lists overflow — could end up in the tail.  The bench world, 32-step
+    // runs without / with every band sorted (profiles/r06_order_table_shipped.txt): 79–90 such tiles (world steps 416–544) 134.4 / 136.1 µs
+    // a step; 105–138 (steps 704–832) 140–147 / 141–139; 237–251 (steps 1 024–1 152) 145 / 138; 234 (step 3 000) 160 / 138.5.
+    // All eight bands sort, or none: a launch lasts as long as its slowest band, so a band sorted next to one left alone pays the
+    // sorting's cost without its gain (a threshold per band: −1…−1.7 % at world steps 400–700, where some bands passed it).  Every
+    // band's workgroup therefore counts the crowded tiles of all eight last spans itself (8 × 512 populations, out of L2).
+    if (threadIdx.x == 0) s_crowded = 0;
     __syncthreads();
+    {
+        uint32_t cr = 0;
+        for (int jj = 0; jj < 8; ++jj)
+            for (int q = lo; q < hi; ++q) cr += ((n[(q / wb) * nty + jj * wb + q % wb] + 63u) / 64u + 7u) / 8u >= 4u ? 1u : 0u;
+        if (cr) atomicAdd(&s_crowded, cr);
+    }
+    __syncthreads();
+    const bool sorted = (uint64_t)s_crowded * 4096u >= (uint64_t)PIC_ORDER_MIN_CROWDED * 8u * (uint32_t)len;
     if (!sorted) {
         for (int q = lo; q < hi; ++q) order[(size_t)j * blen + q] = (uint16_t)tile_at(q);
         return;
