@@ -23,7 +23,7 @@ for upto in starts:
         crowded = int((-(-(-(-n // 64)) // 8) >= 4).sum())
         moved = '-'
         if pic.order is not None:
-            o = pic.order.cpu().numpy().astype(np.int64) & 0xFFFF
+            o = (pic.order.cpu().numpy().astype(np.int64) & 0xFFFF)[:pic.NT]
             ntx, nty = W >> pic.xs, W >> pic.ys
             wb, per = nty // 8, ntx * (nty // 8)
             moved = sum(o[j * per:(j + 1) * per].tolist() != [(q // wb) * nty + j * wb + q % wb for q in range(per)] for j in range(8))
